@@ -1,0 +1,206 @@
+"""CPU oracle (test infrastructure): the Karras schedule, preconditioner and solver loops.
+
+Restates /root/reference/k_diffusion/sampling.py and layers.py:70-90 in plain torch on the CPU.
+Pinned against the real reference by tests/test_oracle_vs_golden.py (known answers recorded by
+oracle/make_golden.py).  ``model`` is any callable ``model(x, sigma[B], **extra) -> denoised``.
+
+The solver arithmetic is written with explicit 0-dim fp32 tensors in the same operation order as
+the reference so that results are bit-identical on the CPU.
+"""
+import math
+
+import torch
+
+
+def sigmas_karras(n, sigma_min, sigma_max, rho=7.0):
+    """sampling.py:17-23 (+ append_zero :13-14).  fp32 ramp, python-double scalar powers."""
+    ramp = torch.linspace(0, 1, n)
+    lo, hi = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
+    s = (hi + ramp * (lo - hi)) ** rho
+    return torch.cat([s, s.new_zeros([1])])
+
+
+def sigmas_exponential(n, sigma_min, sigma_max):
+    """sampling.py:26-29."""
+    s = torch.linspace(math.log(sigma_max), math.log(sigma_min), n).exp()
+    return torch.cat([s, s.new_zeros([1])])
+
+
+def sigmas_polyexponential(n, sigma_min, sigma_max, rho=1.0):
+    """sampling.py:32-36."""
+    ramp = torch.linspace(1, 0, n) ** rho
+    s = torch.exp(ramp * (math.log(sigma_max) - math.log(sigma_min)) + math.log(sigma_min))
+    return torch.cat([s, s.new_zeros([1])])
+
+
+def sigmas_vp(n, beta_d=19.9, beta_min=0.1, eps_s=1e-3):
+    """sampling.py:39-43."""
+    t = torch.linspace(1, eps_s, n)
+    s = torch.sqrt(torch.exp(beta_d * t ** 2 / 2 + beta_min * t) - 1)
+    return torch.cat([s, s.new_zeros([1])])
+
+
+def _bc(v, x):
+    return v.reshape(v.shape + (1,) * (x.ndim - v.ndim)) if torch.is_tensor(v) and v.ndim else v
+
+
+def to_d(x, sigma, denoised):
+    """sampling.py:46-48."""
+    return (x - denoised) / _bc(sigma, x)
+
+
+def ancestral_step(sigma_from, sigma_to, eta=1.0):
+    """sampling.py:51-58."""
+    if not eta:
+        return sigma_to, 0.0
+    up = min(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    down = (sigma_to ** 2 - up ** 2) ** 0.5
+    return down, up
+
+
+def karras_scalings(sigma, sigma_data):
+    """layers.py:70-74 -> (c_skip, c_out, c_in)."""
+    var = sigma ** 2 + sigma_data ** 2
+    return sigma_data ** 2 / var, sigma * sigma_data / var ** 0.5, 1 / var ** 0.5
+
+
+def denoiser(inner, sigma_data):
+    """layers.py:88-90 as a closure: D(x, sigma) = F(x * c_in, sigma) * c_out + x * c_skip."""
+    def model(x, sigma, **kw):
+        c_skip, c_out, c_in = (_bc(c, x) for c in karras_scalings(sigma, sigma_data))
+        return inner(x * c_in, sigma, **kw) * c_out + x * c_skip
+    return model
+
+
+def _report(callback, x, i, sigma, sigma_hat, denoised):
+    if callback is not None:
+        callback({"x": x, "i": i, "sigma": sigma, "sigma_hat": sigma_hat, "denoised": denoised})
+
+
+def _churn(x, sigmas, i, s_churn, s_tmin, s_tmax, s_noise):
+    """sampling.py:123-127 (shared by euler/heun/dpm_2).  Always draws eps (RNG parity)."""
+    gamma = min(s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= sigmas[i] <= s_tmax else 0.0
+    eps = torch.randn_like(x) * s_noise
+    sigma_hat = sigmas[i] * (gamma + 1)
+    if gamma > 0:
+        x = x + eps * (sigma_hat ** 2 - sigmas[i] ** 2) ** 0.5
+    return x, sigma_hat
+
+
+def sample_euler(model, x, sigmas, extra_args=None, callback=None, s_churn=0.0, s_tmin=0.0,
+                 s_tmax=float("inf"), s_noise=1.0):
+    """sampling.py:117-135."""
+    extra = extra_args or {}
+    ones = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        x, sigma_hat = _churn(x, sigmas, i, s_churn, s_tmin, s_tmax, s_noise)
+        den = model(x, sigma_hat * ones, **extra)
+        d = to_d(x, sigma_hat, den)
+        _report(callback, x, i, sigmas[i], sigma_hat, den)
+        x = x + d * (sigmas[i + 1] - sigma_hat)
+    return x
+
+
+def sample_heun(model, x, sigmas, extra_args=None, callback=None, s_churn=0.0, s_tmin=0.0,
+                s_tmax=float("inf"), s_noise=1.0):
+    """sampling.py:158-184."""
+    extra = extra_args or {}
+    ones = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        x, sigma_hat = _churn(x, sigmas, i, s_churn, s_tmin, s_tmax, s_noise)
+        den = model(x, sigma_hat * ones, **extra)
+        d = to_d(x, sigma_hat, den)
+        _report(callback, x, i, sigmas[i], sigma_hat, den)
+        dt = sigmas[i + 1] - sigma_hat
+        if sigmas[i + 1] == 0:
+            x = x + d * dt
+        else:
+            x_2 = x + d * dt
+            den_2 = model(x_2, sigmas[i + 1] * ones, **extra)
+            d_2 = to_d(x_2, sigmas[i + 1], den_2)
+            x = x + ((d + d_2) / 2) * dt
+    return x
+
+
+def sample_dpmpp_2m(model, x, sigmas, extra_args=None, callback=None):
+    """sampling.py:584-607."""
+    extra = extra_args or {}
+    ones = x.new_ones([x.shape[0]])
+    t_of = lambda s: s.log().neg()
+    s_of = lambda t: t.neg().exp()
+    old = None
+    for i in range(len(sigmas) - 1):
+        den = model(x, sigmas[i] * ones, **extra)
+        _report(callback, x, i, sigmas[i], sigmas[i], den)
+        t, t_next = t_of(sigmas[i]), t_of(sigmas[i + 1])
+        h = t_next - t
+        if old is None or sigmas[i + 1] == 0:
+            x = (s_of(t_next) / s_of(t)) * x - (-h).expm1() * den
+        else:
+            r = (t - t_of(sigmas[i - 1])) / h
+            den_d = (1 + 1 / (2 * r)) * den - (1 / (2 * r)) * old
+            x = (s_of(t_next) / s_of(t)) * x - (-h).expm1() * den_d
+        old = den
+    return x
+
+
+def sample_dpmpp_sde(model, x, sigmas, noise_sampler, extra_args=None, callback=None, eta=1.0,
+                     s_noise=1.0, r=0.5):
+    """sampling.py:542-581 with an explicit ``noise_sampler(sigma, sigma_next)``."""
+    extra = extra_args or {}
+    ones = x.new_ones([x.shape[0]])
+    t_of = lambda s: s.log().neg()
+    s_of = lambda t: t.neg().exp()
+    for i in range(len(sigmas) - 1):
+        den = model(x, sigmas[i] * ones, **extra)
+        _report(callback, x, i, sigmas[i], sigmas[i], den)
+        if sigmas[i + 1] == 0:
+            x = x + to_d(x, sigmas[i], den) * (sigmas[i + 1] - sigmas[i])
+            continue
+        t, t_next = t_of(sigmas[i]), t_of(sigmas[i + 1])
+        h = t_next - t
+        s = t + h * r
+        fac = 1 / (2 * r)
+        sd, su = ancestral_step(s_of(t), s_of(s), eta)
+        s_ = t_of(sd)
+        x_2 = (s_of(s_) / s_of(t)) * x - (t - s_).expm1() * den
+        x_2 = x_2 + noise_sampler(s_of(t), s_of(s)) * s_noise * su
+        den_2 = model(x_2, s_of(s) * ones, **extra)
+        sd, su = ancestral_step(s_of(t), s_of(t_next), eta)
+        t_next_ = t_of(sd)
+        den_d = (1 - fac) * den + fac * den_2
+        x = (s_of(t_next_) / s_of(t)) * x - (t - t_next_).expm1() * den_d
+        x = x + noise_sampler(s_of(t), s_of(t_next)) * s_noise * su
+    return x
+
+
+def lms_coeff(order, t, i, j):
+    """sampling.py:247-257."""
+    from scipy import integrate
+    if order - 1 > i:
+        raise ValueError(f"Order {order} too high for step {i}")
+
+    def basis(tau):
+        p = 1.0
+        for k in range(order):
+            if k != j:
+                p *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+        return p
+    return integrate.quad(basis, t[i], t[i + 1], epsrel=1e-4)[0]
+
+
+def sample_lms(model, x, sigmas, extra_args=None, callback=None, order=4):
+    """sampling.py:260-277."""
+    extra = extra_args or {}
+    ones = x.new_ones([x.shape[0]])
+    t = sigmas.detach().cpu().numpy()
+    hist = []
+    for i in range(len(sigmas) - 1):
+        den = model(x, sigmas[i] * ones, **extra)
+        hist.append(to_d(x, sigmas[i], den))
+        hist = hist[-order:]
+        _report(callback, x, i, sigmas[i], sigmas[i], den)
+        cur = min(i + 1, order)
+        cs = [lms_coeff(cur, t, i, j) for j in range(cur)]
+        x = x + sum(c * d for c, d in zip(cs, reversed(hist)))
+    return x

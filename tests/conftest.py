@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    from safetensors.torch import load_file
+    import json
+    from tests.golden import cases
+    gd = cases.GOLDEN_DIR
+    out = {"kat": json.load(open(os.path.join(gd, "kat.json")))}
+    for name in ("ops", "forward", "samples"):
+        out[name] = load_file(os.path.join(gd, name + ".safetensors"))
+    return out
+
+
+@pytest.fixture(scope="session")
+def K():
+    import k_diffusion_amd
+    return k_diffusion_amd

@@ -1,0 +1,173 @@
+"""Pins the CPU oracle (oracle/*.py) against outputs of the REAL reference recorded in
+tests/golden/ by oracle/make_golden.py.  CPU only.  Tolerances: bit-exact for schedules, scalar
+coefficients and solver arithmetic on analytic denoisers; 2e-5 max-norm relative for network ops
+(fp32 summation-order noise); the na2d core itself is parity-unpinned (NATTEN absent)."""
+import struct
+
+import pytest
+import torch
+
+from oracle import hdit, solvers
+from tests.golden import cases
+
+
+def unhex(lst):
+    return torch.tensor([struct.unpack(">f", bytes.fromhex(h))[0] for h in lst], dtype=torch.float32)
+
+
+def bits(t):
+    return t.detach().contiguous().view(torch.int32)
+
+
+def relerr(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def load_cfg(name):
+    # minimal independent restatement of config.py:58-146's v2 defaulting, for the oracle only
+    cfg = cases.raw_config(name)
+    m = cfg["model"]
+    m.setdefault("mapping_width", 256)
+    m.setdefault("mapping_depth", 2)
+    m["mapping_d_ff"] = m.get("mapping_d_ff") or 3 * m["mapping_width"]
+    m["d_ffs"] = m.get("d_ffs") or [3 * w for w in m["widths"]]
+    if not m.get("self_attns"):
+        n = len(m["widths"])
+        m["self_attns"] = [{"type": "neighborhood", "d_head": 64, "kernel_size": 7}] * (n - 1) + [{"type": "global", "d_head": 64}]
+    return cfg
+
+
+def oracle_state_dict(cfg):
+    """Synthetic weights for the oracle: shapes derived from the config (no reference needed)."""
+    from tests.helpers import state_dict_shapes
+    shapes = state_dict_shapes(cfg)
+    return {k: cases.synth.synth_tensor(k, s, cases.WEIGHT_SEED,
+                                        template=hdit.rope_freqs(s[0]) if k.endswith("pos_emb.freqs") else None)
+            for k, s in shapes.items()}
+
+
+def test_sigma_schedules_bit_exact(golden):
+    kat = golden["kat"]
+    for key, hx in kat["sigmas_karras"].items():
+        n, lo, hi, rho = key.split(",")
+        got = solvers.sigmas_karras(int(n), float(lo), float(hi), float(rho))
+        assert torch.equal(bits(got), bits(unhex(hx))), key
+    assert torch.equal(bits(solvers.sigmas_exponential(12, 0.01, 80)), bits(unhex(kat["sigmas_exponential"]["12,0.01,80"])))
+    assert torch.equal(bits(solvers.sigmas_polyexponential(12, 0.01, 80, 2.0)), bits(unhex(kat["sigmas_polyexponential"]["12,0.01,80,2.0"])))
+    assert torch.equal(bits(solvers.sigmas_vp(12)), bits(unhex(kat["sigmas_vp"]["12"])))
+    # SURVEY.md section 8(a) a1 known answers
+    s = solvers.sigmas_karras(50, 1e-2, 80)
+    assert [f"{v:08x}" for v in bits(s[:3]).tolist()] == ["429ffffe", "42902fec", "4281bbba"]
+
+
+def test_scalar_helpers_bit_exact(golden):
+    kat = golden["kat"]
+    for key, hx in kat["ancestral_step"].items():
+        a, b, eta = (float(v) for v in key.split(","))
+        sd, su = solvers.ancestral_step(torch.tensor(a), torch.tensor(b), eta)
+        assert torch.equal(bits(torch.stack([torch.as_tensor(sd), torch.as_tensor(su)])), bits(unhex(hx))), key
+    for s, hx in kat["scalings_sd0.5"].items():
+        got = torch.stack(solvers.karras_scalings(torch.tensor(float(s)), 0.5))
+        assert torch.equal(bits(got), bits(unhex(hx))), s
+    for key, hx in kat["axial_pos"].items():
+        h, w = (int(v) for v in key.split("x"))
+        assert torch.equal(bits(hdit.axial_pos(h, w).reshape(-1)), bits(unhex(hx))), key
+    for nh, hx in kat["rope_freqs"].items():
+        assert torch.equal(bits(hdit.rope_freqs(int(nh)).reshape(-1)), bits(unhex(hx))), nh
+
+
+def test_solver_known_answers_bit_exact(golden):
+    kat = golden["kat"]
+    model = lambda x, sigma, **kw: 0.5 * x
+    sig = solvers.sigmas_karras(10, 1e-2, 80)
+    x0 = torch.full([1, 1, 2, 2], 3.0)
+    for name in ["sample_euler", "sample_heun", "sample_dpmpp_2m", "sample_lms"]:
+        got = getattr(solvers, name)(model, x0, sig)[0, 0, 0, 0]
+        assert torch.equal(bits(got.reshape(1)), bits(unhex(kat["solver_half_x"][name]))), name
+    toy = lambda x, sigma, **kw: torch.tanh(x) / (1 + sigma.view(-1, 1, 1, 1))
+    xt = torch.randn(2, 3, 4, 4, generator=torch.Generator().manual_seed(3)) * 80
+    sig20 = solvers.sigmas_karras(20, 1e-2, 80)
+    for name in ["sample_euler", "sample_heun", "sample_dpmpp_2m", "sample_lms"]:
+        got = getattr(solvers, name)(toy, xt, sig20)
+        assert torch.equal(bits(got.reshape(-1)), bits(unhex(kat["solver_toy"][name]))), name
+    torch.manual_seed(123)
+    got = solvers.sample_euler(toy, xt, sig20, s_churn=10.0)
+    assert torch.equal(bits(got.reshape(-1)), bits(unhex(kat["solver_toy_euler_churn"])))
+    it = iter(cases.recorded_noise(tuple(xt.shape), 64, seed=77))
+    got = solvers.sample_dpmpp_sde(toy, xt, sig20, noise_sampler=lambda a, b: next(it))
+    assert torch.equal(bits(got.reshape(-1)), bits(unhex(kat["solver_toy_sde_recorded"])))
+
+
+def test_ops_vs_reference(golden):
+    o = golden["ops"]
+    x = o["rms_norm.x"]
+    assert relerr(hdit.rms_norm(x, o["rms_norm.scale"]), o["rms_norm.y"]) < 1e-6
+    assert relerr(hdit.ada_rms_norm(x, o["adarms.cond"], o["adarms.w"]), o["adarms.y"]) < 2e-6
+    assert relerr(hdit.linear_geglu(x, o["geglu.w"]), o["geglu.y"]) < 2e-6
+    q, k = hdit.cosine_sim_scale(o["qk.q"], o["qk.k"], o["qk.scale"])
+    pos = hdit.axial_pos(16, 16)
+    theta = hdit.rope_theta(pos, hdit.rope_freqs(2))
+    assert torch.equal(theta, o["qk.theta"])
+    q, k = hdit.apply_rope(q, theta), hdit.apply_rope(k, theta)
+    assert relerr(q, o["qk.q_out"]) < 1e-6 and relerr(k, o["qk.k_out"]) < 1e-6
+    assert relerr(hdit.attn_global(q, k, o["qk.v"]), o["attn_global.o"]) < 1e-5
+    for shift in (0, 4):
+        assert relerr(hdit.attn_shifted_window(q, k, o["qk.v"], 8, shift), o[f"attn_window{shift}.o"]) < 1e-5, shift
+    got = hdit.attn_shifted_window(o["attn_window_rect.q"], o["attn_window_rect.k"], o["attn_window_rect.v"], 8, 4)
+    assert relerr(got, o["attn_window_rect.o"]) < 1e-5
+    assert relerr(hdit.token_merge(x, o["merge.w"], 2, 2), o["merge.y"]) < 2e-6
+    up = hdit.token_split(x, o["split.w"], 2, 2)
+    assert relerr(torch.lerp(o["split.skip"], up, torch.tensor([0.37])), o["split.y"]) < 2e-6
+
+
+def test_na2d_properties():
+    """na2d is parity-unpinned; check the defining properties instead."""
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(1, 9, 12, 2, 64, generator=g) for _ in range(3))
+    out = hdit.na2d(q, k, v, 7, 0.3)
+    # brute force per query
+    for (i, j) in [(0, 0), (4, 6), (8, 11), (1, 10), (7, 2)]:
+        si, sj = min(max(i - 3, 0), 9 - 7), min(max(j - 3, 0), 12 - 7)
+        kk = k[0, si:si + 7, sj:sj + 7].reshape(49, 2, 64)
+        vv = v[0, si:si + 7, sj:sj + 7].reshape(49, 2, 64)
+        p = torch.softmax(torch.einsum("he,khe->hk", q[0, i, j], kk) * 0.3, dim=-1)
+        ref = torch.einsum("hk,khe->he", p, vv)
+        assert torch.allclose(out[0, i, j], ref, atol=1e-5)
+    # a 7x7 image with kernel 7 is global attention
+    q, k, v = (torch.randn(2, 7, 7, 1, 64, generator=g) for _ in range(3))
+    assert torch.allclose(hdit.na2d(q, k, v, 7, 1.0), hdit.attn_global(q, k, v, 1.0), atol=1e-5)
+    with pytest.raises(ValueError):
+        hdit.na2d(q[:, :4], k[:, :4], v[:, :4], 7)
+
+
+@pytest.mark.parametrize("case,cfgname,batch,sigmas", cases.FORWARD_CASES)
+def test_forward_vs_reference(golden, case, cfgname, batch, sigmas):
+    cfg = load_cfg(cfgname)
+    sd = oracle_state_dict(cfg)
+    x, sigma, cls = cases.forward_inputs(cfg, batch, sigmas)
+    y = hdit.forward(sd, cfg["model"], x, sigma, class_cond=cls)
+    assert relerr(y, golden["forward"][case + ".inner"]) < 2e-5
+    den = solvers.denoiser(lambda xx, s, **kw: hdit.forward(sd, cfg["model"], xx, s, **kw), cfg["model"]["sigma_data"])
+    kw = {"class_cond": cls} if cls is not None else {}
+    assert relerr(den(x, sigma, **kw), golden["forward"][case + ".denoised"]) < 2e-5
+
+
+SMALL_SAMPLE_CASES = [c for c in cases.SAMPLE_CASES if c[1].startswith("tiny") or c[1] in ("mnist", "flowers_sw")]
+
+
+@pytest.mark.parametrize("case,cfgname,sampler,steps,batch", SMALL_SAMPLE_CASES)
+def test_sampling_vs_reference(golden, case, cfgname, sampler, steps, batch):
+    cfg = load_cfg(cfgname)
+    mc = cfg["model"]
+    sd = oracle_state_dict(cfg)
+    den = solvers.denoiser(lambda xx, s, **kw: hdit.forward(sd, mc, xx, s, **kw), mc["sigma_data"])
+    x, cls = cases.sample_inputs(cfg, batch)
+    extra = {"class_cond": cls} if cls is not None else {}
+    sigmas = solvers.sigmas_karras(steps, mc["sigma_min"], mc["sigma_max"])
+    kw = {}
+    if sampler == "sample_dpmpp_sde":
+        it = iter(cases.recorded_noise(tuple(x.shape), 2 * steps, seed=77))
+        kw["noise_sampler"] = lambda a, b: next(it)
+    torch.manual_seed(0)
+    y = getattr(solvers, sampler)(den, x, sigmas, extra_args=extra, **kw)
+    assert relerr(y, golden["samples"][case]) < 1e-4
