@@ -1,0 +1,159 @@
+/*
+ * kdiff_hip.h -- C ABI of libkdiff_hip.so: the MI355X (gfx950) kernels behind the k-diffusion
+ * sampling hot path.
+ *
+ * The reference (crowsonkb/k-diffusion) is pure Python and has no FFI of its own; what this ABI
+ * replaces are the reference's *native call sites* -- the third-party CUDA extensions and the
+ * torch.compile'd functions it calls on the hot path.  Each entry point cites the reference
+ * interface it stands in for (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every buffer (device memory);
+ *   - nothing here allocates, frees or synchronises; every launch goes to `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream);
+ *   - return value: 0 on success, negative KD_E* on a rejected call (bad shape / alignment /
+ *     unsupported size); kd_last_error() then describes it.  Nothing throws;
+ *   - activations are token-major ("NHWC"): [batch, h, w, channels] row-major fp32;
+ *     qkv buffers are [batch*h*w, 3, n_heads, 64] (feature index t*(nh*64) + head*64 + e,
+ *     k_diffusion/models/image_transformer_v2.py:386,422,431,467); head dim is fixed at 64
+ *     (every shipped config, k_diffusion/config.py:135-136).
+ */
+#ifndef KDIFF_HIP_H
+#define KDIFF_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KD_OK 0
+#define KD_EINVAL (-1)   /* bad argument / unsupported shape */
+#define KD_ELAUNCH (-2)  /* HIP launch error */
+
+int kd_version(void);
+const char* kd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused GEMM  C = epilogue( prologue(A) @ W^T ).   W is [N_w, K] row-major (nn.Linear.weight).
+ * Replaces: nn.Linear / F.linear call sites image_transformer_v2.py:126-129 (Linear),
+ * :89-95,132-139 (linear_geglu / LinearGEGLU, torch.compile'd), fused with the ops around
+ * them: rms_norm/AdaRMSNorm :98-103,155-166 (prologue), residual add :396,443,476,493,
+ * TokenMerge :586-595, TokenSplit + lerp :610-621, TokenSplitWithoutSkip :598-607 and the
+ * NCHW<->NHWC movedims :723,760, and the Karras preconditioner k_diffusion/layers.py:88-90.
+ */
+enum { KD_A_PLAIN = 0, KD_A_MERGE2x2 = 1, KD_A_PATCH_NCHW = 2 };
+enum { KD_EPI_STORE = 0, KD_EPI_RESIDUAL = 1, KD_EPI_GEGLU = 2, KD_EPI_SPLIT_LERP = 3, KD_EPI_UNPATCH_NCHW = 4 };
+
+typedef struct {
+  int M, N, K;          /* C is [M, N]; K = reduction length (multiple of 4)                      */
+  int a_mode, epi;      /* KD_A_*, KD_EPI_*                                                       */
+  int norm;             /* 1: A'[m,k] = A[m,k] * scale[b(m)*scale_stride + k] * rsqrt(mean_k A^2 + eps) */
+  int rows_per_sample;  /* b(m) = m / rows_per_sample (tokens per image)                          */
+  int scale_stride;     /* K for per-sample AdaRMSNorm scales, 0 for a shared RMSNorm gain        */
+  int gh, gw;           /* token grid of the COARSE side (merge/split: h,w of the merged grid;
+                           patch modes: h,w of the patch grid)                                    */
+  int ph, pw, chan;     /* patch modes: patch size and image channels                             */
+  float eps;            /* rms-norm epsilon                                                       */
+  float out_add;        /* KD_EPI_STORE: constant added to every output (AdaRMSNorm's "+1")       */
+  float sigma_data;     /* patch modes: Karras preconditioner                                     */
+  const float* A;       /* plain: [M,K]; merge: [B,2gh,2gw,K/4]; patch: image [B,chan,gh*ph,gw*pw] */
+  const float* W;       /* [N,K]  (GEGLU: [2N,K], value rows first)                               */
+  float* C;             /* store/residual/geglu: [M,N]; split: [B,2gh,2gw,N/4]; unpatch: image     */
+  const float* R;       /* residual: [M,N]; split: skip [B,2gh,2gw,N/4]; unpatch: x_in image       */
+  const float* scale;   /* norm scales                                                            */
+  const float* sigma;   /* [B] per-sample sigma (patch modes; NULL = no preconditioning)           */
+  const float* fac;     /* split: device pointer to the lerp factor                               */
+} KdGemm;
+
+int kd_gemm_f32(const KdGemm* desc, void* stream);
+
+/* Stand-alone RMS norm over the last dim (mapping network, image_transformer_v2.py:142-152):
+ * y[m,:] = x[m,:] * scale[:] * rsqrt(mean(x[m,:]^2) + eps).  d <= 4096, d % 4 == 0. */
+int kd_rmsnorm_f32(const float* x, const float* scale, float* y, int rows, int d, float eps, void* stream);
+
+/* Conditioning front end (image_transformer_v2.py:734-740 + layers.py:285-293 FourierFeatures):
+ * ff[b, :] = [cos(2*pi*c*w_j), sin(2*pi*c*w_j)], c = log(sigma_b)/4, w = time_emb.weight [half]. */
+int kd_fourier_sigma_f32(const float* sigma, const float* weight, float* ff, int batch, int half, void* stream);
+/* generic FourierFeatures for aug_cond: ff[b,:] = [cos(f), sin(f)], f = 2*pi * in[b,:] @ w^T, w [half, in_dim] */
+int kd_fourier_f32(const float* in, const float* weight, float* ff, int batch, int in_dim, int half, void* stream);
+/* out[b,:] = a[b,:] + (b_rows ? b[b,:] : b[:]) + (emb ? emb[ids[b],:] : 0) + (c ? c[b,:] : 0) */
+int kd_cond_sum_f32(float* out, const float* a, const float* b, int b_rows, const float* emb,
+                    const long long* ids, const float* c, int batch, int d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * q/k preparation, in place on a qkv buffer [tokens_total, 3, nh, 64]:
+ *   q,k <- rope( x * sqrt(scale_h) * rsqrt(sum x^2 + eps) ),   v untouched.
+ * Replaces scale_for_cosine_sim (image_transformer_v2.py:106-114) + apply_rotary_emb_
+ * (:187-231, in place on a view).  cos/sin: [tokens_per_sample, nh, 16] tables of
+ * AxialRoPE.forward's theta (:245-248), computed once on the host.
+ * The attention kernels below can also apply it on the fly (prep != 0) so that this pass and
+ * its HBM round trip disappear from the hot path. */
+int kd_qk_prep_f32(float* qkv, const float* scale_h, const float* cos_t, const float* sin_t,
+                   int batch, int tokens_per_sample, int nh, float eps, void* stream);
+
+/* Dense softmax attention per (sample, head) over all T tokens (T <= 256), softmax scale 1.0.
+ * Replaces F.scaled_dot_product_attention / flash_attn_qkvpacked_func at
+ * image_transformer_v2.py:383,392.  out: [batch*T, nh*64]. */
+int kd_attn_global_f32(const float* qkv, float* out, int batch, int T, int nh,
+                       int prep, const float* scale_h, const float* cos_t, const float* sin_t, float eps,
+                       void* stream);
+
+/* Shifted-window attention (window ws x ws = 64 tokens, ws == 8), roll/window/mask/unwindow
+ * folded into addressing.  Replaces apply_window_attention image_transformer_v2.py:319-337
+ * (+ :253-316).  shift is 0 or ws/2. */
+int kd_attn_window_f32(const float* qkv, float* out, int batch, int H, int W, int nh, int ws, int shift,
+                       int prep, const float* scale_h, const float* cos_t, const float* sin_t, float eps,
+                       void* stream);
+
+/* 2-D neighbourhood attention, kernel ks x ks (ks == 7), window clamped inside the image,
+ * dilation 1, heads-last.  Replaces natten.functional.na2d(q,k,v,7,scale=1.0)
+ * image_transformer_v2.py:428 (and the unfused pair :437-439). */
+int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, int W, int nh, int ks,
+                     int prep, const float* scale_h, const float* cos_t, const float* sin_t, float eps,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Solver step arithmetic (k_diffusion/sampling.py), one fused elementwise launch per step with
+ * host-precomputed fp32 coefficients.  Operation order follows the reference expression trees
+ * exactly (no FMA contraction) so results are bit-identical to the reference's CPU path.
+ *   KD_STEP_EULER      : out = x + ((x - den) / c0) * c1                    (:129-134, :176, :558-560)
+ *   KD_STEP_HEUN_PRED  : aux_out = (x - den)/c0 ; out = x + aux_out * c1     (:170,:179)
+ *   KD_STEP_HEUN_CORR  : d2 = (x2 - den)/c0 ; out = x + ((aux + d2)/2) * c1   (:181-183)  [x2 = in2]
+ *   KD_STEP_DPMPP_2M1  : out = c0 * x - c1 * den                             (:600, also :533,:535,:571,:579)
+ *   KD_STEP_DPMPP_2M2  : out = c0 * x - c1 * (c2 * den - c3 * in2)            (:604-605)   [old = in2]
+ *   KD_STEP_ADD_NOISE  : out = x + (den * c0) * c1                           (:154,:572,:580)  [den = noise]
+ *   KD_STEP_LERP2      : out = c0 * den + c1 * in2                           (:578)
+ *   KD_STEP_AXPY       : out = x + den * c0                                  (:127, :276 terms)
+ */
+enum { KD_STEP_EULER = 0, KD_STEP_HEUN_PRED = 1, KD_STEP_HEUN_CORR = 2, KD_STEP_DPMPP_2M1 = 3,
+       KD_STEP_DPMPP_2M2 = 4, KD_STEP_ADD_NOISE = 5, KD_STEP_LERP2 = 6, KD_STEP_AXPY = 7 };
+int kd_sampler_step_f32(int op, const float* x, const float* den, const float* in2, float* out, float* aux,
+                        float c0, float c1, float c2, float c3, long long n, void* stream);
+
+/* Karras preconditioner for a foreign inner model (k_diffusion/layers.py:88-90):
+ *   kd_precond_in : y = x * c_in(sigma_b)
+ *   kd_precond_out: y = f * c_out(sigma_b) + x * c_skip(sigma_b)          per_sample = C*H*W */
+int kd_precond_in_f32(const float* x, const float* sigma, float* y, float sigma_data, int batch, long long per_sample, void* stream);
+int kd_precond_out_f32(const float* f, const float* x, const float* sigma, float* y, float sigma_data, int batch,
+                       long long per_sample, void* stream);
+
+/* Brownian-interval noise (stands in for torchsde.BrownianTree behind
+ * k_diffusion/sampling.py:65-114): out[b, i] = sign * (W_b,i(t1) - W_b,i(t0)) * inv_norm where W is
+ * a virtual Brownian tree on [T0, T1] (depth-`depth` dyadic bridge, Philox4x32-10 keyed by
+ * seeds[b], counter = (element index, tree node)); path-consistent across nested queries. */
+int kd_brownian_f32(float* out, const unsigned long long* seeds, int batch, long long per_sample,
+                    double T0, double T1, double t0, double t1, float mult, int depth, void* stream);
+
+/* Final image conversion (k_diffusion/utils.py:27-34 to_pil_image): u8 = trunc((clamp(x,-1,1)+1)/2*255)
+ * (torchvision's to_pil_image does mul(255).byte(), i.e. truncation) */
+int kd_to_uint8(const float* x, unsigned char* y, long long n, void* stream);
+
+/* Per-launch timing hooks for bench.py (HIP events recorded on `stream` around each launch). */
+int kd_prof_enable(int on);
+int kd_prof_count(void);
+int kd_prof_get(int i, char* name, int name_cap, float* ms, double* flops, double* bytes);
+int kd_prof_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,87 @@
+"""ctypes binding of csrc/libkdiff_hip.so (C ABI declared in include/kdiff_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent, the first use raises.
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C k-diffusion_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("KDIFF_HIP_LIB") or os.path.join(_HERE, "csrc", "libkdiff_hip.so")
+
+# enums (include/kdiff_hip.h)
+A_PLAIN, A_MERGE2x2, A_PATCH_NCHW = 0, 1, 2
+EPI_STORE, EPI_RESIDUAL, EPI_GEGLU, EPI_SPLIT_LERP, EPI_UNPATCH_NCHW = 0, 1, 2, 3, 4
+STEP_EULER, STEP_HEUN_PRED, STEP_HEUN_CORR, STEP_DPMPP_2M1, STEP_DPMPP_2M2, STEP_ADD_NOISE, STEP_LERP2, STEP_AXPY = range(8)
+
+
+class KdGemm(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("a_mode", C.c_int), ("epi", C.c_int), ("norm", C.c_int),
+        ("rows_per_sample", C.c_int), ("scale_stride", C.c_int),
+        ("gh", C.c_int), ("gw", C.c_int), ("ph", C.c_int), ("pw", C.c_int), ("chan", C.c_int),
+        ("eps", C.c_float), ("out_add", C.c_float), ("sigma_data", C.c_float),
+        ("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("R", C.c_void_p),
+        ("scale", C.c_void_p), ("sigma", C.c_void_p), ("fac", C.c_void_p),
+    ]
+
+
+_vp, _i, _f, _ll, _d = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_double
+
+# name -> argtypes; every symbol declared in include/kdiff_hip.h
+SIGNATURES = {
+    "kd_version": [],
+    "kd_last_error": [],
+    "kd_gemm_f32": [C.POINTER(KdGemm), _vp],
+    "kd_rmsnorm_f32": [_vp, _vp, _vp, _i, _i, _f, _vp],
+    "kd_fourier_sigma_f32": [_vp, _vp, _vp, _i, _i, _vp],
+    "kd_fourier_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "kd_cond_sum_f32": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "kd_qk_prep_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    "kd_attn_global_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp],
+    "kd_attn_window_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp],
+    "kd_attn_na2d_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp],
+    "kd_sampler_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _ll, _vp],
+    "kd_precond_in_f32": [_vp, _vp, _vp, _f, _i, _ll, _vp],
+    "kd_precond_out_f32": [_vp, _vp, _vp, _vp, _f, _i, _ll, _vp],
+    "kd_brownian_f32": [_vp, _vp, _i, _ll, _d, _d, _d, _d, _f, _i, _vp],
+    "kd_to_uint8": [_vp, _vp, _ll, _vp],
+    "kd_prof_enable": [_i],
+    "kd_prof_count": [],
+    "kd_prof_get": [_i, C.c_char_p, _i, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "kd_prof_reset": [],
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library (loads on first use; raises loudly if it is not there)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C k-diffusion_amd/csrc). "
+                "There is no CPU / PyTorch fallback for the sampling hot path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+            fn.argtypes = argtypes
+            fn.restype = C.c_char_p if name == "kd_last_error" else C.c_int
+        _lib = handle
+    return _lib
+
+
+def check(code, what="libkdiff_hip"):
+    if code != 0:
+        msg = lib().kd_last_error()
+        raise RuntimeError(f"{what} failed ({code}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,211 @@
+// HBM-bound element-wise pieces of the sampling hot path (gfx950): solver step arithmetic,
+// Karras preconditioner for foreign inner models, the conditioning front end, stand-alone RMS norm
+// and the final uint8 conversion.  All float4-vectorised, grid-stride.
+//
+// This file is compiled with -ffp-contract=off and uses explicit round-to-nearest intrinsics in the
+// solver steps: the reference evaluates each step as a chain of separate ATen ops (one rounding per
+// op, k_diffusion/sampling.py:129-134, :170-183, :600-605), and the parity target for the solver
+// arithmetic is bit-exactness.
+#include "kd_common.h"
+
+namespace kd {
+
+constexpr int EW_BLOCK = 256;
+static inline unsigned ew_grid(long n_vec) {
+  long b = (n_vec + EW_BLOCK - 1) / EW_BLOCK;
+  return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));   // 256 CUs x 8 blocks, grid-stride the rest
+}
+
+__device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float sub(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float dvd(float a, float b) { return __fdiv_rn(a, b); }
+
+template <int OP>
+__device__ __forceinline__ float step_one(float x, float den, float in2, float& aux, float c0, float c1, float c2, float c3) {
+  if (OP == KD_STEP_EULER) return add(x, mul(dvd(sub(x, den), c0), c1));
+  if (OP == KD_STEP_HEUN_PRED) { aux = dvd(sub(x, den), c0); return add(x, mul(aux, c1)); }
+  if (OP == KD_STEP_HEUN_CORR) { const float d2 = dvd(sub(in2, den), c0); return add(x, mul(dvd(add(aux, d2), 2.0f), c1)); }
+  if (OP == KD_STEP_DPMPP_2M1) return sub(mul(c0, x), mul(c1, den));
+  if (OP == KD_STEP_DPMPP_2M2) return sub(mul(c0, x), mul(c1, sub(mul(c2, den), mul(c3, in2))));
+  if (OP == KD_STEP_ADD_NOISE) return add(x, mul(mul(den, c0), c1));
+  if (OP == KD_STEP_LERP2) return add(mul(c0, den), mul(c1, in2));
+  return add(x, mul(den, c0));  // KD_STEP_AXPY
+}
+
+template <int OP>
+__global__ __launch_bounds__(EW_BLOCK) void sampler_step_kernel(const float* __restrict__ x, const float* __restrict__ den,
+                                                                const float* __restrict__ in2, float* out, float* aux,
+                                                                float c0, float c1, float c2, float c3, long n) {
+  constexpr bool USE_X = OP != KD_STEP_LERP2;
+  constexpr bool USE_IN2 = OP == KD_STEP_HEUN_CORR || OP == KD_STEP_DPMPP_2M2 || OP == KD_STEP_LERP2;
+  constexpr bool AUX_R = OP == KD_STEP_HEUN_CORR, AUX_W = OP == KD_STEP_HEUN_PRED;
+  const long nv = n >> 2;
+  const long stride = (long)gridDim.x * EW_BLOCK;
+  for (long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x; i < nv; i += stride) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 xv = USE_X ? reinterpret_cast<const f32x4*>(x)[i] : zero;
+    const f32x4 dv = reinterpret_cast<const f32x4*>(den)[i];
+    const f32x4 iv = USE_IN2 ? reinterpret_cast<const f32x4*>(in2)[i] : zero;
+    f32x4 av = AUX_R ? reinterpret_cast<const f32x4*>(aux)[i] : zero;
+    f32x4 o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { float a = av[u]; o[u] = step_one<OP>(xv[u], dv[u], iv[u], a, c0, c1, c2, c3); av[u] = a; }
+    reinterpret_cast<f32x4*>(out)[i] = o;
+    if (AUX_W) reinterpret_cast<f32x4*>(aux)[i] = av;
+  }
+  // tail (n % 4 elements)
+  for (long i = (nv << 2) + (long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += stride) {
+    float a = AUX_R ? aux[i] : 0.f;
+    const float o = step_one<OP>(USE_X ? x[i] : 0.f, den[i], USE_IN2 ? in2[i] : 0.f, a, c0, c1, c2, c3);
+    out[i] = o;
+    if (AUX_W) aux[i] = a;
+  }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void precond_in_kernel(const float* __restrict__ x, const float* __restrict__ sigma, float* y,
+                                                              float sd, int batch, long per_sample) {
+  const long n = (long)batch * per_sample;
+  for (long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * EW_BLOCK) {
+    const float s = sigma[i / per_sample];
+    const float c_in = dvd(1.0f, __fsqrt_rn(add(mul(s, s), mul(sd, sd))));
+    y[i] = mul(x[i], c_in);
+  }
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void precond_out_kernel(const float* __restrict__ f, const float* __restrict__ x,
+                                                               const float* __restrict__ sigma, float* y, float sd, int batch, long per_sample) {
+  const long n = (long)batch * per_sample;
+  for (long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * EW_BLOCK) {
+    const float s = sigma[i / per_sample];
+    const float var = add(mul(s, s), mul(sd, sd));
+    const float c_skip = dvd(mul(sd, sd), var);
+    const float c_out = dvd(mul(s, sd), __fsqrt_rn(var));
+    y[i] = add(mul(f[i], c_out), mul(x[i], c_skip));
+  }
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ scale, float* y, int rows, int d, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long)row * d);
+  const int nv = d >> 2;
+  float ss = 0.f;
+  for (int i = lane; i < nv; i += 64) { const f32x4 v = xr[i]; ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+  ss = wave_sum_xor(ss, 64);
+  const float r = rsqrtf(ss / (float)d + eps);
+  f32x4* yr = reinterpret_cast<f32x4*>(y + (long)row * d);
+  for (int i = lane; i < nv; i += 64) yr[i] = xr[i] * (reinterpret_cast<const f32x4*>(scale)[i] * r);
+}
+
+__global__ void fourier_sigma_kernel(const float* sigma, const float* weight, float* ff, int batch, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch * half) return;
+  const int b = i / half, j = i % half;
+  const float c = logf(sigma[b]) / 4.0f;
+  const float f = (6.283185307179586f * c) * weight[j];
+  ff[(long)b * 2 * half + j] = cosf(f);
+  ff[(long)b * 2 * half + half + j] = sinf(f);
+}
+
+__global__ void fourier_kernel(const float* in, const float* weight, float* ff, int batch, int in_dim, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch * half) return;
+  const int b = i / half, j = i % half;
+  float f = 0.f;
+  for (int k = 0; k < in_dim; ++k) f += (6.283185307179586f * in[(long)b * in_dim + k]) * weight[(long)j * in_dim + k];
+  ff[(long)b * 2 * half + j] = cosf(f);
+  ff[(long)b * 2 * half + half + j] = sinf(f);
+}
+
+__global__ void cond_sum_kernel(float* out, const float* a, const float* bvec, int b_rows, const float* emb, const long long* ids,
+                                const float* c, int batch, int d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch * d) return;
+  const int b = i / d, j = i % d;
+  float v = a[i] + (b_rows ? bvec[i] : bvec[j]);
+  if (emb) v = v + emb[ids[b] * (long)d + j];
+  if (c) v = v + c[i];
+  out[i] = v;
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void to_uint8_kernel(const float* __restrict__ x, unsigned char* y, long n) {
+  for (long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * EW_BLOCK) {
+    const float v = fminf(fmaxf(x[i], -1.f), 1.f);
+    y[i] = (unsigned char)(((v + 1.f) / 2.f) * 255.f);   // torchvision to_pil_image: mul(255).byte() truncates
+  }
+}
+
+}  // namespace kd
+
+using namespace kd;
+
+extern "C" int kd_sampler_step_f32(int op, const float* x, const float* den, const float* in2, float* out, float* aux,
+                                   float c0, float c1, float c2, float c3, long long n, void* stream) {
+  if (n <= 0 || !den || !out) return fail(KD_EINVAL, "kd_sampler_step_f32: bad arguments");
+  if (op != KD_STEP_LERP2 && !x) return fail(KD_EINVAL, "kd_sampler_step_f32: op %d needs x", op);
+  if ((op == KD_STEP_HEUN_CORR || op == KD_STEP_DPMPP_2M2 || op == KD_STEP_LERP2) && !in2) return fail(KD_EINVAL, "kd_sampler_step_f32: op %d needs in2", op);
+  if ((op == KD_STEP_HEUN_CORR || op == KD_STEP_HEUN_PRED) && !aux) return fail(KD_EINVAL, "kd_sampler_step_f32: op %d needs aux", op);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned g = ew_grid(n >> 2);
+  LaunchScope prof("sampler_step_f32", 4.0 * n, 12.0 * n, s);
+#define KD_OP(O) case O: hipLaunchKernelGGL(sampler_step_kernel<O>, dim3(g), dim3(EW_BLOCK), 0, s, x, den, in2, out, aux, c0, c1, c2, c3, (long)n); break;
+  switch (op) {
+    KD_OP(KD_STEP_EULER) KD_OP(KD_STEP_HEUN_PRED) KD_OP(KD_STEP_HEUN_CORR) KD_OP(KD_STEP_DPMPP_2M1)
+    KD_OP(KD_STEP_DPMPP_2M2) KD_OP(KD_STEP_ADD_NOISE) KD_OP(KD_STEP_LERP2) KD_OP(KD_STEP_AXPY)
+    default: return fail(KD_EINVAL, "kd_sampler_step_f32: unknown op %d", op);
+  }
+#undef KD_OP
+  return check_launch("kd_sampler_step_f32");
+}
+
+extern "C" int kd_precond_in_f32(const float* x, const float* sigma, float* y, float sigma_data, int batch, long long per_sample, void* stream) {
+  if (!x || !sigma || !y || batch <= 0 || per_sample <= 0) return fail(KD_EINVAL, "kd_precond_in_f32: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope prof("precond_in_f32", 0, 8.0 * batch * per_sample, s);
+  hipLaunchKernelGGL(precond_in_kernel, dim3(ew_grid((long)batch * per_sample)), dim3(EW_BLOCK), 0, s, x, sigma, y, sigma_data, batch, (long)per_sample);
+  return check_launch("kd_precond_in_f32");
+}
+
+extern "C" int kd_precond_out_f32(const float* f, const float* x, const float* sigma, float* y, float sigma_data, int batch,
+                                  long long per_sample, void* stream) {
+  if (!f || !x || !sigma || !y || batch <= 0 || per_sample <= 0) return fail(KD_EINVAL, "kd_precond_out_f32: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope prof("precond_out_f32", 0, 12.0 * batch * per_sample, s);
+  hipLaunchKernelGGL(precond_out_kernel, dim3(ew_grid((long)batch * per_sample)), dim3(EW_BLOCK), 0, s, f, x, sigma, y, sigma_data, batch, (long)per_sample);
+  return check_launch("kd_precond_out_f32");
+}
+
+extern "C" int kd_rmsnorm_f32(const float* x, const float* scale, float* y, int rows, int d, float eps, void* stream) {
+  if (!x || !scale || !y || rows <= 0 || d <= 0 || (d & 3) || d > 4096) return fail(KD_EINVAL, "kd_rmsnorm_f32: bad arguments (d %% 4 == 0, d <= 4096)");
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope prof("rmsnorm_f32", 0, 8.0 * rows * d, s);
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, scale, y, rows, d, eps);
+  return check_launch("kd_rmsnorm_f32");
+}
+
+extern "C" int kd_fourier_sigma_f32(const float* sigma, const float* weight, float* ff, int batch, int half, void* stream) {
+  if (!sigma || !weight || !ff || batch <= 0 || half <= 0) return fail(KD_EINVAL, "kd_fourier_sigma_f32: bad arguments");
+  hipLaunchKernelGGL(fourier_sigma_kernel, dim3((batch * half + 255) / 256), dim3(256), 0, (hipStream_t)stream, sigma, weight, ff, batch, half);
+  return check_launch("kd_fourier_sigma_f32");
+}
+
+extern "C" int kd_fourier_f32(const float* in, const float* weight, float* ff, int batch, int in_dim, int half, void* stream) {
+  if (!in || !weight || !ff || batch <= 0 || half <= 0 || in_dim <= 0) return fail(KD_EINVAL, "kd_fourier_f32: bad arguments");
+  hipLaunchKernelGGL(fourier_kernel, dim3((batch * half + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, weight, ff, batch, in_dim, half);
+  return check_launch("kd_fourier_f32");
+}
+
+extern "C" int kd_cond_sum_f32(float* out, const float* a, const float* b, int b_rows, const float* emb, const long long* ids,
+                               const float* c, int batch, int d, void* stream) {
+  if (!out || !a || !b || batch <= 0 || d <= 0 || (emb && !ids)) return fail(KD_EINVAL, "kd_cond_sum_f32: bad arguments");
+  hipLaunchKernelGGL(cond_sum_kernel, dim3((batch * d + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, a, b, b_rows, emb, ids, c, batch, d);
+  return check_launch("kd_cond_sum_f32");
+}
+
+extern "C" int kd_to_uint8(const float* x, unsigned char* y, long long n, void* stream) {
+  if (!x || !y || n <= 0) return fail(KD_EINVAL, "kd_to_uint8: bad arguments");
+  hipLaunchKernelGGL(to_uint8_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, y, (long)n);
+  return check_launch("kd_to_uint8");
+}

@@ -1,0 +1,266 @@
+"""Tensor-level wrappers over the C ABI (include/kdiff_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation below is a HIP
+kernel from libkdiff_hip.so launched on ``torch.cuda.current_stream()``.  Tensors must be fp32,
+contiguous and on a ROCm device -- anything else raises (there is no eager fallback).
+
+The op names mirror the reference functions they replace
+(k_diffusion/models/image_transformer_v2.py): ``rms_norm`` (:98), ``linear_geglu`` (:89),
+``scale_for_cosine_sim``+``apply_rotary_emb_`` -> ``qk_prep_`` (:106, :230), SDPA / flash-attn ->
+``attn_global`` (:383,:392), ``apply_window_attention`` -> ``attn_window`` (:319),
+``natten.functional.na2d`` -> ``attn_na2d`` (:428).
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as nat
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the HIP path needs a tensor on a ROCm device (got {t.device}); there is no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scale=None, scale_stride=0,
+         rows_per_sample=0, residual=None, grid=(0, 0), patch=(0, 0, 0), eps=1e-6, out_add=0.0,
+         sigma=None, sigma_data=1.0, fac=None, scale_ptr=None):
+    """Fused GEMM (see KdGemm in include/kdiff_hip.h).  ``norm_scale`` may be a tensor or, with
+    ``scale_ptr``, a raw device address inside a larger scale table."""
+    d = nat.KdGemm()
+    d.M, d.N, d.K = M, N, K
+    d.a_mode, d.epi = a_mode, epi
+    d.norm = 1 if (norm_scale is not None or scale_ptr is not None) else 0
+    d.rows_per_sample, d.scale_stride = rows_per_sample, scale_stride
+    d.gh, d.gw = grid
+    d.ph, d.pw, d.chan = patch
+    d.eps, d.out_add, d.sigma_data = eps, out_add, sigma_data
+    d.A, d.W, d.C = _chk(A, "A").data_ptr(), _chk(W, "W").data_ptr(), _chk(out, "C").data_ptr()
+    d.R = None if residual is None else _chk(residual, "R").data_ptr()
+    d.scale = scale_ptr if scale_ptr is not None else (None if norm_scale is None else _chk(norm_scale, "scale").data_ptr())
+    d.sigma = None if sigma is None else _chk(sigma, "sigma").data_ptr()
+    d.fac = None if fac is None else _chk(fac, "fac").data_ptr()
+    nat.check(nat.lib().kd_gemm_f32(C.byref(d), _stream()), "kd_gemm_f32")
+    return out
+
+
+def linear(x, weight, residual=None, out=None, out_add=0.0):
+    """x[..., K] @ weight[N, K]^T (+ residual)  --  Linear (:126-129) with the skip add fused."""
+    K = x.shape[-1]
+    M = x.numel() // K
+    Nn = weight.shape[0]
+    out = torch.empty(*x.shape[:-1], Nn, device=x.device, dtype=x.dtype) if out is None else out
+    return gemm(x, weight, out, M=M, N=Nn, K=K, epi=nat.EPI_RESIDUAL if residual is not None else nat.EPI_STORE,
+                residual=residual, out_add=out_add)
+
+
+def linear_geglu(x, weight, out=None):
+    """linear_geglu (:89-95): value * gelu(gate), value = first half of the output features."""
+    K = x.shape[-1]
+    M = x.numel() // K
+    d_ff = weight.shape[0] // 2
+    out = torch.empty(*x.shape[:-1], d_ff, device=x.device, dtype=x.dtype) if out is None else out
+    return gemm(x, weight, out, M=M, N=d_ff, K=K, epi=nat.EPI_GEGLU)
+
+
+def rms_norm(x, scale, eps=1e-6, out=None):
+    """rms_norm (:98-103) with a shared gain (RMSNorm :142-152)."""
+    d = x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    nat.check(nat.lib().kd_rmsnorm_f32(_p(_chk(x, "x")), _p(_chk(scale, "scale")), _p(_chk(out, "y")), x.numel() // d, d, eps, _stream()),
+            "kd_rmsnorm_f32")
+    return out
+
+
+def norm_linear(x, scale, weight, *, rows_per_sample, epi=nat.EPI_STORE, out=None, eps=1e-6):
+    """AdaRMSNorm/RMSNorm (:155-166) fused into the following Linear / LinearGEGLU.
+    ``scale``: [B, K] per-sample scales (AdaRMSNorm: Linear(cond) + 1) or [K] shared gain."""
+    K = x.shape[-1]
+    M = x.numel() // K
+    Nn = weight.shape[0] // (2 if epi == nat.EPI_GEGLU else 1)
+    out = torch.empty(*x.shape[:-1], Nn, device=x.device, dtype=x.dtype) if out is None else out
+    return gemm(x, weight, out, M=M, N=Nn, K=K, epi=epi, norm_scale=scale, scale_stride=K if scale.dim() == 2 else 0,
+                rows_per_sample=rows_per_sample, eps=eps)
+
+
+def token_merge(x, weight, out=None):
+    """TokenMerge (:586-595) with the 2x2 space-to-depth folded into the GEMM's A addressing.  x: [B, 2h, 2w, C]."""
+    B, H2, W2, Cc = x.shape
+    h, w = H2 // 2, W2 // 2
+    Nn = weight.shape[0]
+    out = torch.empty(B, h, w, Nn, device=x.device, dtype=x.dtype) if out is None else out
+    return gemm(x, weight, out, M=B * h * w, N=Nn, K=4 * Cc, a_mode=nat.A_MERGE2x2, grid=(h, w))
+
+
+def token_split_lerp(x, weight, skip, fac, out=None):
+    """TokenSplit (:610-621): Linear -> depth-to-space -> lerp(skip, x, fac), fused.  x: [B, h, w, K]."""
+    B, h, w, K = x.shape
+    Nn = weight.shape[0]
+    out = torch.empty_like(skip) if out is None else out
+    return gemm(x, weight, out, M=B * h * w, N=Nn, K=K, epi=nat.EPI_SPLIT_LERP, residual=skip, fac=fac, grid=(h, w))
+
+
+def patch_in(image, weight, patch, sigma=None, sigma_data=1.0, out=None):
+    """NCHW->NHWC (:723) + TokenMerge(patch) (:672,:724) (+ Denoiser's x * c_in, layers.py:90)."""
+    B, Cc, H, W = image.shape
+    ph, pw = patch
+    h, w = H // ph, W // pw
+    Nn = weight.shape[0]
+    out = torch.empty(B, h, w, Nn, device=image.device, dtype=image.dtype) if out is None else out
+    return gemm(image, weight, out, M=B * h * w, N=Nn, K=Cc * ph * pw, a_mode=nat.A_PATCH_NCHW, grid=(h, w),
+                patch=(ph, pw, Cc), sigma=sigma, sigma_data=sigma_data)
+
+
+def patch_out(x, norm_scale, weight, patch, channels, x_in=None, sigma=None, sigma_data=1.0, out=None, eps=1e-6):
+    """out_norm (:758) + TokenSplitWithoutSkip (:759) + NHWC->NCHW (:760)
+    (+ Denoiser's F * c_out + x * c_skip, layers.py:90).  x: [B, h, w, K]."""
+    B, h, w, K = x.shape
+    ph, pw = patch
+    out = torch.empty(B, channels, h * ph, w * pw, device=x.device, dtype=x.dtype) if out is None else out
+    return gemm(x, weight, out, M=B * h * w, N=channels * ph * pw, K=K, epi=nat.EPI_UNPATCH_NCHW, norm_scale=norm_scale,
+                scale_stride=0, rows_per_sample=h * w, grid=(h, w), patch=(ph, pw, channels), residual=x_in, sigma=sigma,
+                sigma_data=sigma_data, eps=eps)
+
+
+def fourier_sigma(sigma, weight, out=None):
+    half = weight.shape[0]
+    out = torch.empty(sigma.shape[0], 2 * half, device=sigma.device, dtype=torch.float32) if out is None else out
+    nat.check(nat.lib().kd_fourier_sigma_f32(_p(_chk(sigma, "sigma")), _p(_chk(weight, "weight")), _p(_chk(out, "ff")), sigma.shape[0], half,
+                                         _stream()), "kd_fourier_sigma_f32")
+    return out
+
+
+def fourier_features(x, weight, out=None):
+    """FourierFeatures (k_diffusion/layers.py:285-293)."""
+    half, in_dim = weight.shape
+    B = x.numel() // in_dim
+    out = torch.empty(*x.shape[:-1], 2 * half, device=x.device, dtype=torch.float32) if out is None else out
+    nat.check(nat.lib().kd_fourier_f32(_p(_chk(x, "x")), _p(_chk(weight, "weight")), _p(_chk(out, "ff")), B, in_dim, half, _stream()), "kd_fourier_f32")
+    return out
+
+
+def cond_sum(a, b, emb=None, ids=None, c=None, out=None):
+    """time_emb + aug_emb + class_emb + mapping_emb (:740)."""
+    B, d = a.shape
+    out = torch.empty_like(a) if out is None else out
+    if emb is not None:
+        _chk(ids, "ids", torch.int64)
+    nat.check(nat.lib().kd_cond_sum_f32(_p(_chk(out, "out")), _p(_chk(a, "a")), _p(_chk(b, "b")), 1 if b.dim() == 2 else 0,
+                                    _p(None if emb is None else _chk(emb, "emb")), _p(ids), _p(None if c is None else _chk(c, "c")),
+                                    B, d, _stream()), "kd_cond_sum_f32")
+    return out
+
+
+def _qkv_dims(qkv, nh):
+    if qkv.shape[-1] != 3 * nh * 64:
+        raise ValueError(f"qkv last dim {qkv.shape[-1]} != 3*{nh}*64 (head dim is fixed at 64)")
+
+
+def qk_prep_(qkv, scale_h, cos_t, sin_t, nh, eps=1e-6):
+    """In place on qkv [B, T, 3*nh*64]: scale_for_cosine_sim (:106-114) + apply_rotary_emb_ (:230)."""
+    _qkv_dims(qkv, nh)
+    B = qkv.shape[0]
+    T = qkv.numel() // (B * 3 * nh * 64)
+    nat.check(nat.lib().kd_qk_prep_f32(_p(_chk(qkv, "qkv")), _p(_chk(scale_h, "scale")), _p(_chk(cos_t, "cos")), _p(_chk(sin_t, "sin")),
+                                   B, T, nh, eps, _stream()), "kd_qk_prep_f32")
+    return qkv
+
+
+def _prep_args(prep):
+    if prep is None:
+        return 0, None, None, None, 1e-6
+    scale_h, cos_t, sin_t = prep[:3]
+    eps = prep[3] if len(prep) > 3 else 1e-6
+    return 1, _p(_chk(scale_h, "scale")), _p(_chk(cos_t, "cos")), _p(_chk(sin_t, "sin")), eps
+
+
+def attn_global(qkv, nh, prep=None, out=None):
+    """qkv: [B, T, 3*nh*64] -> [B, T, nh*64].  ``prep=(scale_h, cos, sin[, eps])`` applies the q/k
+    preparation on the fly; ``None`` means q,k are already prepared."""
+    _qkv_dims(qkv, nh)
+    B = qkv.shape[0]
+    T = qkv.numel() // (B * 3 * nh * 64)
+    out = torch.empty(*qkv.shape[:-1], nh * 64, device=qkv.device, dtype=qkv.dtype) if out is None else out
+    f, s, c, sn, eps = _prep_args(prep)
+    nat.check(nat.lib().kd_attn_global_f32(_p(_chk(qkv, "qkv")), _p(_chk(out, "out")), B, T, nh, f, s, c, sn, eps, _stream()), "kd_attn_global_f32")
+    return out
+
+
+def attn_window(qkv, nh, window_size, shift, prep=None, out=None):
+    """qkv: [B, H, W, 3*nh*64] -> [B, H, W, nh*64]; apply_window_attention (:319-337)."""
+    _qkv_dims(qkv, nh)
+    B, H, W, _ = qkv.shape
+    out = torch.empty(B, H, W, nh * 64, device=qkv.device, dtype=qkv.dtype) if out is None else out
+    f, s, c, sn, eps = _prep_args(prep)
+    nat.check(nat.lib().kd_attn_window_f32(_p(_chk(qkv, "qkv")), _p(_chk(out, "out")), B, H, W, nh, window_size, shift, f, s, c, sn, eps, _stream()),
+            "kd_attn_window_f32")
+    return out
+
+
+def attn_na2d(qkv, nh, kernel_size, prep=None, out=None):
+    """qkv: [B, H, W, 3*nh*64] -> [B, H, W, nh*64]; natten.functional.na2d(q, k, v, ks, scale=1.0) (:428)."""
+    _qkv_dims(qkv, nh)
+    B, H, W, _ = qkv.shape
+    out = torch.empty(B, H, W, nh * 64, device=qkv.device, dtype=qkv.dtype) if out is None else out
+    f, s, c, sn, eps = _prep_args(prep)
+    nat.check(nat.lib().kd_attn_na2d_f32(_p(_chk(qkv, "qkv")), _p(_chk(out, "out")), B, H, W, nh, kernel_size, f, s, c, sn, eps, _stream()),
+            "kd_attn_na2d_f32")
+    return out
+
+
+def sampler_step(op, x, den, in2=None, out=None, aux=None, c0=0.0, c1=0.0, c2=0.0, c3=0.0):
+    out = torch.empty_like(den) if out is None else out
+    for name, t in (("x", x), ("den", den), ("in2", in2), ("out", out), ("aux", aux)):
+        if t is not None:
+            _chk(t, name)
+            if t.numel() != den.numel():
+                raise ValueError(f"sampler_step: {name} has {t.numel()} elements, expected {den.numel()}")
+    nat.check(nat.lib().kd_sampler_step_f32(op, _p(x), _p(den), _p(in2), _p(out), _p(aux), float(c0), float(c1), float(c2), float(c3),
+                                        den.numel(), _stream()), "kd_sampler_step_f32")
+    return out
+
+
+def precond_in(x, sigma, sigma_data, out=None):
+    out = torch.empty_like(x) if out is None else out
+    B = x.shape[0]
+    nat.check(nat.lib().kd_precond_in_f32(_p(_chk(x, "x")), _p(_chk(sigma, "sigma")), _p(_chk(out, "y")), float(sigma_data), B, x.numel() // B, _stream()),
+            "kd_precond_in_f32")
+    return out
+
+
+def precond_out(f, x, sigma, sigma_data, out=None):
+    out = torch.empty_like(x) if out is None else out
+    B = x.shape[0]
+    nat.check(nat.lib().kd_precond_out_f32(_p(_chk(f, "f")), _p(_chk(x, "x")), _p(_chk(sigma, "sigma")), _p(_chk(out, "y")), float(sigma_data), B,
+                                       x.numel() // B, _stream()), "kd_precond_out_f32")
+    return out
+
+
+def brownian(out, seeds, T0, T1, t0, t1, mult, depth=36):
+    """out[b, ...] = (W_b(t1) - W_b(t0)) * mult, one virtual Brownian tree per batch item (seeds: uint64 [B])."""
+    B = out.shape[0]
+    _chk(seeds, "seeds", torch.int64)
+    nat.check(nat.lib().kd_brownian_f32(_p(_chk(out, "out")), _p(seeds), B, out.numel() // B, float(T0), float(T1), float(t0), float(t1),
+                                    float(mult), depth, _stream()), "kd_brownian_f32")
+    return out
+
+
+def to_uint8(x, out=None):
+    out = torch.empty(x.shape, device=x.device, dtype=torch.uint8) if out is None else out
+    nat.check(nat.lib().kd_to_uint8(_p(_chk(x, "x")), _p(_chk(out, "y", torch.uint8)), x.numel(), _stream()), "kd_to_uint8")
+    return out

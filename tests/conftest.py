@@ -25,6 +25,6 @@ def golden():
 
 
 @pytest.fixture(scope="session")
-def K():
+def KD():
     import k_diffusion_amd
     return k_diffusion_amd

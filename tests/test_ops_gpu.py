@@ -1,0 +1,251 @@
+"""Parity of every HIP kernel (through the C ABI) against the CPU oracle and the reference's golden
+op outputs.  Needs a real MI355X:  pytest -m gpu.
+
+Tolerances (max-norm relative unless stated): GEMM-class ops 2e-5 (fp32 FMA-chain order only),
+attention 2e-5, elementwise solver steps BIT-EXACT, index maps implied bit-exact by the value checks
+on asymmetric random data."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import brownian as obrown
+from oracle import hdit, solvers
+from tests.helpers import bits, relerr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops(KD):
+    return KD.ops
+
+
+def rn(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def g(t):
+    return t.to(DEV).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (131, 200, 96), (32, 768, 256), (1000, 48, 128), (5, 7 * 4, 12), (384, 512, 1536)])
+def test_gemm_plain_and_residual(ops, M, N, K):
+    x, w, r = rn(M, K, seed=1), rn(N, K, seed=2) / K ** 0.5, rn(M, N, seed=3)
+    assert relerr(ops.linear(g(x), g(w)), x @ w.T) < 2e-5
+    assert relerr(ops.linear(g(x), g(w), residual=g(r)), x @ w.T + r) < 2e-5
+    assert relerr(ops.linear(g(x), g(w), out_add=1.0), x @ w.T + 1) < 2e-5
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    x, w = g(rn(8, 6)), g(rn(4, 6))
+    with pytest.raises(RuntimeError, match="K % 4"):
+        ops.linear(x, w)
+    with pytest.raises(RuntimeError):
+        ops.linear(rn(8, 8), g(rn(4, 8)))          # CPU tensor: no fallback
+
+
+def test_norm_linear_and_geglu(ops, golden):
+    o = golden["ops"]
+    x, cond, wl, wg = o["rms_norm.x"], o["adarms.cond"], o["adarms.w"], o["geglu.w"]
+    # stand-alone rms_norm vs the reference's output
+    assert relerr(ops.rms_norm(g(x), g(o["rms_norm.scale"])), o["rms_norm.y"]) < 2e-6
+    # AdaRMSNorm scale = Linear(cond) + 1 via the "+const" epilogue, then fused norm -> GEGLU
+    scale = ops.linear(g(cond), g(wl), out_add=1.0)
+    y = ops.norm_linear(g(x), scale, g(wg), rows_per_sample=64, epi=2)
+    ref = hdit.linear_geglu(o["adarms.y"], wg)
+    assert relerr(y, ref) < 2e-5
+    # plain GEGLU against the reference's own linear_geglu output
+    assert relerr(ops.linear_geglu(g(x), g(wg)), o["geglu.y"]) < 2e-5
+    # fused norm -> plain linear with shared gain
+    w = rn(96, 128, seed=5) / 128 ** 0.5
+    y = ops.norm_linear(g(x), g(o["rms_norm.scale"]), g(w), rows_per_sample=64)
+    assert relerr(y, o["rms_norm.y"] @ w.T) < 2e-5
+
+
+def test_token_merge_split(ops, golden):
+    o = golden["ops"]
+    x = o["rms_norm.x"]
+    assert relerr(ops.token_merge(g(x), g(o["merge.w"])), o["merge.y"]) < 2e-5
+    for fac in (0.37, 0.5, 0.8):
+        skip = o["split.skip"]
+        ref = torch.lerp(skip, hdit.token_split(x, o["split.w"], 2, 2), torch.tensor([fac]))
+        y = ops.token_split_lerp(g(x), g(o["split.w"]), g(skip), g(torch.tensor([fac])))
+        assert relerr(y, ref) < 2e-5
+    y = ops.token_split_lerp(g(x), g(o["split.w"]), g(o["split.skip"]), g(torch.tensor([0.37])))
+    assert relerr(y, o["split.y"]) < 2e-5
+
+
+@pytest.mark.parametrize("C,H,W,p,d", [(3, 16, 16, 2, 128), (1, 28, 28, 4, 64), (3, 32, 64, 4, 128)])
+def test_patch_in_out(ops, C, H, W, p, d):
+    B = 3
+    img, w_in = rn(B, C, H, W, seed=1), rn(d, C * p * p, seed=2)
+    sigma = torch.tensor([0.05, 1.3, 70.0])
+    ref = hdit.token_merge(img.movedim(1, -1).contiguous(), w_in, p, p)
+    assert relerr(ops.patch_in(g(img), g(w_in), (p, p)), ref) < 2e-5
+    c_skip, c_out, c_in = solvers.karras_scalings(sigma, 0.5)
+    ref_c = hdit.token_merge((img * c_in.view(-1, 1, 1, 1)).movedim(1, -1).contiguous(), w_in, p, p)
+    assert relerr(ops.patch_in(g(img), g(w_in), (p, p), sigma=g(sigma), sigma_data=0.5), ref_c) < 2e-5
+    x, scale, w_out = rn(B, H // p, W // p, d, seed=3), 1 + 0.1 * rn(d, seed=4), rn(C * p * p, d, seed=5) / d ** 0.5
+    inner = hdit.token_split(hdit.rms_norm(x, scale), w_out, p, p).movedim(-1, 1)
+    assert relerr(ops.patch_out(g(x), g(scale), g(w_out), (p, p), C), inner) < 2e-5
+    ref_d = inner * c_out.view(-1, 1, 1, 1) + img * c_skip.view(-1, 1, 1, 1)
+    y = ops.patch_out(g(x), g(scale), g(w_out), (p, p), C, x_in=g(img), sigma=g(sigma), sigma_data=0.5)
+    assert relerr(y, ref_d) < 2e-5
+
+
+def _tables(h, w, nh):
+    theta = hdit.rope_theta(hdit.axial_pos(h, w), hdit.rope_freqs(nh)).reshape(h * w, nh, 16)
+    return torch.cos(theta), torch.sin(theta)
+
+
+def _pack(q, k, v):
+    # heads-last q,k,v [n,h,w,nh,e] -> qkv [n,h,w,3*nh*e]
+    return torch.stack([q, k, v], dim=3).reshape(*q.shape[:3], -1).contiguous()
+
+
+def test_qk_prep_inplace(ops, golden):
+    o = golden["ops"]
+    qkv = g(_pack(o["qk.q"], o["qk.k"], o["qk.v"]))
+    cos, sin = _tables(16, 16, 2)
+    ops.qk_prep_(qkv, g(o["qk.scale"]), g(cos), g(sin), 2)
+    out = qkv.cpu().view(2, 16, 16, 3, 2, 64)
+    assert relerr(out[..., 0, :, :], o["qk.q_out"]) < 2e-6
+    assert relerr(out[..., 1, :, :], o["qk.k_out"]) < 2e-6
+    assert torch.equal(out[..., 2, :, :], o["qk.v"])          # v untouched (:379, :389-390)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_attention_vs_reference_golden(ops, golden, fused):
+    o = golden["ops"]
+    cos, sin = _tables(16, 16, 2)
+    prep = (g(o["qk.scale"]), g(cos), g(sin))
+    if fused:
+        qkv = g(_pack(o["qk.q"], o["qk.k"], o["qk.v"]))
+        kw = dict(prep=prep)
+    else:
+        qkv = g(_pack(o["qk.q_out"], o["qk.k_out"], o["qk.v"]))
+        kw = {}
+    y = ops.attn_global(qkv.view(2, 256, -1), 2, **kw).view(2, 16, 16, 2, 64)
+    assert relerr(y, o["attn_global.o"]) < 2e-5
+    for shift in (0, 4):
+        y = ops.attn_window(qkv, 2, 8, shift, **kw).view(2, 16, 16, 2, 64)
+        assert relerr(y, o[f"attn_window{shift}.o"]) < 2e-5, shift
+    ref = hdit.na2d(o["qk.q_out"], o["qk.k_out"], o["qk.v"], 7, 1.0)
+    y = ops.attn_na2d(qkv, 2, 7, **kw).view(2, 16, 16, 2, 64)
+    assert relerr(y, ref) < 2e-5
+
+
+def test_window_attention_rect(ops, golden):
+    o = golden["ops"]
+    qkv = g(_pack(o["attn_window_rect.q"], o["attn_window_rect.k"], o["attn_window_rect.v"]))
+    y = ops.attn_window(qkv, 1, 8, 4).view(1, 8, 24, 1, 64)
+    assert relerr(y, o["attn_window_rect.o"]) < 2e-5
+
+
+@pytest.mark.parametrize("T,nh,B", [(49, 4, 3), (64, 8, 2), (100, 1, 2), (256, 2, 2), (7, 1, 1)])
+def test_attn_global_sizes(ops, T, nh, B):
+    q, k, v = (rn(B, 1, T, nh, 64, seed=s, scale=sc) for s, sc in ((1, 0.6), (2, 0.6), (3, 1.0)))
+    ref = hdit.attn_global(q, k, v, 1.0)
+    y = ops.attn_global(g(_pack(q, k, v)).view(B, T, -1), nh).view(B, 1, T, nh, 64)
+    assert relerr(y, ref) < 2e-5
+    with pytest.raises(RuntimeError, match="256"):
+        ops.attn_global(g(rn(1, 300, 192)), 1)
+
+
+@pytest.mark.parametrize("H,W,nh,B", [(7, 7, 1, 2), (8, 8, 2, 1), (9, 12, 1, 2), (16, 16, 2, 2), (20, 13, 1, 1), (32, 32, 4, 1)])
+def test_attn_na2d_sizes(ops, H, W, nh, B):
+    q, k, v = (rn(B, H, W, nh, 64, seed=s, scale=sc) for s, sc in ((1, 0.5), (2, 0.5), (3, 1.0)))
+    ref = hdit.na2d(q, k, v, 7, 1.0)
+    y = ops.attn_na2d(g(_pack(q, k, v)), nh, 7).view(B, H, W, nh, 64)
+    assert relerr(y, ref) < 2e-5
+    # fused preparation path against oracle-prepared q, k
+    scale = torch.linspace(5.0, 12.0, nh)
+    cos, sin = _tables(H, W, nh)
+    theta = hdit.rope_theta(hdit.axial_pos(H, W), hdit.rope_freqs(nh))
+    qs, ks = hdit.cosine_sim_scale(q, k, scale)
+    ref = hdit.na2d(hdit.apply_rope(qs, theta), hdit.apply_rope(ks, theta), v, 7, 1.0)
+    y = ops.attn_na2d(g(_pack(q, k, v)), nh, 7, prep=(g(scale), g(cos), g(sin))).view(B, H, W, nh, 64)
+    assert relerr(y, ref) < 2e-5
+    if H == 7:
+        with pytest.raises(RuntimeError, match="smaller"):
+            ops.attn_na2d(g(_pack(q, k, v))[:, :6].contiguous(), nh, 7)
+
+
+def test_sampler_steps_bit_exact(ops):
+    n = 2 * 3 * 17 * 5 + 3                                     # exercises the scalar tail
+    x, d, o2, a = (rn(n, seed=s, scale=sc) for s, sc in ((1, 30.0), (2, 1.0), (3, 1.0), (4, 2.0)))
+    c = [torch.tensor(v, dtype=torch.float32) for v in (0.731, -1.37, 1.618, 0.618)]
+    f = [float(v) for v in c]
+    X, D, O2, A = g(x), g(d), g(o2), g(a)
+    N = __import__("k_diffusion_amd")._native
+    cases = {
+        N.STEP_EULER: x + ((x - d) / c[0]) * c[1],
+        N.STEP_DPMPP_2M1: c[0] * x - c[1] * d,
+        N.STEP_DPMPP_2M2: c[0] * x - c[1] * (c[2] * d - c[3] * o2),
+        N.STEP_ADD_NOISE: x + d * f[0] * c[1],
+        N.STEP_LERP2: c[0] * d + c[1] * o2,
+        N.STEP_AXPY: x + d * c[0],
+    }
+    for op, ref in cases.items():
+        y = ops.sampler_step(op, X, D, in2=O2, c0=f[0], c1=f[1], c2=f[2], c3=f[3])
+        assert torch.equal(bits(y), bits(ref)), op
+    aux = torch.empty_like(X)
+    y = ops.sampler_step(N.STEP_HEUN_PRED, X, D, aux=aux, c0=f[0], c1=f[1])
+    dref = (x - d) / c[0]
+    assert torch.equal(bits(aux), bits(dref)) and torch.equal(bits(y), bits(x + dref * c[1]))
+    y = ops.sampler_step(N.STEP_HEUN_CORR, X, D, in2=O2, aux=A, c0=f[0], c1=f[1])
+    ref = x + ((a + (o2 - d) / c[0]) / 2) * c[1]
+    assert torch.equal(bits(y), bits(ref))
+    # in-place use (out aliases x), as the samplers do
+    Xc = X.clone()
+    ops.sampler_step(N.STEP_DPMPP_2M1, Xc, D, out=Xc, c0=f[0], c1=f[1])
+    assert torch.equal(bits(Xc), bits(cases[N.STEP_DPMPP_2M1]))
+
+
+def test_preconditioner_generic(ops):
+    x, fx = rn(3, 3, 8, 8, seed=1, scale=20.0), rn(3, 3, 8, 8, seed=2)
+    sigma = torch.tensor([0.01, 2.0, 160.0])
+    c_skip, c_out, c_in = (c.view(-1, 1, 1, 1) for c in solvers.karras_scalings(sigma, 0.5))
+    assert torch.equal(bits(ops.precond_in(g(x), g(sigma), 0.5)), bits(x * c_in))
+    assert torch.equal(bits(ops.precond_out(g(fx), g(x), g(sigma), 0.5)), bits(fx * c_out + x * c_skip))
+
+
+def test_conditioning_front_end(ops):
+    sigma = torch.tensor([0.01, 0.3, 7.0, 160.0])
+    w = rn(128, 1, seed=1)
+    ref = hdit.fourier_features((torch.log(sigma) / 4)[:, None], w)
+    assert (ops.fourier_sigma(g(sigma), g(w)).cpu() - ref).abs().max() < 2e-5
+    a9, w9 = rn(4, 9, seed=2, scale=0.3), rn(128, 9, seed=3)
+    assert (ops.fourier_features(g(a9), g(w9)).cpu() - hdit.fourier_features(a9, w9)).abs().max() < 5e-5
+    a, b, emb, c = rn(4, 256, seed=4), rn(256, seed=5), rn(11, 256, seed=6), rn(4, 256, seed=7)
+    ids = torch.tensor([10, 0, 3, 3])
+    assert torch.allclose(ops.cond_sum(g(a), g(b), g(emb), g(ids), g(c)).cpu(), a + b + emb[ids] + c, atol=1e-6)
+    assert torch.allclose(ops.cond_sum(g(a), g(c)).cpu(), a + c, atol=1e-6)
+
+
+def test_brownian_vs_oracle(ops):
+    seeds = [12345, 2 ** 63 - 7, 0]
+    per = 3 * 5 * 7
+    out = torch.empty(3, 3, 5, 7, device=DEV)
+    ops.brownian(out, g(torch.tensor(seeds, dtype=torch.int64)), 0.01, 80.0, 0.5, 3.25, 1.0 / (3.25 - 0.5) ** 0.5)
+    ref = obrown.brownian_increment(seeds, per, 0.01, 80.0, 0.5, 3.25, 1.0 / (3.25 - 0.5) ** 0.5)
+    assert np.abs(out.cpu().numpy().reshape(3, per) - ref).max() < 2e-5
+    # path consistency: W(a,c) == W(a,b) + W(b,c)
+    ab, bc, ac = (torch.empty(3, 3, 5, 7, device=DEV) for _ in range(3))
+    s = g(torch.tensor(seeds, dtype=torch.int64))
+    ops.brownian(ab, s, 0.01, 80.0, 1.0, 2.0, 1.0)
+    ops.brownian(bc, s, 0.01, 80.0, 2.0, 5.5, 1.0)
+    ops.brownian(ac, s, 0.01, 80.0, 1.0, 5.5, 1.0)
+    assert (ab + bc - ac).abs().max() < 1e-5
+    # unit variance of the normalised increment, independent elements
+    big = torch.empty(4, 1 << 16, device=DEV)
+    ops.brownian(big, g(torch.arange(4, dtype=torch.int64) + 99), 0.01, 160.0, 0.02, 0.03, 1.0 / 0.01 ** 0.5)
+    assert abs(big.var().item() - 1.0) < 0.02 and abs(big.mean().item()) < 0.01
+    assert abs(torch.corrcoef(big[:2])[0, 1].item()) < 0.02
+
+
+def test_to_uint8(ops):
+    x = torch.linspace(-1.5, 1.5, 1001)
+    ref = (((x.clamp(-1, 1) + 1) / 2) * 255).to(torch.uint8)
+    assert torch.equal(ops.to_uint8(g(x)).cpu(), ref)
