@@ -120,12 +120,17 @@ int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, int W, int 
  *   KD_STEP_HEUN_CORR  : d2 = (x2 - den)/c0 ; out = x + ((aux + d2)/2) * c1   (:181-183)  [x2 = in2]
  *   KD_STEP_DPMPP_2M1  : out = c0 * x - c1 * den                             (:600, also :533,:535,:571,:579)
  *   KD_STEP_DPMPP_2M2  : out = c0 * x - c1 * (c2 * den - c3 * in2)            (:604-605)   [old = in2]
- *   KD_STEP_ADD_NOISE  : out = x + (den * c0) * c1                           (:154,:572,:580)  [den = noise]
+ *   KD_STEP_ADD_NOISE  : out = x + ((den * c0) * c1) * c2                    (:154,:572,:580,:648)  [den = noise]
  *   KD_STEP_LERP2      : out = c0 * den + c1 * in2                           (:578)
  *   KD_STEP_AXPY       : out = x + den * c0                                  (:127, :276 terms)
+ *   KD_STEP_EULER_FROM : out = x + ((in2 - den) / c0) * c1                   (:213-214, :241-242)  [x2 = in2]
+ *   KD_STEP_AXPBY      : out = c0 * x + c1 * den                             (:638, :679)
+ *   KD_STEP_ADD_DIFF   : out = x + c0 * (den - in2)                          (:643, :645)
+ *   KD_STEP_TO_D       : out = (x - den) / c0                                (:46-48 to_d)
  */
 enum { KD_STEP_EULER = 0, KD_STEP_HEUN_PRED = 1, KD_STEP_HEUN_CORR = 2, KD_STEP_DPMPP_2M1 = 3,
-       KD_STEP_DPMPP_2M2 = 4, KD_STEP_ADD_NOISE = 5, KD_STEP_LERP2 = 6, KD_STEP_AXPY = 7 };
+       KD_STEP_DPMPP_2M2 = 4, KD_STEP_ADD_NOISE = 5, KD_STEP_LERP2 = 6, KD_STEP_AXPY = 7,
+       KD_STEP_EULER_FROM = 8, KD_STEP_AXPBY = 9, KD_STEP_ADD_DIFF = 10, KD_STEP_TO_D = 11 };
 int kd_sampler_step_f32(int op, const float* x, const float* den, const float* in2, float* out, float* aux,
                         float c0, float c1, float c2, float c3, long long n, void* stream);
 

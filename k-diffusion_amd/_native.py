@@ -12,7 +12,8 @@ LIB_PATH = os.environ.get("KDIFF_HIP_LIB") or os.path.join(_HERE, "csrc", "libkd
 # enums (include/kdiff_hip.h)
 A_PLAIN, A_MERGE2x2, A_PATCH_NCHW = 0, 1, 2
 EPI_STORE, EPI_RESIDUAL, EPI_GEGLU, EPI_SPLIT_LERP, EPI_UNPATCH_NCHW = 0, 1, 2, 3, 4
-STEP_EULER, STEP_HEUN_PRED, STEP_HEUN_CORR, STEP_DPMPP_2M1, STEP_DPMPP_2M2, STEP_ADD_NOISE, STEP_LERP2, STEP_AXPY = range(8)
+(STEP_EULER, STEP_HEUN_PRED, STEP_HEUN_CORR, STEP_DPMPP_2M1, STEP_DPMPP_2M2, STEP_ADD_NOISE, STEP_LERP2, STEP_AXPY,
+ STEP_EULER_FROM, STEP_AXPBY, STEP_ADD_DIFF, STEP_TO_D) = range(12)
 
 
 class KdGemm(C.Structure):

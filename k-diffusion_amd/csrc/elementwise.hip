@@ -28,8 +28,12 @@ __device__ __forceinline__ float step_one(float x, float den, float in2, float& 
   if (OP == KD_STEP_HEUN_CORR) { const float d2 = dvd(sub(in2, den), c0); return add(x, mul(dvd(add(aux, d2), 2.0f), c1)); }
   if (OP == KD_STEP_DPMPP_2M1) return sub(mul(c0, x), mul(c1, den));
   if (OP == KD_STEP_DPMPP_2M2) return sub(mul(c0, x), mul(c1, sub(mul(c2, den), mul(c3, in2))));
-  if (OP == KD_STEP_ADD_NOISE) return add(x, mul(mul(den, c0), c1));
+  if (OP == KD_STEP_ADD_NOISE) return add(x, mul(mul(mul(den, c0), c1), c2));
   if (OP == KD_STEP_LERP2) return add(mul(c0, den), mul(c1, in2));
+  if (OP == KD_STEP_EULER_FROM) return add(x, mul(dvd(sub(in2, den), c0), c1));
+  if (OP == KD_STEP_AXPBY) return add(mul(c0, x), mul(c1, den));
+  if (OP == KD_STEP_ADD_DIFF) return add(x, mul(c0, sub(den, in2)));
+  if (OP == KD_STEP_TO_D) return dvd(sub(x, den), c0);
   return add(x, mul(den, c0));  // KD_STEP_AXPY
 }
 
@@ -38,7 +42,7 @@ __global__ __launch_bounds__(EW_BLOCK) void sampler_step_kernel(const float* __r
                                                                 const float* __restrict__ in2, float* out, float* aux,
                                                                 float c0, float c1, float c2, float c3, long n) {
   constexpr bool USE_X = OP != KD_STEP_LERP2;
-  constexpr bool USE_IN2 = OP == KD_STEP_HEUN_CORR || OP == KD_STEP_DPMPP_2M2 || OP == KD_STEP_LERP2;
+  constexpr bool USE_IN2 = OP == KD_STEP_HEUN_CORR || OP == KD_STEP_DPMPP_2M2 || OP == KD_STEP_LERP2 || OP == KD_STEP_EULER_FROM || OP == KD_STEP_ADD_DIFF;
   constexpr bool AUX_R = OP == KD_STEP_HEUN_CORR, AUX_W = OP == KD_STEP_HEUN_PRED;
   const long nv = n >> 2;
   const long stride = (long)gridDim.x * EW_BLOCK;
@@ -145,7 +149,7 @@ extern "C" int kd_sampler_step_f32(int op, const float* x, const float* den, con
                                    float c0, float c1, float c2, float c3, long long n, void* stream) {
   if (n <= 0 || !den || !out) return fail(KD_EINVAL, "kd_sampler_step_f32: bad arguments");
   if (op != KD_STEP_LERP2 && !x) return fail(KD_EINVAL, "kd_sampler_step_f32: op %d needs x", op);
-  if ((op == KD_STEP_HEUN_CORR || op == KD_STEP_DPMPP_2M2 || op == KD_STEP_LERP2) && !in2) return fail(KD_EINVAL, "kd_sampler_step_f32: op %d needs in2", op);
+  if ((op == KD_STEP_HEUN_CORR || op == KD_STEP_DPMPP_2M2 || op == KD_STEP_LERP2 || op == KD_STEP_EULER_FROM || op == KD_STEP_ADD_DIFF) && !in2) return fail(KD_EINVAL, "kd_sampler_step_f32: op %d needs in2", op);
   if ((op == KD_STEP_HEUN_CORR || op == KD_STEP_HEUN_PRED) && !aux) return fail(KD_EINVAL, "kd_sampler_step_f32: op %d needs aux", op);
   hipStream_t s = (hipStream_t)stream;
   const unsigned g = ew_grid(n >> 2);
@@ -154,6 +158,7 @@ extern "C" int kd_sampler_step_f32(int op, const float* x, const float* den, con
   switch (op) {
     KD_OP(KD_STEP_EULER) KD_OP(KD_STEP_HEUN_PRED) KD_OP(KD_STEP_HEUN_CORR) KD_OP(KD_STEP_DPMPP_2M1)
     KD_OP(KD_STEP_DPMPP_2M2) KD_OP(KD_STEP_ADD_NOISE) KD_OP(KD_STEP_LERP2) KD_OP(KD_STEP_AXPY)
+    KD_OP(KD_STEP_EULER_FROM) KD_OP(KD_STEP_AXPBY) KD_OP(KD_STEP_ADD_DIFF) KD_OP(KD_STEP_TO_D)
     default: return fail(KD_EINVAL, "kd_sampler_step_f32: unknown op %d", op);
   }
 #undef KD_OP

@@ -1,0 +1,51 @@
+"""Karras et al. preconditioned denoiser wrapper (k_diffusion/layers.py:45-111, sampling part).
+
+``Denoiser(inner_model, sigma_data)`` keeps the reference's constructor, attributes
+(``inner_model``, ``sigma_data``, ``weighting``, ``scales``) and ``forward(input, sigma, **kwargs)``.
+With the native HDiT inner model the three preconditioning passes (x * c_in, F * c_out, + x * c_skip)
+disappear into the patch-in / patch-out GEMMs; with a foreign inner model they run as two HIP
+elementwise kernels around it.  The training-time ``loss`` methods are out of scope.
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+
+class Denoiser(nn.Module):
+    """D(x, sigma) = F(x * c_in, sigma) * c_out + x * c_skip."""
+
+    def __init__(self, inner_model, sigma_data=1., weighting='karras', scales=1):
+        super().__init__()
+        self.inner_model = inner_model
+        self.sigma_data = sigma_data
+        self.scales = scales
+        if not callable(weighting) and weighting not in ('karras', 'soft-min-snr', 'snr'):
+            raise ValueError(f'Unknown weighting type {weighting}')
+        self.weighting = weighting
+
+    def get_scalings(self, sigma):
+        """(c_skip, c_out, c_in) for a sigma tensor (layers.py:70-74)."""
+        var = sigma ** 2 + self.sigma_data ** 2
+        return self.sigma_data ** 2 / var, sigma * self.sigma_data / var ** 0.5, 1 / var ** 0.5
+
+    def loss(self, *args, **kwargs):
+        raise NotImplementedError('training losses are outside this package\'s scope (sampling hot path only)')
+
+    def forward(self, input, sigma, **kwargs):
+        inner = self.inner_model
+        fused = getattr(inner, 'forward_preconditioned', None)
+        if fused is not None:
+            return fused(input, sigma, self.sigma_data, **kwargs)
+        sigma = sigma.to(device=input.device, dtype=torch.float32).reshape(-1).expand(input.shape[0]).contiguous()
+        x = input.contiguous()
+        f = inner(ops.precond_in(x, sigma, self.sigma_data), sigma, **kwargs)
+        return ops.precond_out(f.contiguous(), x, sigma, self.sigma_data)
+
+
+class DenoiserWithVariance(Denoiser):
+    pass
+
+
+class SimpleLossDenoiser(Denoiser):
+    pass

@@ -1,0 +1,426 @@
+"""Hourglass diffusion transformer ("image_transformer_v2") denoiser, MI355X-native forward.
+
+Drop-in for ``k_diffusion.models.ImageTransformerDenoiserModelV2``
+(k_diffusion/models/image_transformer_v2.py:667-762): same constructor, same ``forward(x, sigma,
+aug_cond, class_cond, mapping_cond)``, same ``state_dict`` keys and shapes (the checkpoint
+contract), same error behaviour for missing conditioning.
+
+What differs is *how* the forward runs.  The reference is a tree of nn.Modules issuing ~5 400
+ATen / Triton / NATTEN / flash-attn launches per forward.  Here the module tree only *holds*
+weights; the forward is a flat, pre-planned list of ~90 launches of hand-written gfx950 kernels
+(csrc/, C ABI in include/kdiff_hip.h) over a token-major fp32 workspace:
+
+  conditioning : FourierFeatures kernel -> GEMMs (mapping network) -> ONE GEMM producing every
+                 AdaRMSNorm scale of the network ([B, sum(d)] table, "+1" folded into the epilogue)
+  patch_in     : NCHW gather + patch + Linear (+ Karras c_in) in one GEMM
+  each layer   : [AdaRMSNorm -> qkv GEMM] -> attention core with cosine-sim scaling and axial RoPE
+                 applied on the fly -> [out_proj GEMM + residual] ;
+                 [AdaRMSNorm -> up GEMM -> GEGLU] -> [down GEMM + residual]
+  merge/split  : 2x2 space-to-depth / depth-to-space folded into GEMM addressing; lerp in the epilogue
+  patch_out    : [RMSNorm -> GEMM -> NHWC->NCHW scatter (+ Karras c_out, c_skip)] in one GEMM
+
+The plan (workspace + prebuilt launch descriptors) is cached per input shape.  There is no eager /
+CPU path: calling ``forward`` without a ROCm device or without the built library raises.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Union
+
+import torch
+from torch import nn
+
+from .. import _native as nat
+from . import axial_rope
+
+D_HEAD = 64
+
+
+# ---------------------------------------------------------------------------------- configuration
+
+@dataclass
+class GlobalAttentionSpec:
+    d_head: int
+
+
+@dataclass
+class NeighborhoodAttentionSpec:
+    d_head: int
+    kernel_size: int
+
+
+@dataclass
+class ShiftedWindowAttentionSpec:
+    d_head: int
+    window_size: int
+
+
+@dataclass
+class NoAttentionSpec:
+    pass
+
+
+@dataclass
+class LevelSpec:
+    depth: int
+    width: int
+    d_ff: int
+    self_attn: Union[GlobalAttentionSpec, NeighborhoodAttentionSpec, ShiftedWindowAttentionSpec, NoAttentionSpec]
+    dropout: float
+
+
+@dataclass
+class MappingSpec:
+    depth: int
+    width: int
+    d_ff: int
+    dropout: float
+
+
+# ---------------------------------------------------------------------------------- weight holders
+
+class _Holder(nn.Module):
+    """Names a group of parameters / sub-holders so that state_dict keys match the reference."""
+
+    def __init__(self, **children):
+        super().__init__()
+        for k, v in children.items():
+            if isinstance(v, nn.Parameter):
+                self.register_parameter(k, v)
+            elif isinstance(v, torch.Tensor):
+                self.register_buffer(k, v)
+            else:
+                self.add_module(k, v)
+
+
+def _linear_weight(out_f, in_f, zero=False):
+    """nn.Linear's default init (kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(in), 1/sqrt(in))), or the
+    reference's zero_init (image_transformer_v2.py:37-41)."""
+    w = torch.zeros(out_f, in_f)
+    if not zero:
+        bound = 1.0 / math.sqrt(in_f)
+        w.uniform_(-bound, bound)
+    return _Holder(weight=nn.Parameter(w))
+
+
+def _layer(spec: LevelSpec, cond_features: int):
+    d, parts = spec.width, {}
+    if not isinstance(spec.self_attn, NoAttentionSpec):
+        nh = d // spec.self_attn.d_head
+        parts["self_attn"] = _Holder(
+            scale=nn.Parameter(torch.full([nh], 10.0)),
+            norm=_Holder(linear=_linear_weight(d, cond_features, zero=True)),
+            qkv_proj=_linear_weight(3 * d, d),
+            pos_emb=_Holder(freqs=axial_rope.rope_freqs(spec.self_attn.d_head // 2, nh)),
+            out_proj=_linear_weight(d, d, zero=True))
+    parts["ff"] = _Holder(norm=_Holder(linear=_linear_weight(d, cond_features, zero=True)),
+                          up_proj=_linear_weight(2 * spec.d_ff, d),
+                          down_proj=_linear_weight(d, spec.d_ff, zero=True))
+    return _Holder(**parts)
+
+
+def _rms_scale(n):
+    return _Holder(scale=nn.Parameter(torch.ones(n)))
+
+
+# ---------------------------------------------------------------------------------- the plan
+
+class _Launch:
+    __slots__ = ("fn", "args", "what")
+
+    def __init__(self, fn, args, what):
+        self.fn, self.args, self.what = fn, args, what
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class _Plan:
+    """Workspace + prebuilt launch list for one (batch, H, W, conditioning-kinds) combination."""
+
+    def __init__(self, model, B, H, W, has_aug, has_class, has_mapping_cond, device):
+        lib = nat.lib()
+        m = model
+        self.keep = []           # descriptors and tensors that must outlive the plan
+        self.launches = []
+        f32 = dict(device=device, dtype=torch.float32)
+        ph, pw = m.patch_size
+        if H % ph or W % pw:
+            raise ValueError(f"input {H}x{W} not divisible by the patch size {ph}x{pw}")
+        levels = m.level_specs
+        n_lv = len(levels)
+        grids = [(H // ph, W // pw)]
+        for _ in range(n_lv - 1):
+            gh, gw = grids[-1]
+            if gh % 2 or gw % 2:
+                raise ValueError(f"token grid {gh}x{gw} cannot be merged 2x2")
+            grids.append((gh // 2, gw // 2))
+        self.B, self.grids = B, grids
+        mw, mdff = m.mapping_spec.width, m.mapping_spec.d_ff
+
+        # ---- static buffers -----------------------------------------------------------------
+        self.sigma = torch.empty(B, **f32)
+        self.class_ids = torch.zeros(B, device=device, dtype=torch.int64)
+        self.aug_in = torch.zeros(B, 9, **f32) if has_aug else None
+        self.map_in = torch.zeros(B, m.mapping_cond_dim, **f32) if has_mapping_cond else None
+        xs = [torch.empty(B, gh, gw, lv.width, **f32) for (gh, gw), lv in zip(grids, levels)]
+        toks = [B * gh * gw for gh, gw in grids]
+        qkv = torch.empty(max(t * 3 * lv.width for t, lv in zip(toks, levels)), **f32)
+        att = torch.empty(max(t * lv.width for t, lv in zip(toks, levels)), **f32)
+        hid = torch.empty(max(t * lv.d_ff for t, lv in zip(toks, levels)), **f32)
+        ff, temb, emb, mres, cond = (torch.empty(B, mw, **f32) for _ in range(5))
+        mh = torch.empty(B, mdff, **f32)
+        norm_mods = m._ada_norm_modules()
+        offsets, total = {}, 0
+        for name, mod in norm_mods:
+            offsets[name] = total
+            total += mod.linear.weight.shape[0]
+        wcat = torch.cat([mod.linear.weight.detach() for _, mod in norm_mods], dim=0).contiguous()
+        scales = torch.empty(B, total, **f32)
+        self.keep += [xs, qkv, att, hid, ff, temb, emb, mres, cond, mh, wcat, scales]
+        self.xs = xs
+
+        def gemm(what, A, Wt, Cc, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, scale_ptr=None, scale_stride=0,
+                 rows_per_sample=0, R=None, grid=(0, 0), patch=(0, 0, 0), out_add=0.0, sigma=None, fac=None):
+            d = nat.KdGemm()
+            d.M, d.N, d.K, d.a_mode, d.epi = M, N, K, a_mode, epi
+            d.norm = 1 if scale_ptr is not None else 0
+            d.rows_per_sample, d.scale_stride = rows_per_sample, scale_stride
+            d.gh, d.gw = grid
+            d.ph, d.pw, d.chan = patch
+            d.eps, d.out_add, d.sigma_data = 1e-6, out_add, 1.0
+            d.A = None if A is None else A.data_ptr()
+            d.W, d.C = Wt.data_ptr(), (None if Cc is None else Cc.data_ptr())
+            d.R = None if R is None else R.data_ptr()
+            d.scale = scale_ptr
+            d.sigma = None if sigma is None else sigma.data_ptr()
+            d.fac = None if fac is None else fac.data_ptr()
+            self.keep.append(d)
+            self.launches.append(_Launch(lib.kd_gemm_f32, (C.byref(d),), what))
+            return d
+
+        def call(what, fn, *args):
+            self.launches.append(_Launch(fn, args, what))
+
+        # ---- conditioning (image_transformer_v2.py:734-740, :569-581) ------------------------------
+        call("fourier_sigma", lib.kd_fourier_sigma_f32, _ptr(self.sigma), _ptr(m.time_emb.weight), _ptr(ff), B, mw // 2)
+        gemm("time_in_proj", ff, m.time_in_proj.weight, temb, B, mw, mw)
+        if has_aug:
+            aug_ff, aug_proj = torch.empty(B, mw, **f32), torch.empty(B, mw, **f32)
+            self.keep += [aug_ff, aug_proj]
+            call("fourier_aug", lib.kd_fourier_f32, _ptr(self.aug_in), _ptr(m.aug_emb.weight), _ptr(aug_ff), B, 9, mw // 2)
+            gemm("aug_in_proj", aug_ff, m.aug_in_proj.weight, aug_proj, B, mw, mw)
+            aug_term, aug_rows = aug_proj, 1
+        else:
+            # aug_cond = zeros  =>  FourierFeatures = [cos 0, sin 0] = [1..1, 0..0]: a constant vector
+            z_ff, aug_const = torch.empty(1, mw, **f32), torch.empty(1, mw, **f32)
+            self.keep += [z_ff, aug_const]
+            zeros9 = torch.zeros(1, 9, **f32)
+            self.keep.append(zeros9)
+            call("fourier_aug0", lib.kd_fourier_f32, _ptr(zeros9), _ptr(m.aug_emb.weight), _ptr(z_ff), 1, 9, mw // 2)
+            gemm("aug_in_proj0", z_ff, m.aug_in_proj.weight, aug_const, 1, mw, mw)
+            aug_term, aug_rows = aug_const, 0
+        map_term = None
+        if has_mapping_cond:
+            map_term = torch.empty(B, mw, **f32)
+            self.keep.append(map_term)
+            gemm("mapping_cond_in_proj", self.map_in, m.mapping_cond_in_proj.weight, map_term, B, mw, m.mapping_cond_dim)
+        call("cond_sum", lib.kd_cond_sum_f32, _ptr(emb), _ptr(temb), _ptr(aug_term), aug_rows,
+             _ptr(m.class_emb.weight) if has_class else None, _ptr(self.class_ids) if has_class else None,
+             None if map_term is None else _ptr(map_term), B, mw)
+        call("mapping.in_norm", lib.kd_rmsnorm_f32, _ptr(emb), _ptr(m.mapping.in_norm.scale), _ptr(mres), B, mw, C.c_float(1e-6))
+        for blk in m.mapping.blocks:
+            gemm("mapping.up_proj", mres, blk.up_proj.weight, mh, B, mdff, mw, epi=nat.EPI_GEGLU,
+                 scale_ptr=blk.norm.scale.data_ptr(), scale_stride=0, rows_per_sample=B)
+            gemm("mapping.down_proj", mh, blk.down_proj.weight, mres, B, mw, mdff, epi=nat.EPI_RESIDUAL, R=mres)
+        call("mapping.out_norm", lib.kd_rmsnorm_f32, _ptr(mres), _ptr(m.mapping.out_norm.scale), _ptr(cond), B, mw, C.c_float(1e-6))
+        gemm("ada_norm_scales", cond, wcat, scales, B, total, mw, out_add=1.0)
+
+        # ---- hourglass ------------------------------------------------------------------------
+        self.d_patch_in = gemm("patch_in", None, m.patch_in.proj.weight, xs[0], toks[0], levels[0].width, m.in_channels * ph * pw,
+                               a_mode=nat.A_PATCH_NCHW, grid=grids[0], patch=(ph, pw, m.in_channels))
+
+        def scale_ptr(name):
+            return scales.data_ptr() + 4 * offsets[name]
+
+        def add_layer(li, prefix, mod, index):
+            lv, (gh, gw), T = levels[li], grids[li], toks[li]
+            d, x = lv.width, xs[li]
+            rps = gh * gw
+            if hasattr(mod, "self_attn"):
+                sa, spec = mod.self_attn, lv.self_attn
+                nh = d // spec.d_head
+                gemm(prefix + "qkv_proj", x, sa.qkv_proj.weight, qkv, T, 3 * d, d, scale_ptr=scale_ptr(prefix + "self_attn.norm"),
+                     scale_stride=total, rows_per_sample=rps)
+                cos_t, sin_t = m._rope_tables(li, grids, sa, device)
+                self.keep += [cos_t, sin_t]
+                prep = (1, _ptr(sa.scale), _ptr(cos_t), _ptr(sin_t), C.c_float(1e-6))
+                if isinstance(spec, GlobalAttentionSpec):
+                    call(prefix + "attn_global", lib.kd_attn_global_f32, _ptr(qkv), _ptr(att), B, gh * gw, nh, *prep)
+                elif isinstance(spec, NeighborhoodAttentionSpec):
+                    call(prefix + "attn_na2d", lib.kd_attn_na2d_f32, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.kernel_size, *prep)
+                else:
+                    shift = spec.window_size // 2 if index % 2 == 1 else 0          # :523
+                    call(prefix + "attn_window", lib.kd_attn_window_f32, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.window_size, shift, *prep)
+                gemm(prefix + "out_proj", att, sa.out_proj.weight, x, T, d, d, epi=nat.EPI_RESIDUAL, R=x)
+            gemm(prefix + "up_proj", x, mod.ff.up_proj.weight, hid, T, lv.d_ff, d, epi=nat.EPI_GEGLU,
+                 scale_ptr=scale_ptr(prefix + "ff.norm"), scale_stride=total, rows_per_sample=rps)
+            gemm(prefix + "down_proj", hid, mod.ff.down_proj.weight, x, T, d, lv.d_ff, epi=nat.EPI_RESIDUAL, R=x)
+
+        for li in range(n_lv - 1):
+            for i, mod in enumerate(m.down_levels[li]):
+                add_layer(li, f"down_levels.{li}.{i}.", mod, i)
+            gemm(f"merges.{li}", xs[li], m.merges[li].proj.weight, xs[li + 1], toks[li + 1], levels[li + 1].width, 4 * levels[li].width,
+                 a_mode=nat.A_MERGE2x2, grid=grids[li + 1])
+        for i, mod in enumerate(m.mid_level):
+            add_layer(n_lv - 1, f"mid_level.{i}.", mod, i)
+        for li in reversed(range(n_lv - 1)):
+            gemm(f"splits.{li}", xs[li + 1], m.splits[li].proj.weight, xs[li], toks[li + 1], 4 * levels[li].width, levels[li + 1].width,
+                 epi=nat.EPI_SPLIT_LERP, R=xs[li], fac=m.splits[li].fac, grid=grids[li + 1])
+            for i, mod in enumerate(m.up_levels[li]):
+                add_layer(li, f"up_levels.{li}.{i}.", mod, i + levels[li].depth)                      # :697
+        self.d_patch_out = gemm("patch_out", xs[0], m.patch_out.proj.weight, None, toks[0], m.out_channels * ph * pw, levels[0].width,
+                                epi=nat.EPI_UNPATCH_NCHW, scale_ptr=m.out_norm.scale.data_ptr(), scale_stride=0,
+                                rows_per_sample=grids[0][0] * grids[0][1], grid=grids[0], patch=(ph, pw, m.out_channels))
+
+    def run(self, x, out, sigma_data):
+        """x: input image (read by patch_in and, when preconditioning, by patch_out); out: result image.
+        ``self.sigma`` / ``self.class_ids`` / ``self.aug_in`` / ``self.map_in`` were filled by the caller."""
+        pin, pout = self.d_patch_in, self.d_patch_out
+        pin.A = x.data_ptr()
+        pout.C = out.data_ptr()
+        if sigma_data is None:
+            pin.sigma, pout.sigma, pout.R = None, None, None
+        else:
+            sp = self.sigma.data_ptr()
+            pin.sigma, pout.sigma, pout.R = sp, sp, x.data_ptr()
+            pin.sigma_data = pout.sigma_data = float(sigma_data)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for ln in self.launches:
+            rc = ln.fn(*ln.args, stream)
+            if rc:
+                nat.check(rc, ln.what)
+
+
+# ---------------------------------------------------------------------------------- the model
+
+class ImageTransformerDenoiserModelV2(nn.Module):
+    def __init__(self, levels, mapping, in_channels, out_channels, patch_size, num_classes=0, mapping_cond_dim=0):
+        super().__init__()
+        for lv in levels:
+            sa = lv.self_attn
+            if not isinstance(sa, (GlobalAttentionSpec, NeighborhoodAttentionSpec, ShiftedWindowAttentionSpec, NoAttentionSpec)):
+                raise ValueError(f"unsupported self attention spec {sa}")
+            if not isinstance(sa, NoAttentionSpec) and sa.d_head != D_HEAD:
+                raise ValueError(f"the HIP attention cores are built for d_head == {D_HEAD} (got {sa.d_head})")
+            if not isinstance(sa, NoAttentionSpec) and lv.width % sa.d_head:
+                raise ValueError(f"width {lv.width} is not a multiple of d_head {sa.d_head}")
+        self.level_specs, self.mapping_spec = list(levels), mapping
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.patch_size = (patch_size, patch_size) if isinstance(patch_size, int) else tuple(patch_size)
+        self.num_classes, self.mapping_cond_dim = num_classes, mapping_cond_dim
+        ph, pw = self.patch_size
+        mw = mapping.width
+
+        self.patch_in = _Holder(proj=_linear_weight(levels[0].width, in_channels * ph * pw))
+        self.time_emb = _Holder(weight=torch.randn(mw // 2, 1))
+        self.time_in_proj = _linear_weight(mw, mw)
+        self.aug_emb = _Holder(weight=torch.randn(mw // 2, 9))
+        self.aug_in_proj = _linear_weight(mw, mw)
+        self.class_emb = _Holder(weight=nn.Parameter(torch.randn(num_classes, mw))) if num_classes else None
+        self.mapping_cond_in_proj = _linear_weight(mw, mapping_cond_dim) if mapping_cond_dim else None
+        self.mapping = _Holder(
+            in_norm=_rms_scale(mw),
+            blocks=nn.ModuleList([_Holder(norm=_rms_scale(mw), up_proj=_linear_weight(2 * mapping.d_ff, mw),
+                                          down_proj=_linear_weight(mw, mapping.d_ff, zero=True)) for _ in range(mapping.depth)]),
+            out_norm=_rms_scale(mw))
+        self.down_levels, self.up_levels = nn.ModuleList(), nn.ModuleList()
+        for i, lv in enumerate(levels):
+            if i < len(levels) - 1:
+                self.down_levels.append(nn.ModuleList([_layer(lv, mw) for _ in range(lv.depth)]))
+                self.up_levels.append(nn.ModuleList([_layer(lv, mw) for _ in range(lv.depth)]))
+            else:
+                self.mid_level = nn.ModuleList([_layer(lv, mw) for _ in range(lv.depth)])
+        self.merges = nn.ModuleList([_Holder(proj=_linear_weight(b.width, 4 * a.width)) for a, b in zip(levels[:-1], levels[1:])])
+        self.splits = nn.ModuleList([_Holder(proj=_linear_weight(4 * a.width, b.width), fac=nn.Parameter(torch.ones(1) * 0.5))
+                                     for a, b in zip(levels[:-1], levels[1:])])
+        self.out_norm = _rms_scale(levels[0].width)
+        self.patch_out = _Holder(proj=_linear_weight(out_channels * ph * pw, levels[0].width, zero=True))
+        self._plans, self._fingerprint = {}, None
+
+    # ---- bookkeeping ---------------------------------------------------------------------------
+    def _ada_norm_modules(self):
+        out = []
+
+        def visit(prefix, layers):
+            for i, mod in enumerate(layers):
+                if hasattr(mod, "self_attn"):
+                    out.append((f"{prefix}{i}.self_attn.norm", mod.self_attn.norm))
+                out.append((f"{prefix}{i}.ff.norm", mod.ff.norm))
+        for li, lvl in enumerate(self.down_levels):
+            visit(f"down_levels.{li}.", lvl)
+        for li, lvl in enumerate(self.up_levels):
+            visit(f"up_levels.{li}.", lvl)
+        visit("mid_level.", self.mid_level)
+        return out
+
+    def _rope_tables(self, li, grids, sa, device):
+        h0, w0 = grids[0]
+        pos = axial_rope.make_axial_pos(h0, w0).view(h0, w0, 2)
+        for _ in range(li):
+            pos = axial_rope.downscale_pos(pos)
+        cos_t, sin_t = axial_rope.rope_tables(pos, sa.pos_emb.freqs)
+        return cos_t.to(device), sin_t.to(device)
+
+    def _weights_fingerprint(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def param_groups(self, base_lr=5e-4, mapping_lr_scale=1 / 3):
+        raise NotImplementedError("training is outside this package's scope (sampling hot path only)")
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def forward(self, x, sigma, aug_cond=None, class_cond=None, mapping_cond=None):
+        """Inner model F(x, sigma): [B, C, H, W] fp32 on a ROCm device -> [B, C, H, W]."""
+        return self._run(x, sigma, aug_cond, class_cond, mapping_cond, None)
+
+    def forward_preconditioned(self, x, sigma, sigma_data, aug_cond=None, class_cond=None, mapping_cond=None):
+        """Denoiser D(x, sigma) = F(x * c_in, sigma) * c_out + x * c_skip (k_diffusion/layers.py:88-90)
+        with c_in folded into the patch gather and c_out / c_skip into the un-patch scatter."""
+        return self._run(x, sigma, aug_cond, class_cond, mapping_cond, sigma_data)
+
+    @torch.no_grad()
+    def _run(self, x, sigma, aug_cond, class_cond, mapping_cond, sigma_data):
+        if class_cond is None and self.class_emb is not None:
+            raise ValueError("class_cond must be specified if num_classes > 0")
+        if mapping_cond is None and self.mapping_cond_in_proj is not None:
+            raise ValueError("mapping_cond must be specified if mapping_cond_dim > 0")
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected input [B, {self.in_channels}, H, W], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("ImageTransformerDenoiserModelV2 runs on the HIP path only: move the model and inputs "
+                               "to a ROCm device (there is no CPU fallback)")
+        if x.dtype != torch.float32:
+            raise TypeError(f"fp32 inputs only (got {x.dtype})")
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        fp = self._weights_fingerprint()
+        if fp != self._fingerprint:
+            self._plans, self._fingerprint = {}, fp
+        has_class = self.class_emb is not None
+        key = (B, H, W, aug_cond is not None, has_class, self.mapping_cond_in_proj is not None, x.device)
+        plan = self._plans.get(key)
+        if plan is None:
+            if self.patch_in.proj.weight.device != x.device:
+                raise RuntimeError(f"model weights are on {self.patch_in.proj.weight.device}, input on {x.device}")
+            plan = self._plans[key] = _Plan(self, B, H, W, key[3], has_class, key[5], x.device)
+        plan.sigma.copy_(sigma.reshape(-1).expand(B) if sigma.numel() == 1 else sigma.reshape(B), non_blocking=True)
+        if has_class:
+            plan.class_ids.copy_(class_cond.reshape(B), non_blocking=True)
+        if plan.aug_in is not None:
+            plan.aug_in.copy_(aug_cond.reshape(B, 9), non_blocking=True)
+        if plan.map_in is not None:
+            plan.map_in.copy_(mapping_cond.reshape(B, self.mapping_cond_dim), non_blocking=True)
+        out = torch.empty(B, self.out_channels, H, W, device=x.device, dtype=torch.float32)
+        plan.run(x, out, sigma_data)
+        return out

@@ -223,7 +223,7 @@ def attn_na2d(qkv, nh, kernel_size, prep=None, out=None):
     return out
 
 
-def sampler_step(op, x, den, in2=None, out=None, aux=None, c0=0.0, c1=0.0, c2=0.0, c3=0.0):
+def sampler_step(op, x, den, in2=None, out=None, aux=None, c0=0.0, c1=0.0, c2=1.0, c3=0.0):
     out = torch.empty_like(den) if out is None else out
     for name, t in (("x", x), ("den", den), ("in2", in2), ("out", out), ("aux", aux)):
         if t is not None:

@@ -1,0 +1,475 @@
+"""Karras ODE/SDE samplers, MI355X-native.
+
+Same call surface as k_diffusion/sampling.py: ``sample_X(model, x, sigmas, extra_args=None,
+callback=None, disable=None, **solver_kwargs) -> Tensor`` with ``model(x, sigma[B], **extra_args)
+-> denoised``, ``callback({'x','i','sigma','sigma_hat','denoised'})`` once per step, pluggable
+``noise_sampler(sigma, sigma_next)``, functional in ``x``.
+
+How the loop runs here (vs. the reference's ~12 scalar + ~6 tensor ATen launches and one
+device->host sync per step, sampling.py:594-606):
+  * the schedule is read back to the host ONCE; every per-step coefficient is evaluated there with
+    0-dim fp32 torch ops in the reference's own operation order (bit-identical scalars, SURVEY.md
+    App. A.7), so there is no device-side scalar math and no per-step sync;
+  * each step's tensor arithmetic is ONE fused HIP launch (``kd_sampler_step_f32``) whose expression
+    tree reproduces the reference's rounding sequence exactly (bit-exact given the same denoised);
+  * the per-step sigma vectors handed to the model are rows of one table uploaded before the loop.
+"""
+import math
+
+import torch
+from tqdm.auto import trange
+
+from . import _native as nat
+from . import ops, utils
+
+# --------------------------------------------------------------------------------- schedules
+
+
+def append_zero(x):
+    return torch.cat([x, x.new_zeros([1])])
+
+
+def get_sigmas_karras(n, sigma_min, sigma_max, rho=7., device='cpu'):
+    """Karras et al. (2022) schedule.  Evaluated on the CPU (fp32 ramp, double scalars) exactly as the
+    reference does (sampling.py:17-23) and then moved, so the schedule is bit-identical everywhere."""
+    ramp = torch.linspace(0, 1, n)
+    lo, hi = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
+    return append_zero((hi + ramp * (lo - hi)) ** rho).to(device)
+
+
+def get_sigmas_exponential(n, sigma_min, sigma_max, device='cpu'):
+    return append_zero(torch.linspace(math.log(sigma_max), math.log(sigma_min), n).exp()).to(device)
+
+
+def get_sigmas_polyexponential(n, sigma_min, sigma_max, rho=1., device='cpu'):
+    ramp = torch.linspace(1, 0, n) ** rho
+    return append_zero(torch.exp(ramp * (math.log(sigma_max) - math.log(sigma_min)) + math.log(sigma_min))).to(device)
+
+
+def get_sigmas_vp(n, beta_d=19.9, beta_min=0.1, eps_s=1e-3, device='cpu'):
+    t = torch.linspace(1, eps_s, n)
+    return append_zero(torch.sqrt(torch.exp(beta_d * t ** 2 / 2 + beta_min * t) - 1)).to(device)
+
+
+# --------------------------------------------------------------------------------- helpers
+
+def to_d(x, sigma, denoised):
+    """Karras ODE derivative (x - denoised) / sigma."""
+    if x.is_cuda and (not torch.is_tensor(sigma) or sigma.numel() == 1):
+        return ops.sampler_step(nat.STEP_TO_D, x.contiguous(), denoised.contiguous(), c0=float(sigma))
+    return (x - denoised) / utils.append_dims(sigma, x.ndim)
+
+
+def get_ancestral_step(sigma_from, sigma_to, eta=1.):
+    """(sigma_down, sigma_up) of an ancestral step (sampling.py:51-58)."""
+    if not eta:
+        return sigma_to, 0.
+    sigma_up = min(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    return (sigma_to ** 2 - sigma_up ** 2) ** 0.5, sigma_up
+
+
+def default_noise_sampler(x):
+    return lambda sigma, sigma_next: torch.randn_like(x)
+
+
+def _f(v):
+    return float(v)
+
+
+class BatchedBrownianTree:
+    """Brownian increments W(t1) - W(t0) for a tensor shaped like ``x`` (sampling.py:65-89).
+
+    The reference wraps one host-side ``torchsde.BrownianTree`` per seed.  Here every element owns a
+    virtual Brownian tree evaluated on demand by the HIP kernel ``kd_brownian_f32`` (Philox4x32-10
+    keyed by the seed, counter = (element, tree node)); a list of seeds gives one tree per batch item,
+    a single seed one tree over the whole tensor.  The random stream is this package's own
+    (torchsde's is generator- and device-dependent and not reproducible here)."""
+
+    def __init__(self, x, t0, t1, seed=None, **kwargs):
+        t0, t1, self.sign = self.sort(_f(t0), _f(t1))
+        self.t0, self.t1 = t0, t1
+        if seed is None:
+            seed = torch.randint(0, 2 ** 63 - 1, []).item()
+        try:
+            seeds = [int(s) for s in seed]
+            assert len(seeds) == x.shape[0]
+            self.batched = True
+        except TypeError:
+            seeds, self.batched = [int(seed)], False
+        self.shape, self.device = tuple(x.shape), x.device
+        self.depth = int(kwargs.get('depth', 36))
+        self.seeds = torch.tensor([s & 0x7FFFFFFFFFFFFFFF for s in seeds], dtype=torch.int64, device=x.device)
+
+    @staticmethod
+    def sort(a, b):
+        return (a, b, 1) if a < b else (b, a, -1)
+
+    def _clip(self, t):
+        # queries are derived from the schedule through exp(log(sigma)) round trips: allow roundoff
+        # beyond the end points, reject anything really outside the tree's interval
+        slack = 1e-4 * max(abs(self.t0), abs(self.t1), 1e-12)
+        if t < self.t0 - slack or t > self.t1 + slack:
+            raise ValueError(f'Brownian query {t} outside the tree interval [{self.t0}, {self.t1}]')
+        return min(max(t, self.t0), self.t1)
+
+    def increment(self, t0, t1, mult=1.0):
+        t0, t1, sign = self.sort(self._clip(_f(t0)), self._clip(_f(t1)))
+        out = torch.empty(self.shape, device=self.device, dtype=torch.float32)
+        view = out if self.batched else out.view(1, -1)
+        ops.brownian(view, self.seeds, self.t0, self.t1, t0, t1, mult * self.sign * sign, self.depth)
+        return out
+
+    def __call__(self, t0, t1):
+        return self.increment(t0, t1)
+
+
+class BrownianTreeNoiseSampler:
+    """Unit-variance, path-consistent noise between two sigmas (sampling.py:92-114)."""
+
+    def __init__(self, x, sigma_min, sigma_max, seed=None, transform=lambda x: x):
+        self.transform = transform
+        t0, t1 = self.transform(torch.as_tensor(_f(sigma_min))), self.transform(torch.as_tensor(_f(sigma_max)))
+        self.tree = BatchedBrownianTree(x, t0, t1, seed)
+
+    def __call__(self, sigma, sigma_next):
+        t0, t1 = _f(self.transform(torch.as_tensor(_f(sigma)))), _f(self.transform(torch.as_tensor(_f(sigma_next))))
+        return self.tree.increment(t0, t1, mult=1.0 / math.sqrt(abs(t1 - t0)))
+
+
+class _Loop:
+    """State shared by the sampler loops: host copy of the schedule, working buffer, model calls."""
+
+    def __init__(self, model, x, sigmas, extra_args, callback):
+        if not x.is_cuda:
+            raise RuntimeError('the samplers run on the HIP path only: x must live on a ROCm device (no CPU fallback)')
+        if x.dtype != torch.float32:
+            raise TypeError(f'fp32 latents only (got {x.dtype})')
+        self.model, self.extra, self.callback = model, ({} if extra_args is None else extra_args), callback
+        self.sigmas = sigmas
+        self.sig = sigmas.detach().to('cpu', torch.float32)      # the ONE device->host transfer
+        self.x = x.contiguous()
+        self.B = x.shape[0]
+        self._owned = False
+
+    def __len__(self):
+        return len(self.sig) - 1
+
+    def sigma_rows(self, values):
+        """[len(values), B] device table of per-sample sigma vectors (sigma * s_in)."""
+        v = torch.stack([torch.as_tensor(s, dtype=torch.float32).reshape(()) for s in values])
+        return v.to(self.x.device)[:, None].expand(len(values), self.B).contiguous()
+
+    def denoise(self, sigma_row, x=None):
+        return self.model(self.x if x is None else x, sigma_row, **self.extra).contiguous()
+
+    def report(self, i, denoised, sigma_hat=None):
+        if self.callback is not None:
+            s = self.sigmas[i]
+            self.callback({'x': self.x, 'i': i, 'sigma': s, 'sigma_hat': s if sigma_hat is None else sigma_hat, 'denoised': denoised})
+
+    def fresh(self):
+        return torch.empty_like(self.x)
+
+    def update(self, op, den, in2=None, aux=None, **c):
+        """x <- step(op)(x, ...) ; never writes into the caller's tensor, and hands callbacks a tensor
+        that later steps do not overwrite."""
+        out = self.x if (self._owned and self.callback is None) else self.fresh()
+        ops.sampler_step(op, self.x, den, in2=in2, out=out, aux=aux, **{k: _f(v) for k, v in c.items()})
+        self.x, self._owned = out, True
+
+    def add_noise(self, noise, c0, c1, c2=1.0):
+        self.update(nat.STEP_ADD_NOISE, noise.contiguous(), c0=c0, c1=c1, c2=c2)
+
+
+def _churn_plan(sig, s_churn, s_tmin, s_tmax):
+    """Per-step (gamma, sigma_hat) of Karras Alg. 2 (sampling.py:123-125)."""
+    n = len(sig) - 1
+    gammas = [min(s_churn / n, 2 ** 0.5 - 1) if s_tmin <= sig[i] <= s_tmax else 0. for i in range(n)]
+    return gammas, [sig[i] * (g + 1) for i, g in enumerate(gammas)]
+
+
+def _apply_churn(lp, i, gamma, sigma_hat, s_noise):
+    if gamma > 0:
+        eps = torch.randn_like(lp.x)
+        lp.add_noise(eps, s_noise, (sigma_hat ** 2 - lp.sig[i] ** 2) ** 0.5)
+
+
+# --------------------------------------------------------------------------------- samplers
+
+@torch.no_grad()
+def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None, s_churn=0., s_tmin=0., s_tmax=float('inf'), s_noise=1.):
+    """Algorithm 2 (Euler steps) from Karras et al. (2022)."""
+    lp = _Loop(model, x, sigmas, extra_args, callback)
+    sig = lp.sig
+    gammas, hats = _churn_plan(sig, s_churn, s_tmin, s_tmax)
+    rows = lp.sigma_rows(hats)
+    for i in trange(len(lp), disable=disable):
+        _apply_churn(lp, i, gammas[i], hats[i], s_noise)
+        den = lp.denoise(rows[i])
+        lp.report(i, den, hats[i])
+        lp.update(nat.STEP_EULER, den, c0=hats[i], c1=sig[i + 1] - hats[i])
+    return lp.x
+
+
+@torch.no_grad()
+def sample_euler_ancestral(model, x, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1., noise_sampler=None):
+    """Ancestral sampling with Euler method steps."""
+    lp = _Loop(model, x, sigmas, extra_args, callback)
+    sig = lp.sig
+    noise_sampler = default_noise_sampler(lp.x) if noise_sampler is None else noise_sampler
+    rows = lp.sigma_rows(sig[:-1])
+    for i in trange(len(lp), disable=disable):
+        den = lp.denoise(rows[i])
+        sigma_down, sigma_up = get_ancestral_step(sig[i], sig[i + 1], eta=eta)
+        lp.report(i, den)
+        lp.update(nat.STEP_EULER, den, c0=sig[i], c1=sigma_down - sig[i])
+        if sig[i + 1] > 0:
+            lp.add_noise(noise_sampler(sigmas[i], sigmas[i + 1]), s_noise, sigma_up)
+    return lp.x
+
+
+@torch.no_grad()
+def sample_heun(model, x, sigmas, extra_args=None, callback=None, disable=None, s_churn=0., s_tmin=0., s_tmax=float('inf'), s_noise=1.):
+    """Algorithm 2 (Heun steps) from Karras et al. (2022)."""
+    lp = _Loop(model, x, sigmas, extra_args, callback)
+    sig = lp.sig
+    gammas, hats = _churn_plan(sig, s_churn, s_tmin, s_tmax)
+    rows, rows_next = lp.sigma_rows(hats), lp.sigma_rows(sig[1:])
+    d, x_2 = lp.fresh(), lp.fresh()
+    for i in trange(len(lp), disable=disable):
+        _apply_churn(lp, i, gammas[i], hats[i], s_noise)
+        den = lp.denoise(rows[i])
+        lp.report(i, den, hats[i])
+        dt = sig[i + 1] - hats[i]
+        if sig[i + 1] == 0:
+            lp.update(nat.STEP_EULER, den, c0=hats[i], c1=dt)
+        else:
+            ops.sampler_step(nat.STEP_HEUN_PRED, lp.x, den, out=x_2, aux=d, c0=_f(hats[i]), c1=_f(dt))
+            den_2 = lp.denoise(rows_next[i], x_2)
+            lp.update(nat.STEP_HEUN_CORR, den_2, in2=x_2, aux=d, c0=sig[i + 1], c1=dt)
+    return lp.x
+
+
+@torch.no_grad()
+def sample_dpm_2(model, x, sigmas, extra_args=None, callback=None, disable=None, s_churn=0., s_tmin=0., s_tmax=float('inf'), s_noise=1.):
+    """A sampler inspired by DPM-Solver-2 and Algorithm 2 from Karras et al. (2022)."""
+    lp = _Loop(model, x, sigmas, extra_args, callback)
+    sig = lp.sig
+    gammas, hats = _churn_plan(sig, s_churn, s_tmin, s_tmax)
+    mids = [hats[i].log().lerp(sig[i + 1].log(), 0.5).exp() if sig[i + 1] != 0 else sig[i + 1] for i in range(len(lp))]
+    rows, rows_mid = lp.sigma_rows(hats), lp.sigma_rows(mids)
+    d, x_2 = lp.fresh(), lp.fresh()
+    for i in trange(len(lp), disable=disable):
+        _apply_churn(lp, i, gammas[i], hats[i], s_noise)
+        den = lp.denoise(rows[i])
+        lp.report(i, den, hats[i])
+        if sig[i + 1] == 0:
+            lp.update(nat.STEP_EULER, den, c0=hats[i], c1=sig[i + 1] - hats[i])
+        else:
+            ops.sampler_step(nat.STEP_HEUN_PRED, lp.x, den, out=x_2, aux=d, c0=_f(hats[i]), c1=_f(mids[i] - hats[i]))
+            den_2 = lp.denoise(rows_mid[i], x_2)
+            lp.update(nat.STEP_EULER_FROM, den_2, in2=x_2, c0=mids[i], c1=sig[i + 1] - hats[i])
+    return lp.x
+
+
+@torch.no_grad()
+def sample_dpm_2_ancestral(model, x, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1., noise_sampler=None):
+    """Ancestral sampling with DPM-Solver second-order steps."""
+    lp = _Loop(model, x, sigmas, extra_args, callback)
+    sig = lp.sig
+    noise_sampler = default_noise_sampler(lp.x) if noise_sampler is None else noise_sampler
+    steps = [get_ancestral_step(sig[i], sig[i + 1], eta=eta) for i in range(len(lp))]
+    mids = [sig[i].log().lerp(torch.as_tensor(sd).log(), 0.5).exp() if sd != 0 else torch.zeros(()) for i, (sd, _) in enumerate(steps)]
+    rows, rows_mid = lp.sigma_rows(sig[:-1]), lp.sigma_rows(mids)
+    d, x_2 = lp.fresh(), lp.fresh()
+    for i in trange(len(lp), disable=disable):
+        den = lp.denoise(rows[i])
+        sigma_down, sigma_up = steps[i]
+        lp.report(i, den)
+        if sigma_down == 0:
+            lp.update(nat.STEP_EULER, den, c0=sig[i], c1=sigma_down - sig[i])
+        else:
+            ops.sampler_step(nat.STEP_HEUN_PRED, lp.x, den, out=x_2, aux=d, c0=_f(sig[i]), c1=_f(mids[i] - sig[i]))
+            den_2 = lp.denoise(rows_mid[i], x_2)
+            lp.update(nat.STEP_EULER_FROM, den_2, in2=x_2, c0=mids[i], c1=sigma_down - sig[i])
+            lp.add_noise(noise_sampler(sigmas[i], sigmas[i + 1]), s_noise, sigma_up)
+    return lp.x
+
+
+def linear_multistep_coeff(order, t, i, j):
+    """Adams-Bashforth weight of history entry j at step i (host quadrature, sampling.py:247-257)."""
+    from scipy import integrate
+    if order - 1 > i:
+        raise ValueError(f'Order {order} too high for step {i}')
+
+    def lagrange(tau):
+        out = 1.
+        for k in range(order):
+            if k != j:
+                out *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+        return out
+    return integrate.quad(lagrange, t[i], t[i + 1], epsrel=1e-4)[0]
+
+
+@torch.no_grad()
+def sample_lms(model, x, sigmas, extra_args=None, callback=None, disable=None, order=4):
+    lp = _Loop(model, x, sigmas, extra_args, callback)
+    sig = lp.sig
+    t = sig.numpy()
+    rows = lp.sigma_rows(sig[:-1])
+    ds = []
+    for i in trange(len(lp), disable=disable):
+        den = lp.denoise(rows[i])
+        ds.append(ops.sampler_step(nat.STEP_TO_D, lp.x, den, c0=_f(sig[i])))
+        ds = ds[-order:]
+        lp.report(i, den)
+        cur = min(i + 1, order)
+        coeffs = [linear_multistep_coeff(cur, t, i, j) for j in range(cur)]
+        hist = list(reversed(ds))
+        if cur == 1:
+            lp.update(nat.STEP_AXPY, hist[0], c0=coeffs[0])
+        else:
+            acc = ops.sampler_step(nat.STEP_LERP2, None, hist[0], in2=hist[1], c0=coeffs[0], c1=coeffs[1])
+            for c, dj in zip(coeffs[2:], hist[2:]):
+                ops.sampler_step(nat.STEP_AXPY, acc, dj, out=acc, c0=c)
+            lp.update(nat.STEP_AXPY, acc, c0=1.0)
+    return lp.x
+
+
+@torch.no_grad()
+def sample_dpmpp_2s_ancestral(model, x, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1., noise_sampler=None):
+    """Ancestral sampling with DPM-Solver++(2S) second-order steps."""
+    lp = _Loop(model, x, sigmas, extra_args, callback)
+    sig = lp.sig
+    noise_sampler = default_noise_sampler(lp.x) if noise_sampler is None else noise_sampler
+    sigma_fn, t_fn = (lambda t: t.neg().exp()), (lambda s: s.log().neg())
+    plan = []
+    for i in range(len(lp)):
+        sigma_down, sigma_up = get_ancestral_step(sig[i], sig[i + 1], eta=eta)
+        if sigma_down == 0:
+            plan.append((sigma_down, sigma_up, None))
+        else:
+            t, t_next = t_fn(sig[i]), t_fn(torch.as_tensor(sigma_down))
+            h = t_next - t
+            s = t + 0.5 * h
+            plan.append((sigma_down, sigma_up, (sigma_fn(s), sigma_fn(s) / sigma_fn(t), (-h * 0.5).expm1(),
+                                                sigma_fn(t_next) / sigma_fn(t), (-h).expm1())))
+    rows = lp.sigma_rows(sig[:-1])
+    rows_s = lp.sigma_rows([p[2][0] if p[2] is not None else torch.zeros(()) for p in plan])
+    x_2 = lp.fresh()
+    for i in trange(len(lp), disable=disable):
+        den = lp.denoise(rows[i])
+        sigma_down, sigma_up, second = plan[i]
+        lp.report(i, den)
+        if second is None:
+            lp.update(nat.STEP_EULER, den, c0=sig[i], c1=sigma_down - sig[i])
+        else:
+            _, a1, b1, a2, b2 = second
+            ops.sampler_step(nat.STEP_DPMPP_2M1, lp.x, den, out=x_2, c0=_f(a1), c1=_f(b1))
+            den_2 = lp.denoise(rows_s[i], x_2)
+            lp.update(nat.STEP_DPMPP_2M1, den_2, c0=a2, c1=b2)
+        if sig[i + 1] > 0:
+            lp.add_noise(noise_sampler(sigmas[i], sigmas[i + 1]), s_noise, sigma_up)
+    return lp.x
+
+
+@torch.no_grad()
+def sample_dpmpp_sde(model, x, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1., noise_sampler=None, r=1 / 2):
+    """DPM-Solver++ (stochastic)."""
+    lp = _Loop(model, x, sigmas, extra_args, callback)
+    sig = lp.sig
+    if noise_sampler is None:
+        noise_sampler = BrownianTreeNoiseSampler(lp.x, sig[sig > 0].min(), sig.max())
+    sigma_fn, t_fn = (lambda t: t.neg().exp()), (lambda s: s.log().neg())
+    mids = []
+    for i in range(len(lp)):
+        if sig[i + 1] == 0:
+            mids.append(torch.zeros(()))
+        else:
+            t, t_next = t_fn(sig[i]), t_fn(sig[i + 1])
+            mids.append(sigma_fn(t + (t_next - t) * r))
+    rows, rows_mid = lp.sigma_rows(sig[:-1]), lp.sigma_rows(mids)
+    x_2, den_d = lp.fresh(), lp.fresh()
+    for i in trange(len(lp), disable=disable):
+        den = lp.denoise(rows[i])
+        lp.report(i, den)
+        if sig[i + 1] == 0:
+            lp.update(nat.STEP_EULER, den, c0=sig[i], c1=sig[i + 1] - sig[i])
+            continue
+        t, t_next = t_fn(sig[i]), t_fn(sig[i + 1])
+        h = t_next - t
+        s = t + h * r
+        fac = 1 / (2 * r)
+        # step 1: ancestral sub-step to the midpoint
+        sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(s), eta)
+        s_ = t_fn(torch.as_tensor(sd))
+        ops.sampler_step(nat.STEP_DPMPP_2M1, lp.x, den, out=x_2, c0=_f(sigma_fn(s_) / sigma_fn(t)), c1=_f((t - s_).expm1()))
+        ops.sampler_step(nat.STEP_ADD_NOISE, x_2, noise_sampler(sigma_fn(t), sigma_fn(s)).contiguous(), out=x_2, c0=_f(s_noise), c1=_f(su))
+        den_2 = lp.denoise(rows_mid[i], x_2)
+        # step 2: full ancestral step with the blended denoised
+        sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(t_next), eta)
+        t_next_ = t_fn(torch.as_tensor(sd))
+        ops.sampler_step(nat.STEP_LERP2, None, den, in2=den_2, out=den_d, c0=1 - fac, c1=fac)
+        lp.update(nat.STEP_DPMPP_2M1, den_d, c0=sigma_fn(t_next_) / sigma_fn(t), c1=(t - t_next_).expm1())
+        lp.add_noise(noise_sampler(sigma_fn(t), sigma_fn(t_next)), s_noise, su)
+    return lp.x
+
+
+@torch.no_grad()
+def sample_dpmpp_2m(model, x, sigmas, extra_args=None, callback=None, disable=None):
+    """DPM-Solver++(2M)."""
+    lp = _Loop(model, x, sigmas, extra_args, callback)
+    sig = lp.sig
+    sigma_fn, t_fn = (lambda t: t.neg().exp()), (lambda s: s.log().neg())
+    rows = lp.sigma_rows(sig[:-1])
+    old = None
+    for i in trange(len(lp), disable=disable):
+        den = lp.denoise(rows[i])
+        lp.report(i, den)
+        t, t_next = t_fn(sig[i]), t_fn(sig[i + 1])
+        h = t_next - t
+        a, b = sigma_fn(t_next) / sigma_fn(t), (-h).expm1()
+        if old is None or sig[i + 1] == 0:
+            lp.update(nat.STEP_DPMPP_2M1, den, c0=a, c1=b)
+        else:
+            ratio = (t - t_fn(sig[i - 1])) / h
+            lp.update(nat.STEP_DPMPP_2M2, den, in2=old, c0=a, c1=b, c2=1 + 1 / (2 * ratio), c3=1 / (2 * ratio))
+        old = den
+    return lp.x
+
+
+@torch.no_grad()
+def sample_dpmpp_2m_sde(model, x, sigmas, extra_args=None, callback=None, disable=None, eta=1., s_noise=1., noise_sampler=None, solver_type='midpoint'):
+    """DPM-Solver++(2M) SDE."""
+    if solver_type not in {'heun', 'midpoint'}:
+        raise ValueError('solver_type must be \'heun\' or \'midpoint\'')
+    lp = _Loop(model, x, sigmas, extra_args, callback)
+    sig = lp.sig
+    if noise_sampler is None:
+        noise_sampler = BrownianTreeNoiseSampler(lp.x, sig[sig > 0].min(), sig.max())
+    rows = lp.sigma_rows(sig[:-1])
+    old, h_last = None, None
+    for i in trange(len(lp), disable=disable):
+        den = lp.denoise(rows[i])
+        lp.report(i, den)
+        if sig[i + 1] == 0:
+            lp.update(nat.STEP_AXPBY, den, c0=0.0, c1=1.0)               # x = denoised
+        else:
+            t, s = -sig[i].log(), -sig[i + 1].log()
+            h = s - t
+            eta_h = eta * h
+            lp.update(nat.STEP_AXPBY, den, c0=sig[i + 1] / sig[i] * (-eta_h).exp(), c1=(-h - eta_h).expm1().neg())
+            if old is not None:
+                ratio = h_last / h
+                if solver_type == 'heun':
+                    coef = ((-h - eta_h).expm1().neg() / (-h - eta_h) + 1) * (1 / ratio)
+                else:
+                    coef = 0.5 * (-h - eta_h).expm1().neg() * (1 / ratio)
+                lp.update(nat.STEP_ADD_DIFF, den, in2=old, c0=coef)
+            if eta:
+                lp.add_noise(noise_sampler(sigmas[i], sigmas[i + 1]), sig[i + 1], (-2 * eta_h).expm1().neg().sqrt(), s_noise)
+            h_last = h
+        old = den
+        if sig[i + 1] == 0:
+            h_last = None
+    return lp.x

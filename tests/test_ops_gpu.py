@@ -183,7 +183,11 @@ def test_sampler_steps_bit_exact(ops):
         N.STEP_EULER: x + ((x - d) / c[0]) * c[1],
         N.STEP_DPMPP_2M1: c[0] * x - c[1] * d,
         N.STEP_DPMPP_2M2: c[0] * x - c[1] * (c[2] * d - c[3] * o2),
-        N.STEP_ADD_NOISE: x + d * f[0] * c[1],
+        N.STEP_ADD_NOISE: x + d * f[0] * c[1] * c[2],
+        N.STEP_EULER_FROM: x + ((o2 - d) / c[0]) * c[1],
+        N.STEP_AXPBY: c[0] * x + c[1] * d,
+        N.STEP_ADD_DIFF: x + c[0] * (d - o2),
+        N.STEP_TO_D: (x - d) / c[0],
         N.STEP_LERP2: c[0] * d + c[1] * o2,
         N.STEP_AXPY: x + d * c[0],
     }
