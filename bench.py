@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the k-diffusion sampling hot path on MI355X (contract: see the task statement).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: a complete 50-step ``sample_dpmpp_2m`` run
+(50 denoiser evaluations of the 256x256 image_transformer_v2 + the fused solver steps) for
+``--batch`` images per GPU, followed -- for N > 1 -- by the path's one exchange step, the RCCL
+all-gather of the finished images (k_diffusion/evaluation.py:87).  Initial noise, weights and the
+sigma table are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import k_diffusion_amd as K  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3, help="timed passes (each = one full sampling run of a batch)")
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--config", default="configs/config_oxford_flowers.json")
+    p.add_argument("--batch", type=int, default=32, help="images per GPU per pass")
+    p.add_argument("--sampler", default="sample_dpmpp_2m")
+    p.add_argument("--sampler-steps", type=int, default=50)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time for the baseline sample")
+    p.add_argument("--no-kernel-events", action="store_true", help="do not record per-launch HIP events in the timed region")
+    p.add_argument("--kernel-table", default=None, help="write the per-kernel event timings to this JSON file")
+    return p.parse_args()
+
+
+def build_model(cfg, device, seed):
+    model = K.config.make_model(cfg).eval().requires_grad_(False)
+    model.load_state_dict(K.synth.synth_state_dict(model.state_dict(), seed=seed))
+    return model.to(device)
+
+
+def kernel_table():
+    """Per-launch HIP-event timings recorded by the library -> grouped per kernel."""
+    import ctypes as C
+    lib = K._native.lib()
+    groups = {}
+    name = C.create_string_buffer(128)
+    ms, fl, by = C.c_float(), C.c_double(), C.c_double()
+    for i in range(lib.kd_prof_count()):
+        K._native.check(lib.kd_prof_get(i, name, 128, C.byref(ms), C.byref(fl), C.byref(by)), "kd_prof_get")
+        g = groups.setdefault(name.value.decode(), {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        g["launches"] += 1
+        g["ms"] += ms.value
+        g["flops"] += fl.value
+        g["bytes"] += by.value
+    lib.kd_prof_reset()
+    return groups
+
+
+def cpu_baseline(cfg, seed, sampler_steps, target_seconds):
+    """The CPU oracle (a port of the reference's algorithm: oracle/hdit.py + oracle/solvers.py) timed on
+    this host's cores for a bounded sample of the same workload (same weights / noise recipe)."""
+    from oracle import hdit, solvers
+    mc = cfg["model"]
+    cores = min(os.cpu_count(), 32)      # torch's intra-op pool stops scaling (and thrashes) far below 256 threads on these op sizes
+    torch.set_num_threads(cores)
+    model = K.config.make_model(cfg)
+    sd = K.synth.synth_state_dict(model.state_dict(), seed=seed)
+    den = solvers.denoiser(lambda x, s, **kw: hdit.forward(sd, mc, x, s, **kw), mc["sigma_data"])
+    shape = (mc["input_channels"], *mc["input_size"])
+    x = K.synth.synth_noise(shape, seed, 0, mc["sigma_max"])[None]
+    sig = solvers.sigmas_karras(sampler_steps, mc["sigma_min"], mc["sigma_max"])
+    t0 = time.perf_counter()
+    den(x, sig[:1])
+    one = time.perf_counter() - t0
+    n = max(2, min(sampler_steps, int(target_seconds / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        solvers.sample_dpmpp_2m(den, x, torch.cat([sig[:n], sig[-1:]]))
+    dt = time.perf_counter() - t0
+    per_image = dt / n * sampler_steps
+    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 image, {n} of {sampler_steps} DPM++2M steps with the oracle (torch CPU fp32, {cores} threads), "
+                      f"{dt:.1f} s measured, scaled to {sampler_steps} steps"}
+
+
+def main():
+    args = parse()
+    ctx = K.distributed.RankContext()
+    if ctx.num_processes != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.num_processes}")
+    if ctx.device.type != "cuda":
+        raise SystemExit("bench.py needs an MI355X: no ROCm device visible (there is no CPU fallback for the hot path)")
+    dev = ctx.device
+    cfg = K.config.load_config(os.path.join(REPO, args.config) if not os.path.isabs(args.config) else args.config)
+    mc = cfg["model"]
+    model = build_model(cfg, dev, args.seed)
+    den = K.Denoiser(model, sigma_data=mc["sigma_data"])
+    B = args.batch
+    shape = (mc["input_channels"], *mc["input_size"])
+    lo = ctx.process_index * B
+    x0 = torch.stack([K.synth.synth_noise(shape, args.seed, lo + g, mc["sigma_max"]) for g in range(B)]).to(dev)
+    extra = {}
+    if cfg["dataset"]["num_classes"]:
+        extra["class_cond"] = (torch.arange(lo, lo + B) % cfg["dataset"]["num_classes"]).to(dev)
+    sigmas = K.sampling.get_sigmas_karras(args.sampler_steps, mc["sigma_min"], mc["sigma_max"], rho=7., device=dev)
+    sampler = getattr(K.sampling, args.sampler)
+
+    def one_pass():
+        imgs = sampler(den, x0, sigmas, extra_args=extra, disable=True)
+        return ctx.gather(imgs)
+
+    for _ in range(args.warmup):
+        one_pass()
+    ctx.wait_for_everyone()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    ctx.wait_for_everyone()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if ctx.num_processes > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    # Per-kernel durations for the roofline: ONE more identical pass, right after the timed region, with a HIP
+    # event pair recorded on the launch stream around every kernel launch (kd_prof_*).  Kept out of the timed
+    # region because ~9k event records per pass cost ~5% throughput.
+    if ctx.is_main_process and not args.no_kernel_events:
+        K._native.lib().kd_prof_reset()
+        K._native.lib().kd_prof_enable(1)
+        sampler(den, x0, sigmas, extra_args=extra, disable=True)
+        torch.cuda.synchronize()
+        K._native.lib().kd_prof_enable(0)
+    assert torch.isfinite(out).all()
+
+    if ctx.is_main_process:
+        groups = kernel_table()
+        total_ms = sum(g["ms"] for g in groups.values())
+        fam = {}
+        for name, g in groups.items():
+            f = fam.setdefault(name.split(" ")[0], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            for k in f:
+                f[k] += g[k]
+        if not fam:
+            fam = {"(no kernel events recorded)": {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}}
+        dom_name, dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+        tflops = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] else 0.0
+        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 5), "launches": dom["launches"],
+                    "share_of_kernel_time": round(dom["ms"] / total_ms, 4) if total_ms else None,
+                    "measured_on": "one extra identical pass immediately after the timed region (HIP events per launch)",
+                    "note": "algorithmic 2*M*N*K flops of every launch of this kernel family in the profiled pass / sum of their "
+                            "HIP-event durations (events recorded on the launch stream); fp32-input MFMA peak"}
+        if args.kernel_table:
+            with open(args.kernel_table, "w") as f:
+                json.dump({"families": fam, "kernels": groups, "timed_seconds": dt}, f, indent=1)
+        n_img = args.gpus * B * args.steps
+        from oracle import hdit
+        mac = hdit.forward_cost_mac(mc)["total"]
+        nfe = args.sampler_steps if args.sampler == "sample_dpmpp_2m" else None
+        result = {
+            "metric": "images/sec, 256x256 image_transformer_v2, 50-step DPM++2M (whole job)",
+            "value": round(n_img / dt, 3), "unit": "images/sec", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (seeded noise, random-init weights incl. re-randomised zero-init projections)",
+            "per_gpu": round(n_img / dt / args.gpus, 3),
+            "config": {"workload": f"{os.path.basename(args.config)} {mc['input_size'][0]}x{mc['input_size'][1]}, {args.sampler} "
+                                   f"{args.sampler_steps} steps, batch {B}/GPU, fp32 parity mode, all-gather of finished images",
+                       "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus} (independent images, one final all-gather)"},
+            "algorithmic_tflops": round(n_img * 2 * mac * (nfe or 0) / dt / 1e12, 2) if nfe else None,
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and args.gpus == 1:
+            result["cpu_baseline"] = cpu_baseline(cfg, args.seed, args.sampler_steps, args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    ctx.wait_for_everyone()
+    ctx.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -43,7 +43,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const KdGemm p) {
   const int wr = wid >> 1, wc = wid & 1;
   constexpr int NCOL = (EPI == KD_EPI_GEGLU) ? 64 : BN;   // output columns covered per tile
   const int n_tiles = (p.N + NCOL - 1) / NCOL;
-  const int nt = blockIdx.x % n_tiles, mt = blockIdx.x / n_tiles;
+  // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs (private
+  // L2s), so give every XCD one CONTIGUOUS chunk of the (m-tile, n-tile) space with n fastest: the n-tiles
+  // that re-read one A row-panel then run back to back on ONE L2 instead of missing in 8 of them.  The remap
+  // is a bijection for any grid size (performance only -- correctness never depends on placement).
+  int tile;
+  {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int nt = tile % n_tiles, mt = tile / n_tiles;
   const int m0 = mt * BM, n0 = nt * NCOL;
   const int M = p.M, N = p.N, K = p.K;
 
@@ -248,7 +258,9 @@ static int launch(const KdGemm& d, hipStream_t s) {
     attr_set = true;
   }
   const double n_eff = (EPI == KD_EPI_GEGLU) ? 2.0 * d.N : (double)d.N;
-  LaunchScope prof("gemm_f32", 2.0 * d.M * n_eff * d.K, 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N), s);
+  char nm[96] = "gemm_f32";
+  if (prof_on()) snprintf(nm, sizeof(nm), "gemm_f32<a%d,n%d,e%d> M=%d N=%d K=%d", AMODE, (int)NORM, EPI, d.M, d.N, d.K);
+  LaunchScope prof(nm, 2.0 * d.M * n_eff * d.K, 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N), s);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), Cfg::LDS_BYTES, s, d);
   return check_launch("kd_gemm_f32");
 }

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, as the MI355X guide prescribes)
+into per-kernel HBM traffic per launch.
+
+    python profiles/summarize_pmc.py gpurun_out/pmc_fetch/f_counter_collection.csv \
+           gpurun_out/pmc_write/w_counter_collection.csv profiles/rNN_pmc_summary.json
+
+Units / corrections (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 this
+rocprofv3 reports exactly 1/2 of the bytes of a wide coalesced streaming read (128-B requests tallied at
+64 B), so FETCH_SIZE is doubled; WRITE_SIZE is used as reported (uncalibrated).  Dispatches are keyed by
+(kernel name, grid size) so that the different GEMM shapes of one kernel stay apart.
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def load(path, counter):
+    acc = defaultdict(lambda: [0, 0.0])
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            key = (row["Kernel_Name"], int(row["Grid_Size"]))
+            acc[key][0] += 1
+            acc[key][1] += float(row["Counter_Value"])
+    return acc
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    fe, wr = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
+    rows = []
+    for key in sorted(set(fe) | set(wr)):
+        n_f, kib_f = fe.get(key, (0, 0.0))
+        n_w, kib_w = wr.get(key, (0, 0.0))
+        if not key[0].startswith(("void kd::", "kd::")):
+            continue
+        f_bytes = 2.0 * 1024.0 * kib_f / max(n_f, 1)
+        w_bytes = 1024.0 * kib_w / max(n_w, 1)
+        rows.append({"kernel": key[0], "grid_size": key[1], "dispatches": n_f, "fetch_bytes_per_launch": round(f_bytes),
+                     "write_bytes_per_launch": round(w_bytes), "hbm_bytes_per_launch": round(f_bytes + w_bytes)})
+    json.dump({"note": "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE x1, KiB -> bytes; per launch averages", "kernels": rows},
+              open(out, "w"), indent=1)
+    for r in sorted(rows, key=lambda r: -r["hbm_bytes_per_launch"])[:25]:
+        print(f'{r["kernel"][:60]:60s} grid={r["grid_size"]:8d} n={r["dispatches"]:4d} fetch={r["fetch_bytes_per_launch"]/1e6:9.1f} MB write={r["write_bytes_per_launch"]/1e6:9.1f} MB')
+
+
+if __name__ == "__main__":
+    main()
