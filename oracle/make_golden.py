@@ -78,6 +78,11 @@ def scalar_kats():
     it = iter(noise)
     kat["solver_toy_euler_ancestral_recorded"] = hexf(
         S.sample_euler_ancestral(toy, xt, sig20, disable=True, noise_sampler=lambda a, b: next(it)))
+    # the reference's merged configs (config.py:23-146 defaulting) for the four shipped v2 configs
+    kat["merged_configs"] = {}
+    for name in ("config_mnist_transformer.json", "config_cifar10_transformer.json",
+                 "config_oxford_flowers_shifted_window.json", "config_oxford_flowers.json"):
+        kat["merged_configs"][name] = K.config.load_config(os.path.join("/root/reference/configs", name))
     return kat
 
 
@@ -173,6 +178,8 @@ def main():
     meta = {"generator": "oracle/make_golden.py", "torch": torch.__version__,
             "reference": "crowsonkb/k-diffusion @ /root/reference (v0.2.0.dev0)"}
     json.dump({"meta": meta, **scalar_kats()}, open(os.path.join(gd, "kat.json"), "w"), indent=1)
+    if "--kat-only" in sys.argv:
+        return
     save_file(op_fixtures(), os.path.join(gd, "ops.safetensors"), metadata=meta)
     save_file(forward_fixtures(), os.path.join(gd, "forward.safetensors"), metadata=meta)
     save_file(sample_fixtures(), os.path.join(gd, "samples.safetensors"), metadata=meta)

@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Samples from k-diffusion image_transformer_v2 models on MI355X (drop-in for the reference's sample.py).
+
+Keeps the reference CLI (sample.py:19-30: --batch-size --checkpoint --config -n --prefix --steps, output
+``{prefix}_{i:05}.png``) and its flow (load_config -> make_model -> load safetensors -> Denoiser ->
+get_sigmas_karras -> compute_features(gather) -> PNG).  One process per GPU: run it plainly for one GPU or under
+``python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 sample.py ...`` for N (RCCL
+all-gather of the finished images, k_diffusion/evaluation.py:87).
+
+Additive flags (the reference hard-codes sample_lms, an unseeded rank-local randn and no class conditioning,
+sample.py:59-60, and therefore cannot run its own class-conditional configs):
+  --sampler NAME       any K.sampling.sample_* (default: lms, like the reference)
+  --seed S             per-image noise from (seed, global image index): identical images for any GPU count
+  --class-cond C       class id for every image (-1: image index mod num_classes) for class-conditional configs
+  --random-weights     no checkpoint: synthetic weights (K.synth), for smoke runs and benchmarking
+  --no-png             skip PNG encoding (timing runs)
+"""
+import argparse
+import math
+import sys
+import time
+from pathlib import Path
+
+import torch
+from tqdm import tqdm
+
+import k_diffusion_amd as K
+
+
+def parse(argv=None):
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument('--batch-size', type=int, default=64, help='the batch size')
+    p.add_argument('--checkpoint', type=Path, help='the checkpoint to use (safetensors)')
+    p.add_argument('--config', type=Path, help='the model config')
+    p.add_argument('-n', type=int, default=64, help='the number of images to sample')
+    p.add_argument('--prefix', type=str, default='out', help='the output prefix')
+    p.add_argument('--steps', type=int, default=50, help='the number of denoising steps')
+    p.add_argument('--sampler', type=str, default='lms', help='K.sampling.sample_<name>')
+    p.add_argument('--seed', type=int, default=None, help='seed for the per-image initial noise')
+    p.add_argument('--class-cond', type=int, default=None, help='class id for all images; -1 = index mod num_classes')
+    p.add_argument('--random-weights', action='store_true', help='synthetic weights instead of a checkpoint')
+    p.add_argument('--no-png', action='store_true', help='do not write PNG files')
+    args = p.parse_args(argv)
+    if args.checkpoint is None and not args.random_weights:
+        p.error('--checkpoint is required (or pass --random-weights)')
+    if args.checkpoint is None and args.config is None:
+        p.error('--random-weights needs --config')
+    return args
+
+
+def resolve_sampler(name):
+    fn = getattr(K.sampling, name if name.startswith('sample_') else 'sample_' + name, None)
+    if fn is None:
+        raise SystemExit(f'unknown sampler {name!r}; available: ' +
+                         ', '.join(sorted(n[7:] for n in dir(K.sampling) if n.startswith('sample_'))))
+    return fn
+
+
+def class_ids(args, num_classes, lo, n, device):
+    """class_cond for global image indices [lo, lo+n) or None for unconditional models."""
+    if not num_classes:
+        return None
+    if args.class_cond is None:
+        raise SystemExit(f'this config is class-conditional ({num_classes} classes): pass --class-cond C (or -1)')
+    if args.class_cond < 0:
+        return (torch.arange(lo, lo + n) % num_classes).to(device)
+    return torch.full([n], args.class_cond, dtype=torch.int64, device=device)
+
+
+def main(argv=None):
+    args = parse(argv)
+    config = K.config.load_config(args.config if args.config else args.checkpoint)
+    model_config = config['model']
+    # TODO (as in the reference): non-square input sizes
+    assert len(model_config['input_size']) == 2 and model_config['input_size'][0] == model_config['input_size'][1]
+    size = model_config['input_size']
+
+    accelerator = K.distributed.RankContext()
+    device = accelerator.device
+    print('Using device:', device, flush=True)
+    if device.type != 'cuda':
+        raise SystemExit('sample.py runs the HIP hot path: no ROCm device is visible (there is no CPU fallback)')
+
+    inner_model = K.config.make_model(config).eval().requires_grad_(False)
+    if args.random_weights:
+        inner_model.load_state_dict(K.synth.synth_state_dict(inner_model.state_dict(), seed=args.seed or 0))
+    else:
+        import safetensors.torch as safetorch
+        inner_model.load_state_dict(safetorch.load_file(args.checkpoint))
+    inner_model = inner_model.to(device)
+    accelerator.print('Parameters:', K.utils.n_params(inner_model))
+    model = K.Denoiser(inner_model, sigma_data=model_config['sigma_data'])
+
+    sigma_min, sigma_max = model_config['sigma_min'], model_config['sigma_max']
+    sampler = resolve_sampler(args.sampler)
+    num_classes = config['dataset']['num_classes']
+    shape = (model_config['input_channels'], size[0], size[1])
+    per_rank = math.ceil(args.n / accelerator.num_processes)
+    cursor = [accelerator.process_index * per_rank]          # global index of this rank's next image
+
+    @torch.no_grad()
+    @K.utils.eval_mode(model)
+    def run():
+        if accelerator.is_local_main_process:
+            tqdm.write('Sampling...')
+        sigmas = K.sampling.get_sigmas_karras(args.steps, sigma_min, sigma_max, rho=7., device=device)
+
+        def sample_fn(n):
+            lo = cursor[0]
+            cursor[0] += n
+            if args.seed is None:
+                x = torch.randn([n, *shape], device=device) * sigma_max
+            else:
+                x = torch.stack([K.synth.synth_noise(shape, args.seed, lo + g, sigma_max) for g in range(n)]).to(device)
+            extra = {}
+            cc = class_ids(args, num_classes, lo, n, device)
+            if cc is not None:
+                extra['class_cond'] = cc
+            return sampler(model, x, sigmas, extra_args=extra, disable=not accelerator.is_local_main_process)
+
+        t0 = time.perf_counter()
+        x_0 = K.evaluation.compute_features(accelerator, sample_fn, lambda x: x, args.n, args.batch_size)
+        torch.cuda.synchronize()
+        accelerator.print(f'{args.n} images in {time.perf_counter() - t0:.2f} s')
+        if accelerator.is_main_process and not args.no_png:
+            for i, out in enumerate(x_0):
+                K.utils.to_pil_image(out).save(f'{args.prefix}_{i:05}.png')
+        return x_0
+
+    try:
+        return run()
+    except KeyboardInterrupt:
+        pass
+    finally:
+        accelerator.shutdown()
+
+
+if __name__ == '__main__':
+    main()
+    sys.exit(0)
