@@ -41,6 +41,9 @@ const char* kd_last_error(void);
  * NCHW<->NHWC movedims :723,760, and the Karras preconditioner k_diffusion/layers.py:88-90.
  */
 enum { KD_A_PLAIN = 0, KD_A_MERGE2x2 = 1, KD_A_PATCH_NCHW = 2 };
+/* arithmetic of the products: exact fp32 MFMA (bit-for-bit an fmaf chain), or each fp32 operand split into two
+ * bf16 (hi + lo, 16 significand bits) with hi*hi + hi*lo + lo*hi on the bf16 MFMA and fp32 accumulation */
+enum { KD_PREC_EXACT = 0, KD_PREC_SPLIT3 = 1 };
 enum { KD_EPI_STORE = 0, KD_EPI_RESIDUAL = 1, KD_EPI_GEGLU = 2, KD_EPI_SPLIT_LERP = 3, KD_EPI_UNPATCH_NCHW = 4 };
 
 typedef struct {
@@ -62,9 +65,20 @@ typedef struct {
   const float* scale;   /* norm scales                                                            */
   const float* sigma;   /* [B] per-sample sigma (patch modes; NULL = no preconditioning)           */
   const float* fac;     /* split: device pointer to the lerp factor                               */
+  int precision;        /* KD_PREC_*                                                              */
+  const void* Wp;       /* KD_PREC_SPLIT3: packed split image of W from kd_pack_weight_bf16x3     */
+  int debug;            /* must be 0.  Profiling ablations (benchmarks/ only): 1 no C stores, 2 no MFMA,
+                           8 GEGLU without erf                                                    */
+  int scale_tab;        /* internal, overwritten by the library: norm scales staged in LDS        */
 } KdGemm;
 
 int kd_gemm_f32(const KdGemm* desc, void* stream);
+
+/* One-off packing of a weight for KD_PREC_SPLIT3 (weights are static during sampling): W [N or 2N (geglu), K]
+ * fp32 -> `out`, kd_packed_weight_bytes(N, K, geglu) bytes: [n-tile][k-step][hi|lo][128 rows][32 bf16] in the
+ * kernel's swizzled LDS order, zero-padded.  N is the OUTPUT width (GEGLU: d_ff, W has 2*d_ff rows). */
+long long kd_packed_weight_bytes(int N, int K, int geglu);
+int kd_pack_weight_bf16x3(const float* W, void* out, int N, int K, int geglu, void* stream);
 
 /* Stand-alone RMS norm over the last dim (mapping network, image_transformer_v2.py:142-152):
  * y[m,:] = x[m,:] * scale[:] * rsqrt(mean(x[m,:]^2) + eps).  d <= 4096, d % 4 == 0. */

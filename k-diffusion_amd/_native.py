@@ -12,6 +12,15 @@ LIB_PATH = os.environ.get("KDIFF_HIP_LIB") or os.path.join(_HERE, "csrc", "libkd
 # enums (include/kdiff_hip.h)
 A_PLAIN, A_MERGE2x2, A_PATCH_NCHW = 0, 1, 2
 EPI_STORE, EPI_RESIDUAL, EPI_GEGLU, EPI_SPLIT_LERP, EPI_UNPATCH_NCHW = 0, 1, 2, 3, 4
+PREC_EXACT, PREC_SPLIT3 = 0, 1
+
+
+def default_precision():
+    """GEMM arithmetic: KDIFF_GEMM=exact -> fp32 MFMA; split3 (default) -> 3x bf16 split products, fp32 accumulate."""
+    mode = os.environ.get("KDIFF_GEMM", "split3").lower()
+    if mode not in ("exact", "split3"):
+        raise ValueError(f"KDIFF_GEMM={mode!r}: expected 'exact' or 'split3'")
+    return PREC_EXACT if mode == "exact" else PREC_SPLIT3
 (STEP_EULER, STEP_HEUN_PRED, STEP_HEUN_CORR, STEP_DPMPP_2M1, STEP_DPMPP_2M2, STEP_ADD_NOISE, STEP_LERP2, STEP_AXPY,
  STEP_EULER_FROM, STEP_AXPBY, STEP_ADD_DIFF, STEP_TO_D) = range(12)
 
@@ -25,6 +34,7 @@ class KdGemm(C.Structure):
         ("eps", C.c_float), ("out_add", C.c_float), ("sigma_data", C.c_float),
         ("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("R", C.c_void_p),
         ("scale", C.c_void_p), ("sigma", C.c_void_p), ("fac", C.c_void_p),
+        ("precision", C.c_int), ("Wp", C.c_void_p), ("debug", C.c_int), ("scale_tab", C.c_int),
     ]
 
 
@@ -35,6 +45,8 @@ SIGNATURES = {
     "kd_version": [],
     "kd_last_error": [],
     "kd_gemm_f32": [C.POINTER(KdGemm), _vp],
+    "kd_packed_weight_bytes": [_i, _i, _i],
+    "kd_pack_weight_bf16x3": [_vp, _vp, _i, _i, _i, _vp],
     "kd_rmsnorm_f32": [_vp, _vp, _vp, _i, _i, _f, _vp],
     "kd_fourier_sigma_f32": [_vp, _vp, _vp, _i, _i, _vp],
     "kd_fourier_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
@@ -77,7 +89,7 @@ def lib():
             except AttributeError as e:
                 raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.argtypes = argtypes
-            fn.restype = C.c_char_p if name == "kd_last_error" else C.c_int
+            fn.restype = C.c_char_p if name == "kd_last_error" else (C.c_longlong if name == "kd_packed_weight_bytes" else C.c_int)
         _lib = handle
     return _lib
 

@@ -31,6 +31,7 @@ import torch
 from torch import nn
 
 from .. import _native as nat
+from .. import ops
 from . import axial_rope
 
 D_HEAD = 64
@@ -142,6 +143,7 @@ class _Plan:
     def __init__(self, model, B, H, W, has_aug, has_class, has_mapping_cond, device):
         lib = nat.lib()
         m = model
+        precision = nat.default_precision()
         self.keep = []           # descriptors and tensors that must outlive the plan
         self.launches = []
         f32 = dict(device=device, dtype=torch.float32)
@@ -185,6 +187,9 @@ class _Plan:
                  rows_per_sample=0, R=None, grid=(0, 0), patch=(0, 0, 0), out_add=0.0, sigma=None, fac=None):
             d = nat.KdGemm()
             d.M, d.N, d.K, d.a_mode, d.epi = M, N, K, a_mode, epi
+            d.precision = precision
+            if precision == nat.PREC_SPLIT3:
+                d.Wp = ops.pack_weight(Wt, N, K, epi == nat.EPI_GEGLU).data_ptr()
             d.norm = 1 if scale_ptr is not None else 0
             d.rows_per_sample, d.scale_stride = rows_per_sample, scale_stride
             d.gh, d.gw = grid
@@ -408,7 +413,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         if fp != self._fingerprint:
             self._plans, self._fingerprint = {}, fp
         has_class = self.class_emb is not None
-        key = (B, H, W, aug_cond is not None, has_class, self.mapping_cond_in_proj is not None, x.device)
+        key = (B, H, W, aug_cond is not None, has_class, self.mapping_cond_in_proj is not None, x.device, nat.default_precision())
         plan = self._plans.get(key)
         if plan is None:
             if self.patch_in.proj.weight.device != x.device:

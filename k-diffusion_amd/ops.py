@@ -11,6 +11,7 @@ The op names mirror the reference functions they replace
 ``natten.functional.na2d`` -> ``attn_na2d`` (:428).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -37,12 +38,38 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_packed = {}
+_GEMM_DEBUG = int(os.environ.get("KD_GEMM_DEBUG", "0"))      # profiling ablations, benchmarks/ only
+
+
+def pack_weight(W, N, K, geglu, cache=True):
+    """Packed split-bf16 image of a weight for KD_PREC_SPLIT3 (uint8 tensor).  Weights are static while
+    sampling, so the image is cached per (storage, version, shape)."""
+    key = (W.data_ptr(), W._version, tuple(W.shape), N, K, bool(geglu))
+    img = _packed.get(key) if cache else None
+    if img is None:
+        _chk(W, "W")
+        lib = nat.lib()
+        img = torch.empty(lib.kd_packed_weight_bytes(N, K, int(geglu)), device=W.device, dtype=torch.uint8)
+        nat.check(lib.kd_pack_weight_bf16x3(_p(W), _p(img), N, K, int(geglu), _stream()), "kd_pack_weight_bf16x3")
+        if cache:
+            if len(_packed) > 512:
+                _packed.clear()
+            _packed[key] = img
+    return img
+
+
 def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scale=None, scale_stride=0,
          rows_per_sample=0, residual=None, grid=(0, 0), patch=(0, 0, 0), eps=1e-6, out_add=0.0,
-         sigma=None, sigma_data=1.0, fac=None, scale_ptr=None):
+         sigma=None, sigma_data=1.0, fac=None, scale_ptr=None, precision=None):
     """Fused GEMM (see KdGemm in include/kdiff_hip.h).  ``norm_scale`` may be a tensor or, with
-    ``scale_ptr``, a raw device address inside a larger scale table."""
+    ``scale_ptr``, a raw device address inside a larger scale table.  ``precision``: nat.PREC_EXACT /
+    nat.PREC_SPLIT3 (default: KDIFF_GEMM env, split3)."""
     d = nat.KdGemm()
+    d.precision = nat.default_precision() if precision is None else precision
+    d.debug = _GEMM_DEBUG
+    if d.precision == nat.PREC_SPLIT3:
+        d.Wp = pack_weight(W, N, K, epi == nat.EPI_GEGLU).data_ptr()
     d.M, d.N, d.K = M, N, K
     d.a_mode, d.epi = a_mode, epi
     d.norm = 1 if (norm_scale is not None or scale_ptr is not None) else 0

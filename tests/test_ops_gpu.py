@@ -1,8 +1,8 @@
 """Parity of every HIP kernel (through the C ABI) against the CPU oracle and the reference's golden
 op outputs.  Needs a real MI355X:  pytest -m gpu.
 
-Tolerances (max-norm relative unless stated): GEMM-class ops 2e-5 (fp32 FMA-chain order only),
-attention 2e-5, elementwise solver steps BIT-EXACT, index maps implied bit-exact by the value checks
+Tolerances (max-norm relative unless stated): GEMM-class ops 2e-5 in the exact-fp32 MFMA mode (FMA-chain
+order only) and 1e-4 in the default split-bf16x3 mode (per-product error <= ~2^-15), attention 2e-5, elementwise solver steps BIT-EXACT, index maps implied bit-exact by the value checks
 on asymmetric random data."""
 import numpy as np
 import pytest
@@ -21,6 +21,13 @@ def ops(KD):
     return KD.ops
 
 
+@pytest.fixture(params=["exact", "split3"])
+def gtol(request, monkeypatch):
+    """Runs a GEMM-class test in both arithmetic modes; returns the mode's tolerance."""
+    monkeypatch.setenv("KDIFF_GEMM", request.param)
+    return 2e-5 if request.param == "exact" else 1e-4
+
+
 def rn(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
 
@@ -29,12 +36,29 @@ def g(t):
     return t.to(DEV).contiguous()
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (131, 200, 96), (32, 768, 256), (1000, 48, 128), (5, 7 * 4, 12), (384, 512, 1536)])
-def test_gemm_plain_and_residual(ops, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (131, 200, 96), (32, 768, 256), (1000, 48, 128), (5, 7 * 4, 12), (384, 512, 1536),
+                                   (257, 129, 48), (64, 3072, 512)])
+def test_gemm_plain_and_residual(ops, gtol, M, N, K):
     x, w, r = rn(M, K, seed=1), rn(N, K, seed=2) / K ** 0.5, rn(M, N, seed=3)
-    assert relerr(ops.linear(g(x), g(w)), x @ w.T) < 2e-5
-    assert relerr(ops.linear(g(x), g(w), residual=g(r)), x @ w.T + r) < 2e-5
-    assert relerr(ops.linear(g(x), g(w), out_add=1.0), x @ w.T + 1) < 2e-5
+    assert relerr(ops.linear(g(x), g(w)), x @ w.T) < gtol
+    assert relerr(ops.linear(g(x), g(w), residual=g(r)), x @ w.T + r) < gtol
+    assert relerr(ops.linear(g(x), g(w), out_add=1.0), x @ w.T + 1) < gtol
+
+
+def test_split3_error_is_bounded_and_asymmetric_safe(ops, monkeypatch):
+    """The split-bf16x3 product against an fp64 reference on wide-dynamic-range data: error stays ~2^-15-class
+    relative to sum|a*b| (a transposed / permuted operand would show up as O(1))."""
+    monkeypatch.setenv("KDIFF_GEMM", "split3")
+    M, N, K = 300, 260, 512
+    x = rn(M, K, seed=7) * torch.logspace(-3, 3, K)[None, :]
+    w = rn(N, K, seed=8) * torch.logspace(2, -2, N)[:, None]
+    ref = x.double() @ w.double().T
+    bound = x.abs().double() @ w.abs().double().T
+    got = ops.linear(g(x), g(w)).cpu().double()
+    assert ((got - ref).abs() / bound).max().item() < 2.0 ** -14
+    monkeypatch.setenv("KDIFF_GEMM", "exact")
+    got = ops.linear(g(x), g(w)).cpu().double()
+    assert ((got - ref).abs() / bound).max().item() < 2.0 ** -20
 
 
 def test_gemm_rejects_bad_shapes(ops):
@@ -45,7 +69,7 @@ def test_gemm_rejects_bad_shapes(ops):
         ops.linear(rn(8, 8), g(rn(4, 8)))          # CPU tensor: no fallback
 
 
-def test_norm_linear_and_geglu(ops, golden):
+def test_norm_linear_and_geglu(ops, gtol, golden):
     o = golden["ops"]
     x, cond, wl, wg = o["rms_norm.x"], o["adarms.cond"], o["adarms.w"], o["geglu.w"]
     # stand-alone rms_norm vs the reference's output
@@ -54,44 +78,44 @@ def test_norm_linear_and_geglu(ops, golden):
     scale = ops.linear(g(cond), g(wl), out_add=1.0)
     y = ops.norm_linear(g(x), scale, g(wg), rows_per_sample=64, epi=2)
     ref = hdit.linear_geglu(o["adarms.y"], wg)
-    assert relerr(y, ref) < 2e-5
+    assert relerr(y, ref) < gtol
     # plain GEGLU against the reference's own linear_geglu output
-    assert relerr(ops.linear_geglu(g(x), g(wg)), o["geglu.y"]) < 2e-5
+    assert relerr(ops.linear_geglu(g(x), g(wg)), o["geglu.y"]) < gtol
     # fused norm -> plain linear with shared gain
     w = rn(96, 128, seed=5) / 128 ** 0.5
     y = ops.norm_linear(g(x), g(o["rms_norm.scale"]), g(w), rows_per_sample=64)
-    assert relerr(y, o["rms_norm.y"] @ w.T) < 2e-5
+    assert relerr(y, o["rms_norm.y"] @ w.T) < gtol
 
 
-def test_token_merge_split(ops, golden):
+def test_token_merge_split(ops, gtol, golden):
     o = golden["ops"]
     x = o["rms_norm.x"]
-    assert relerr(ops.token_merge(g(x), g(o["merge.w"])), o["merge.y"]) < 2e-5
+    assert relerr(ops.token_merge(g(x), g(o["merge.w"])), o["merge.y"]) < gtol
     for fac in (0.37, 0.5, 0.8):
         skip = o["split.skip"]
         ref = torch.lerp(skip, hdit.token_split(x, o["split.w"], 2, 2), torch.tensor([fac]))
         y = ops.token_split_lerp(g(x), g(o["split.w"]), g(skip), g(torch.tensor([fac])))
-        assert relerr(y, ref) < 2e-5
+        assert relerr(y, ref) < gtol
     y = ops.token_split_lerp(g(x), g(o["split.w"]), g(o["split.skip"]), g(torch.tensor([0.37])))
-    assert relerr(y, o["split.y"]) < 2e-5
+    assert relerr(y, o["split.y"]) < gtol
 
 
 @pytest.mark.parametrize("C,H,W,p,d", [(3, 16, 16, 2, 128), (1, 28, 28, 4, 64), (3, 32, 64, 4, 128)])
-def test_patch_in_out(ops, C, H, W, p, d):
+def test_patch_in_out(ops, gtol, C, H, W, p, d):
     B = 3
     img, w_in = rn(B, C, H, W, seed=1), rn(d, C * p * p, seed=2)
     sigma = torch.tensor([0.05, 1.3, 70.0])
     ref = hdit.token_merge(img.movedim(1, -1).contiguous(), w_in, p, p)
-    assert relerr(ops.patch_in(g(img), g(w_in), (p, p)), ref) < 2e-5
+    assert relerr(ops.patch_in(g(img), g(w_in), (p, p)), ref) < gtol
     c_skip, c_out, c_in = solvers.karras_scalings(sigma, 0.5)
     ref_c = hdit.token_merge((img * c_in.view(-1, 1, 1, 1)).movedim(1, -1).contiguous(), w_in, p, p)
-    assert relerr(ops.patch_in(g(img), g(w_in), (p, p), sigma=g(sigma), sigma_data=0.5), ref_c) < 2e-5
+    assert relerr(ops.patch_in(g(img), g(w_in), (p, p), sigma=g(sigma), sigma_data=0.5), ref_c) < gtol
     x, scale, w_out = rn(B, H // p, W // p, d, seed=3), 1 + 0.1 * rn(d, seed=4), rn(C * p * p, d, seed=5) / d ** 0.5
     inner = hdit.token_split(hdit.rms_norm(x, scale), w_out, p, p).movedim(-1, 1)
-    assert relerr(ops.patch_out(g(x), g(scale), g(w_out), (p, p), C), inner) < 2e-5
+    assert relerr(ops.patch_out(g(x), g(scale), g(w_out), (p, p), C), inner) < gtol
     ref_d = inner * c_out.view(-1, 1, 1, 1) + img * c_skip.view(-1, 1, 1, 1)
     y = ops.patch_out(g(x), g(scale), g(w_out), (p, p), C, x_in=g(img), sigma=g(sigma), sigma_data=0.5)
-    assert relerr(y, ref_d) < 2e-5
+    assert relerr(y, ref_d) < gtol
 
 
 def _tables(h, w, nh):
