@@ -83,6 +83,9 @@ def run_attn(args, res, what):
         byts = 4.0 * B * h * h * nh * 64 * 4
         if what == "na" and lv < 2:
             us = timeit(lambda: ops.attn_na2d(qkv, nh, 7, prep=prep, out=out), args.iters)
+            us0 = timeit(lambda: ops.attn_na2d(qkv, nh, 7, out=out), args.iters)
+            print(f"na (q,k prepared by the qkv GEMM) L{lv}  {us0:8.1f} us  {byts / us0 / 1e3:7.0f} GB/s", flush=True)
+            res[f"na_noprep L{lv}"] = {"us": round(us0, 1), "gbs": round(byts / us0 / 1e3, 0)}
         elif what == "window" and lv < 2:
             us = min(timeit(lambda: ops.attn_window(qkv, nh, 8, s, prep=prep, out=out), args.iters) for s in (0, 4))
         elif what == "global" and lv == 2:

@@ -44,7 +44,9 @@ enum { KD_A_PLAIN = 0, KD_A_MERGE2x2 = 1, KD_A_PATCH_NCHW = 2 };
 /* arithmetic of the products: exact fp32 MFMA (bit-for-bit an fmaf chain), or each fp32 operand split into two
  * bf16 (hi + lo, 16 significand bits) with hi*hi + hi*lo + lo*hi on the bf16 MFMA and fp32 accumulation */
 enum { KD_PREC_EXACT = 0, KD_PREC_SPLIT3 = 1 };
-enum { KD_EPI_STORE = 0, KD_EPI_RESIDUAL = 1, KD_EPI_GEGLU = 2, KD_EPI_SPLIT_LERP = 3, KD_EPI_UNPATCH_NCHW = 4 };
+enum { KD_EPI_STORE = 0, KD_EPI_RESIDUAL = 1, KD_EPI_GEGLU = 2, KD_EPI_SPLIT_LERP = 3, KD_EPI_UNPATCH_NCHW = 4,
+       KD_EPI_QKV = 5 /* store a qkv projection with q,k prepared: cosine-sim scaling + axial RoPE
+                         (image_transformer_v2.py:106-121,187-231) applied in the epilogue, v untouched */ };
 
 typedef struct {
   int M, N, K;          /* C is [M, N]; K = reduction length (multiple of 4)                      */
@@ -70,6 +72,10 @@ typedef struct {
   int debug;            /* must be 0.  Profiling ablations (benchmarks/ only): 1 no C stores, 2 no MFMA,
                            8 GEGLU without erf                                                    */
   int scale_tab;        /* internal, overwritten by the library: norm scales staged in LDS        */
+  int n_heads;          /* KD_EPI_QKV: N == 3 * n_heads * 64; token of row m = m % rows_per_sample   */
+  const float* qk_scale;  /* KD_EPI_QKV: [n_heads] cosine-sim scale (self_attn.scale)                 */
+  const float* rope_cos;  /* KD_EPI_QKV: [rows_per_sample, n_heads, 16] cos / sin of AxialRoPE theta  */
+  const float* rope_sin;
 } KdGemm;
 
 int kd_gemm_f32(const KdGemm* desc, void* stream);

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("KDIFF_HIP_LIB") or os.path.join(_HERE, "csrc", "libkd
 
 # enums (include/kdiff_hip.h)
 A_PLAIN, A_MERGE2x2, A_PATCH_NCHW = 0, 1, 2
-EPI_STORE, EPI_RESIDUAL, EPI_GEGLU, EPI_SPLIT_LERP, EPI_UNPATCH_NCHW = 0, 1, 2, 3, 4
+EPI_STORE, EPI_RESIDUAL, EPI_GEGLU, EPI_SPLIT_LERP, EPI_UNPATCH_NCHW, EPI_QKV = 0, 1, 2, 3, 4, 5
 PREC_EXACT, PREC_SPLIT3 = 0, 1
 
 
@@ -35,6 +35,7 @@ class KdGemm(C.Structure):
         ("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("R", C.c_void_p),
         ("scale", C.c_void_p), ("sigma", C.c_void_p), ("fac", C.c_void_p),
         ("precision", C.c_int), ("Wp", C.c_void_p), ("debug", C.c_int), ("scale_tab", C.c_int),
+        ("n_heads", C.c_int), ("qk_scale", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
     ]
 
 

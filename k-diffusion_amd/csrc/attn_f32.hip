@@ -23,30 +23,13 @@
 // (16 head dims each, two DPP shuffles per score); the 14x14 key halo of an 8x8 query tile is staged
 // in LDS, K first, then V in the same buffer.
 #include "kd_common.h"
+#include <type_traits>
 
 namespace kd {
 
 constexpr int DH = 64;          // head dim (fixed: every config, k_diffusion/config.py:135-136)
 constexpr int LDS_ROW = DH + 4; // padded LDS row (floats)
 constexpr int ROT = 16;         // rotary angles per head: dims [0,16) pair with [16,32)
-
-// ---- q/k row preparation, 16 lanes per 64-float row: lane c = lane & 15 owns dims [4c, 4c+4) -------
-// scale_for_cosine_sim (image_transformer_v2.py:106-114) then _apply_rotary_emb_inplace (:187-199).
-__device__ __forceinline__ f32x4 prep_row16(f32x4 v, int c, float sqrt_scale, const float* cs_row, const float* sn_row, float eps) {
-  float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-  ss = wave_sum_xor(ss, 16);
-  const float f = sqrt_scale * rsqrtf(ss + eps);
-  v = v * f;
-  f32x4 o;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) o[u] = __shfl_xor(v[u], 4, 64);
-  if (c < 8) {
-    const f32x4 cs = *reinterpret_cast<const f32x4*>(cs_row + 4 * (c & 3));
-    const f32x4 sn = *reinterpret_cast<const f32x4*>(sn_row + 4 * (c & 3));
-    v = (c < 4) ? (v * cs - o * sn) : (v * cs + o * sn);
-  }
-  return v;
-}
 
 __global__ __launch_bounds__(256) void qk_prep_kernel(float* qkv, const float* scale_h, const float* cos_t, const float* sin_t,
                                                       long rows_total, int tokens_per_sample, int nh, float eps) {
@@ -257,6 +240,22 @@ __global__ __launch_bounds__(MAXT * 64) void attn_dense_kernel(const DenseArgs a
 }
 
 // ---- neighbourhood core -----------------------------------------------------------------------------
+// One 128-thread workgroup (2 wave64s) per (sample, head, 8x8 query tile).  The 14x14 key halo of the tile is
+// staged in LDS ONCE, K first (cosine-sim scale + RoPE applied on the way in), then V in the same buffer, both as
+// split bf16 (hi = bf16(x), lo = bf16(x - hi)): the two products of the tile then run on the bf16 MFMA with the
+// 3-term split (hi*hi + hi*lo + lo*hi, fp32 accumulate; per-product error <= ~2^-15, like the GEMMs).
+//   wave w owns query rows 4w..4w+3 (32 queries = the MFMA's 32 columns); its clamped 7x7 windows lie inside 10
+//   halo rows = 140 keys -> 5 key tiles of 32
+//   S^T[key][query] = K Q^T : K rows are the A operand (8 consecutive head dims per lane, 16-byte LDS reads from
+//                     128-byte rows, chunk index XOR-swizzled with (row>>1)&7), Q the B operand from registers
+//   mask (window test per (key, query) from indices; nothing materialised) + softmax, in registers: a lane owns ONE
+//                     query (column) and 16 keys per tile, so the row reductions are in-lane plus one cross-half shuffle
+//   O^T[e][query]   = V^T P^T: the P registers feed the B operand directly (an MFMA contracts over 16 keys in the
+//                     k-slot order [4h..4h+3, 8+4h..8+4h+3] of lane-half h; any order is valid as long as A uses
+//                     the same one), so V is staged TRANSPOSED ([e][key], 456-byte rows: conflict-free 8-byte reads)
+// The V halo is prefetched into registers before the QK^T phase so that its HBM latency hides behind the MFMAs.
+// Against a dense MFMA tiling the masked keys waste ~65% of the matrix work, but at the bf16 rate that is ~13 us
+// per launch at the largest level; the kernel is bound by staging (HBM/L2 -> LDS) and LDS traffic instead.
 struct NaArgs {
   const float* qkv; float* out;
   const float* scale_h; const float* cos_t; const float* sin_t;
@@ -265,13 +264,41 @@ struct NaArgs {
 };
 
 constexpr int NA_K = 7, NA_TILE = 8, NA_HALO = NA_TILE + NA_K - 1;   // 14
+constexpr int NA_KEYS = NA_HALO * NA_HALO;                           // 196
+constexpr int NA_ROWS = 224;                                         // halo rows padded to 7 key tiles of 32
+constexpr int NA_KT = 5;                                             // key tiles per wave
+constexpr int NA_STAGE_IT = (NA_KEYS + 7) / 8;                       // 25 staging rounds of 8 rows (16 lanes per row)
+constexpr int NA_VT_STRIDE = 456;                                    // bytes per e-row of the transposed V image
+constexpr int NA_IMG_K = NA_ROWS * 128;                              // bytes of one K image  [224][64] bf16
+constexpr int NA_IMG_V = DH * NA_VT_STRIDE;                          // bytes of one V^T image [64][228] bf16
+constexpr int NA_LDS = 2 * (NA_IMG_K > NA_IMG_V ? NA_IMG_K : NA_IMG_V);
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
+  using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+  bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+// 4 floats -> (hi, lo) bf16 quads
+__device__ __forceinline__ void split4_bf16(const f32x4 v, u32x2& hi, u32x2& lo) {
+  hi[0] = pack2_bf16(v[0], v[1]);
+  hi[1] = pack2_bf16(v[2], v[3]);
+  lo[0] = pack2_bf16(v[0] - __uint_as_float(hi[0] << 16), v[1] - __uint_as_float(hi[0] & 0xFFFF0000u));
+  lo[1] = pack2_bf16(v[2] - __uint_as_float(hi[1] << 16), v[3] - __uint_as_float(hi[1] & 0xFFFF0000u));
+}
+// byte offset of (row, 16-byte chunk c of 8) in a [rows][64] bf16 image with 128-byte rows
+__device__ __forceinline__ int na_kswz(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 
 template <bool PREP>
-__global__ __launch_bounds__(256) void attn_na2d_kernel(const NaArgs a) {
-  __shared__ __attribute__((aligned(16))) float KV[NA_HALO * NA_HALO * LDS_ROW];   // K, then V
-  const int tid = threadIdx.x;
+__global__ __launch_bounds__(128) void attn_na2d_kernel(const NaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char na_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h2 = lane >> 5;
   const int tiles_x = (a.W + NA_TILE - 1) / NA_TILE, tiles_y = (a.H + NA_TILE - 1) / NA_TILE;
   int r = blockIdx.x;
   const int tx = r % tiles_x; r /= tiles_x;
@@ -285,116 +312,240 @@ __global__ __launch_bounds__(256) void attn_na2d_kernel(const NaArgs a) {
   const int hy0 = clampi(ty0 - NA_K / 2, 0, max(0, a.H - NA_HALO));
   const int hx0 = clampi(tx0 - NA_K / 2, 0, max(0, a.W - NA_HALO));
 
-  auto stage = [&](int which) {   // which: 1 = K (prepared), 2 = V
-    const int c = tid & 15;
-    for (int hr = tid >> 4; hr < NA_HALO * NA_HALO; hr += 16) {
-      const int ky = hy0 + hr / NA_HALO, kx = hx0 + hr % NA_HALO;
-      const bool ok = ky < a.H && kx < a.W;
-      const int tok = ok ? ky * a.W + kx : 0;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(base + (long)tok * row_stride + which * a.nh * DH + 4 * c);
-      if (PREP && which == 1)
-        v = prep_row16(v, c, sqrt_scale, a.cos_t + ((long)tok * a.nh + head) * ROT, a.sin_t + ((long)tok * a.nh + head) * ROT, a.eps);
-      *reinterpret_cast<f32x4*>(KV + hr * LDS_ROW + 4 * c) = v;
+  // ---- halo loads: 16 lanes per key row, 8 rows per round; all rounds requested before any is consumed --------
+  const int c16 = tid & 15, rsub = tid >> 4;
+  auto halo_tok = [&](int it) -> int {       // token index of this thread's row in round `it`, -1 outside the image / halo
+    const int hr = it * 8 + rsub;
+    const int ky = hy0 + hr / NA_HALO, kx = hx0 + hr % NA_HALO;
+    return (hr < NA_KEYS && ky < a.H && kx < a.W) ? ky * a.W + kx : -1;
+  };
+  // ---- this lane's query (column l31 of wave wid): 32 of its 64 dims, 8-wide chunks 2*step + h2 ----------------
+  const int qy_raw = ty0 + 4 * wid + (l31 >> 3), qx_raw = tx0 + (l31 & 7);
+  const bool q_ok = qy_raw < a.H && qx_raw < a.W;
+  const int qy = min(qy_raw, a.H - 1), qx = min(qx_raw, a.W - 1);     // overhanging lanes shadow a real query, never store
+  const int q_tok = qy * a.W + qx;
+  f32x4 qf[8];
+  {
+    const float* rp = base + (long)q_tok * row_stride;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      qf[2 * st] = *reinterpret_cast<const f32x4*>(rp + 16 * st + 8 * h2);
+      qf[2 * st + 1] = *reinterpret_cast<const f32x4*>(rp + 16 * st + 8 * h2 + 4);
+    }
+  }
+
+  // ---- K -> LDS: prepare (scale_for_cosine_sim + RoPE), split, swizzled row-major images ------------------------
+  // two batches of rounds, each requested in full before it is consumed (memory-level parallelism vs registers)
+  char* Khi = na_smem;
+  char* Klo = na_smem + NA_IMG_K;
+  auto stage_k = [&](auto it0_tag, auto n_tag) {
+    constexpr int IT0 = decltype(it0_tag)::value, N = decltype(n_tag)::value;
+    f32x4 kreg[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int tok = halo_tok(IT0 + i);
+      kreg[i] = *reinterpret_cast<const f32x4*>(base + (long)(tok < 0 ? 0 : tok) * row_stride + a.nh * DH + 4 * c16);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int tok = halo_tok(IT0 + i);
+      const int hr = (IT0 + i) * 8 + rsub;
+      f32x4 v = kreg[i];
+      if (tok < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (PREP) {
+        const int tk = tok < 0 ? 0 : tok;
+        v = prep_row16(v, c16, sqrt_scale, a.cos_t + ((long)tk * a.nh + head) * ROT, a.sin_t + ((long)tk * a.nh + head) * ROT, a.eps);
+      }
+      u32x2 hi, lo;
+      split4_bf16(v, hi, lo);
+      const int o = na_kswz(hr, c16 >> 1) + (c16 & 1) * 8;
+      *reinterpret_cast<u32x2*>(Khi + o) = hi;
+      *reinterpret_cast<u32x2*>(Klo + o) = lo;
     }
   };
-  stage(1);
-
-  // ---- this lane's query quarter: query qb = tid>>2 of the 8x8 tile, dims [16*pi, 16*pi+16) ----------
-  const int qb = tid >> 2, pi = tid & 3;
-  const int qy = ty0 + (qb >> 3), qx = tx0 + (qb & 7);
-  const bool q_ok = qy < a.H && qx < a.W;
-  const int q_tok = q_ok ? qy * a.W + qx : 0;
-  f32x4 q[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) q[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (q_ok) {
-    const float* rp = base + (long)q_tok * row_stride + 16 * pi;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) q[j] = *reinterpret_cast<const f32x4*>(rp + 4 * j);
+  stage_k(std::integral_constant<int, 0>{}, std::integral_constant<int, 13>{});
+  stage_k(std::integral_constant<int, 13>{}, std::integral_constant<int, NA_STAGE_IT - 13>{});
+  // rows 200..223 are read by the last key tile of wave 1 (always masked): keep them finite
+  for (int i = tid; i < (NA_ROWS - 200) * 8; i += 128) {
+    *reinterpret_cast<u32x4*>(Khi + 200 * 128 + i * 16) = u32x4{0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(Klo + 200 * 128 + i * 16) = u32x4{0u, 0u, 0u, 0u};
   }
+
+  // ---- q preparation + split into B-operand fragments --------------------------------------------------------------
   if (PREP) {
     float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ss += q[j][0] * q[j][0] + q[j][1] * q[j][1] + q[j][2] * q[j][2] + q[j][3] * q[j][3];
-    ss = wave_sum_xor(ss, 4);
+    for (int i = 0; i < 8; ++i) ss += qf[i][0] * qf[i][0] + qf[i][1] * qf[i][1] + qf[i][2] * qf[i][2] + qf[i][3] * qf[i][3];
+    ss += __shfl_xor(ss, 32, 64);
     const float f = sqrt_scale * rsqrtf(ss + a.eps);
-    const float* cs = a.cos_t + ((long)q_tok * a.nh + head) * ROT;
-    const float* sn = a.sin_t + ((long)q_tok * a.nh + head) * ROT;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      q[j] = q[j] * f;
-      f32x4 o;
+    for (int i = 0; i < 8; ++i) qf[i] = qf[i] * f;
+    // rotary pairs (d, d+16), d < 16: step 0 holds dims 8h2..8h2+7, step 1 holds 16+8h2..: both in this lane
+    const float* cs = a.cos_t + ((long)q_tok * a.nh + head) * ROT + 8 * h2;
+    const float* sn = a.sin_t + ((long)q_tok * a.nh + head) * ROT + 8 * h2;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) o[u] = __shfl_xor(q[j][u], 1, 64);   // pi 0 <-> 1 : dims d <-> d+16
-      if (pi < 2) {
-        const f32x4 cc = *reinterpret_cast<const f32x4*>(cs + 4 * j);
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(sn + 4 * j);
-        q[j] = (pi == 0) ? (q[j] * cc - o * sc) : (q[j] * cc + o * sc);
-      }
+    for (int u = 0; u < 2; ++u) {
+      const f32x4 cc = *reinterpret_cast<const f32x4*>(cs + 4 * u), sc = *reinterpret_cast<const f32x4*>(sn + 4 * u);
+      const f32x4 x1 = qf[u], x2 = qf[2 + u];
+      qf[u] = x1 * cc - x2 * sc;
+      qf[2 + u] = x2 * cc + x1 * sc;
     }
   }
-  // clamped window start (NATTEN semantics, dilation 1), relative to the halo origin
+  bf16x8 qh[4], ql[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    u32x2 h0, l0, h1, l1;
+    split4_bf16(qf[2 * st], h0, l0);
+    split4_bf16(qf[2 * st + 1], h1, l1);
+    qh[st] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+    ql[st] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+  }
+
+  // clamped window start (NATTEN semantics, dilation 1), relative to the halo origin; first halo row of this wave
   const int wy = clampi(qy - NA_K / 2, 0, a.H - NA_K) - hy0;
   const int wx = clampi(qx - NA_K / 2, 0, a.W - NA_K) - hx0;
+  // (at the bottom border the halo is pulled up, so the wave's 10 rows are clamped into the halo's 14)
+  const int row_lo = min(clampi(min(ty0 + 4 * wid, a.H - 1) - NA_K / 2, 0, a.H - NA_K) - hy0, NA_HALO - 10);
+  const int kbase = row_lo * NA_HALO;            // first key (halo index) of this wave's 160-key range
   __syncthreads();
 
-  // ---- scores over the 49 keys ---------------------------------------------------------------------
-  float s[NA_K * NA_K];
-  float m = -INFINITY;
-  if (q_ok) {
+  // ---- S^T = K Q^T over the wave's 5 key tiles ----------------------------------------------------------------------
+  f32x16 S[NA_KT];
 #pragma unroll
-    for (int ai = 0; ai < NA_K; ++ai) {
+  for (int t = 0; t < NA_KT; ++t) {
 #pragma unroll
-      for (int bj = 0; bj < NA_K; ++bj) {
-        const float* kp = KV + ((wy + ai) * NA_HALO + wx + bj) * LDS_ROW + 16 * pi;
-        float d = 0.f;
+    for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
+    const int row = kbase + t * 32 + l31;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + 4 * j);
-          d += q[j][0] * kf[0] + q[j][1] * kf[1] + q[j][2] * kf[2] + q[j][3] * kf[3];
-        }
-        s[ai * NA_K + bj] = d;
-      }
+    for (int st = 0; st < 4; ++st) {
+      const int o = na_kswz(row, 2 * st + h2);
+      const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Khi + o);
+      const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Klo + o);
+      S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[st], S[t], 0, 0, 0);
+      S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[st], S[t], 0, 0, 0);
+      S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[st], S[t], 0, 0, 0);
     }
-  } else {
-#pragma unroll
-    for (int i = 0; i < NA_K * NA_K; ++i) s[i] = 0.f;
   }
+
+  // ---- V halo prefetch (requested now, consumed after the softmax) ---------------------------------------------------------------
+  f32x4 vreg[NA_STAGE_IT];
+#pragma unroll
+  for (int it = 0; it < NA_STAGE_IT; ++it) {
+    const int tok = halo_tok(it);
+    vreg[it] = *reinterpret_cast<const f32x4*>(base + (long)(tok < 0 ? 0 : tok) * row_stride + 2 * a.nh * DH + 4 * c16);
+  }
+
+  // ---- window mask + softmax over keys (the mask enters as an additive 0 / -inf bias) ----
+  // validity of the wave's 160 keys for THIS lane's query as 5 x 32-bit words: the window is 7 runs of 7 consecutive
+  // halo keys; bit j of word t <=> key kbase + 32t + j is inside the window
+  unsigned vw[NA_KT];
+#pragma unroll
+  for (int t = 0; t < NA_KT; ++t) vw[t] = 0u;
+  {
+    const int s0 = (wy - row_lo) * NA_HALO + wx;
+#pragma unroll
+    for (int rr = 0; rr < NA_K; ++rr) {
+      const int s_ = s0 + rr * NA_HALO, word = s_ >> 5;
+      const unsigned long long run = 0x7Full << (s_ & 31);
+#pragma unroll
+      for (int t = 0; t < NA_KT; ++t)
+        vw[t] |= (word == t ? (unsigned)run : 0u) | (word + 1 == t ? (unsigned)(run >> 32) : 0u);
+    }
+#pragma unroll
+    for (int t = 0; t < NA_KT; ++t) vw[t] >>= 4 * h2;         // accumulator element i of this lane is key (i&3) + 8*(i>>2) + 4*h2
+  }
+  auto key_bias = [&](int t, int i) -> float {
+    return (vw[t] & (1u << ((i & 3) + 8 * (i >> 2)))) ? 0.f : -INFINITY;
+  };
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NA_KT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      S[t][i] += key_bias(t, i);          // additive 0 / -inf mask, folded in once
+      m = fmaxf(m, S[t][i]);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
   float l = 0.f;
 #pragma unroll
-  for (int i = 0; i < NA_K * NA_K; ++i) {
-    s[i] = wave_sum_xor(s[i], 4);
-    m = fmaxf(m, s[i]);
-  }
+  for (int t = 0; t < NA_KT; ++t)
 #pragma unroll
-  for (int i = 0; i < NA_K * NA_K; ++i) {
-    s[i] = expf(s[i] - m);
-    l += s[i];
-  }
-  __syncthreads();
-  stage(2);
-  __syncthreads();
+    for (int i = 0; i < 16; ++i) {
+      const float pv = __expf(S[t][i] - m);
+      S[t][i] = pv;
+      l += pv;
+    }
+  l += __shfl_xor(l, 32, 64);
 
-  // ---- output quarter ---------------------------------------------------------------------------
-  f32x4 o[4];
+  // ---- V -> LDS, transposed: Vt[e][key], split --------------------------------------------------------------------------
+  __syncthreads();                       // every wave is done reading K
+  char* Vhi = na_smem;
+  char* Vlo = na_smem + NA_IMG_V;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (q_ok) {
+  for (int it = 0; it < NA_STAGE_IT; ++it) {
+    const int tok = halo_tok(it);
+    const int hr = it * 8 + rsub;
+    if (hr < NA_KEYS) {
+      f32x4 v = vreg[it];
+      if (tok < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x2 hi, lo;
+      split4_bf16(v, hi, lo);
 #pragma unroll
-    for (int ai = 0; ai < NA_K; ++ai) {
-#pragma unroll
-      for (int bj = 0; bj < NA_K; ++bj) {
-        const float* vp = KV + ((wy + ai) * NA_HALO + wx + bj) * LDS_ROW + 16 * pi;
-        const float p = s[ai * NA_K + bj];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = o[j] + *reinterpret_cast<const f32x4*>(vp + 4 * j) * p;
+      for (int u = 0; u < 4; ++u) {
+        const int o = (4 * c16 + u) * NA_VT_STRIDE + hr * 2;
+        *reinterpret_cast<unsigned short*>(Vhi + o) = (unsigned short)(hi[u >> 1] >> (16 * (u & 1)));
+        *reinterpret_cast<unsigned short*>(Vlo + o) = (unsigned short)(lo[u >> 1] >> (16 * (u & 1)));
       }
     }
-    const float inv = 1.0f / l;
-    float* op = a.out + ((long)b * T + q_tok) * (a.nh * DH) + head * DH + 16 * pi;
+  }
+  for (int i = tid; i < DH * (NA_ROWS - NA_KEYS) / 4; i += 128) {     // keys 196..223 of every e-row: zero (8-byte pieces)
+    const int e = i / ((NA_ROWS - NA_KEYS) / 4), kq = i % ((NA_ROWS - NA_KEYS) / 4);
+    *reinterpret_cast<u32x2*>(Vhi + e * NA_VT_STRIDE + (NA_KEYS + 4 * kq) * 2) = u32x2{0u, 0u};
+    *reinterpret_cast<u32x2*>(Vlo + e * NA_VT_STRIDE + (NA_KEYS + 4 * kq) * 2) = u32x2{0u, 0u};
+  }
+  __syncthreads();
+
+  // ---- O^T = V^T P^T ------------------------------------------------------------------------------------------------------
+  f32x16 O[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(op + 4 * j) = o[j] * inv;
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) O[e][i] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NA_KT; ++t) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      // B operand: this lane's 8 probabilities of k-slots (regs 8u..8u+7 = keys 16u+4h2+{0..3} and 16u+8+4h2+{0..3})
+      u32x2 ph0, pl0, ph1, pl1;
+      split4_bf16(f32x4{S[t][8 * u], S[t][8 * u + 1], S[t][8 * u + 2], S[t][8 * u + 3]}, ph0, pl0);
+      split4_bf16(f32x4{S[t][8 * u + 4], S[t][8 * u + 5], S[t][8 * u + 6], S[t][8 * u + 7]}, ph1, pl1);
+      const bf16x8 ph = __builtin_bit_cast(bf16x8, u32x4{ph0[0], ph0[1], ph1[0], ph1[1]});
+      const bf16x8 pl = __builtin_bit_cast(bf16x8, u32x4{pl0[0], pl0[1], pl1[0], pl1[1]});
+      const int key0 = kbase + t * 32 + 16 * u + 4 * h2;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int o = (32 * e + l31) * NA_VT_STRIDE + key0 * 2;
+        const u32x2 vh0 = *reinterpret_cast<const u32x2*>(Vhi + o), vh1 = *reinterpret_cast<const u32x2*>(Vhi + o + 16);
+        const u32x2 vl0 = *reinterpret_cast<const u32x2*>(Vlo + o), vl1 = *reinterpret_cast<const u32x2*>(Vlo + o + 16);
+        const bf16x8 vh = __builtin_bit_cast(bf16x8, u32x4{vh0[0], vh0[1], vh1[0], vh1[1]});
+        const bf16x8 vl = __builtin_bit_cast(bf16x8, u32x4{vl0[0], vl0[1], vl1[0], vl1[1]});
+        O[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, O[e], 0, 0, 0);
+        O[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, O[e], 0, 0, 0);
+        O[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, O[e], 0, 0, 0);
+      }
+    }
+  }
+
+  if (q_ok) {
+    const float inv = 1.0f / l;
+    float* op = a.out + ((long)b * T + q_tok) * (a.nh * DH) + head * DH;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {O[e][4 * g] * inv, O[e][4 * g + 1] * inv, O[e][4 * g + 2] * inv, O[e][4 * g + 3] * inv};
+        *reinterpret_cast<f32x4*>(op + e * 32 + 8 * g + 4 * h2) = v;
+      }
   }
 }
 
@@ -475,7 +626,13 @@ extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, 
   const long nb = (long)batch * nh * ((H + NA_TILE - 1) / NA_TILE) * ((W + NA_TILE - 1) / NA_TILE);
   hipStream_t s = (hipStream_t)stream;
   LaunchScope prof("attn_na2d_f32", 4.0 * batch * (double)H * W * nh * DH * ks * ks, 16.0 * batch * (double)H * W * nh * DH, s);
-  if (prep) hipLaunchKernelGGL(attn_na2d_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(attn_na2d_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, a);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
+    attr_set = true;
+  }
+  if (prep) hipLaunchKernelGGL(attn_na2d_kernel<true>, dim3((unsigned)nb), dim3(128), NA_LDS, s, a);
+  else hipLaunchKernelGGL(attn_na2d_kernel<false>, dim3((unsigned)nb), dim3(128), NA_LDS, s, a);
   return check_launch("kd_attn_na2d_f32");
 }

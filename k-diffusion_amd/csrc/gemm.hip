@@ -397,6 +397,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KdGemm p) {
             off[t] = (long)gmc * N + gnc;
           }
           if (EPI == KD_EPI_RESIDUAL || EPI == KD_EPI_SPLIT_LERP) rv[t] = *reinterpret_cast<const f32x4*>(p.R + off[t]);
+          if (EPI == KD_EPI_QKV) {
+            // this wave's 64 columns are ONE (q|k|v, head) vector of the row; 16 lanes hold it (4 dims each)
+            const int vec = wn0 >> 6, which = vec / p.n_heads, head = vec - which * p.n_heads;
+            if (which < 2) {
+              const long tr = ((long)(gmc % p.rows_per_sample) * p.n_heads + head) * KD_ROT;
+              v[t] = prep_row16(v[t], lane & 15, sqrtf(p.qk_scale[head]), p.rope_cos + tr, p.rope_sin + tr, p.eps);
+            }
+          }
         }
 #pragma unroll
         for (int t = 0; t < PER_LANE; ++t) {
@@ -536,6 +544,8 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
   if (d.epi == KD_EPI_UNPATCH_NCHW && (d.ph <= 0 || d.pw <= 0 || d.chan <= 0 || d.N != d.ph * d.pw * d.chan || d.gh <= 0 || d.gw <= 0 || d.M % (d.gh * d.gw) || (d.sigma && !d.R)))
     return fail(KD_EINVAL, "kd_gemm_f32: unpatch needs N == ph*pw*chan, gh, gw (and R when sigma is given)");
   if (d.norm && d.rows_per_sample <= 0) return fail(KD_EINVAL, "kd_gemm_f32: rows_per_sample");
+  if (d.epi == KD_EPI_QKV && (d.n_heads <= 0 || d.N != 3 * d.n_heads * 64 || d.rows_per_sample <= 0 || !d.qk_scale || !d.rope_cos || !d.rope_sin))
+    return fail(KD_EINVAL, "kd_gemm_f32: qkv epilogue needs N == 3*n_heads*64, rows_per_sample, qk_scale, rope_cos, rope_sin");
   KdGemm e = d;
   if (e.rows_per_sample <= 0) e.rows_per_sample = e.M;
   // all rows of a 128-row tile share their scale vector: stage it in LDS once per tile
@@ -549,6 +559,8 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
   KD_CASE(KD_A_PLAIN, true, KD_EPI_STORE)
   KD_CASE(KD_A_PLAIN, false, KD_EPI_STORE)
   KD_CASE(KD_A_PLAIN, false, KD_EPI_RESIDUAL)
+  KD_CASE(KD_A_PLAIN, true, KD_EPI_QKV)
+  KD_CASE(KD_A_PLAIN, false, KD_EPI_QKV)
   KD_CASE(KD_A_PLAIN, true, KD_EPI_GEGLU)
   KD_CASE(KD_A_PLAIN, false, KD_EPI_GEGLU)
   KD_CASE(KD_A_MERGE2x2, false, KD_EPI_STORE)

@@ -78,6 +78,25 @@ __device__ __forceinline__ float erf_fast(float a) {
 }
 __device__ __forceinline__ float gelu_erf_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
+constexpr int KD_ROT = 16;       // rotary angles per head: dims [0,16) pair with [16,32)
+// ---- q/k row preparation, 16 lanes per 64-float row: lane c = lane & 15 owns dims [4c, 4c+4) -------
+// scale_for_cosine_sim (image_transformer_v2.py:106-114) then _apply_rotary_emb_inplace (:187-199).
+__device__ __forceinline__ f32x4 prep_row16(f32x4 v, int c, float sqrt_scale, const float* cs_row, const float* sn_row, float eps) {
+  float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  ss = wave_sum_xor(ss, 16);
+  const float f = sqrt_scale * rsqrtf(ss + eps);
+  v = v * f;
+  f32x4 o;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) o[u] = __shfl_xor(v[u], 4, 64);
+  if (c < 8) {
+    const f32x4 cs = *reinterpret_cast<const f32x4*>(cs_row + 4 * (c & 3));
+    const f32x4 sn = *reinterpret_cast<const f32x4*>(sn_row + 4 * (c & 3));
+    v = (c < 4) ? (v * cs - o * sn) : (v * cs + o * sn);
+  }
+  return v;
+}
+
 // 32x32 MFMA C/D fragment: element `reg` of lane `lane` is C[row][col]
 __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 

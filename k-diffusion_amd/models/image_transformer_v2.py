@@ -184,7 +184,7 @@ class _Plan:
         self.xs = xs
 
         def gemm(what, A, Wt, Cc, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, scale_ptr=None, scale_stride=0,
-                 rows_per_sample=0, R=None, grid=(0, 0), patch=(0, 0, 0), out_add=0.0, sigma=None, fac=None):
+                 rows_per_sample=0, R=None, grid=(0, 0), patch=(0, 0, 0), out_add=0.0, sigma=None, fac=None, qk=None):
             d = nat.KdGemm()
             d.M, d.N, d.K, d.a_mode, d.epi = M, N, K, a_mode, epi
             d.precision = precision
@@ -201,6 +201,8 @@ class _Plan:
             d.scale = scale_ptr
             d.sigma = None if sigma is None else sigma.data_ptr()
             d.fac = None if fac is None else fac.data_ptr()
+            if qk is not None:
+                d.qk_scale, d.rope_cos, d.rope_sin, d.n_heads = qk[0].data_ptr(), qk[1].data_ptr(), qk[2].data_ptr(), qk[3]
             self.keep.append(d)
             self.launches.append(_Launch(lib.kd_gemm_f32, (C.byref(d),), what))
             return d
@@ -256,11 +258,14 @@ class _Plan:
             if hasattr(mod, "self_attn"):
                 sa, spec = mod.self_attn, lv.self_attn
                 nh = d // spec.d_head
-                gemm(prefix + "qkv_proj", x, sa.qkv_proj.weight, qkv, T, 3 * d, d, scale_ptr=scale_ptr(prefix + "self_attn.norm"),
-                     scale_stride=total, rows_per_sample=rps)
                 cos_t, sin_t = m._rope_tables(li, grids, sa, device)
                 self.keep += [cos_t, sin_t]
-                prep = (1, _ptr(sa.scale), _ptr(cos_t), _ptr(sin_t), C.c_float(1e-6))
+                # q, k leave the qkv GEMM already prepared (cosine-sim scale + RoPE in its epilogue): every halo /
+                # window / key tile of the attention cores would otherwise redo that work per use
+                gemm(prefix + "qkv_proj", x, sa.qkv_proj.weight, qkv, T, 3 * d, d, epi=nat.EPI_QKV,
+                     scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps,
+                     qk=(sa.scale, cos_t, sin_t, nh))
+                prep = (0, None, None, None, C.c_float(1e-6))
                 if isinstance(spec, GlobalAttentionSpec):
                     call(prefix + "attn_global", lib.kd_attn_global_f32, _ptr(qkv), _ptr(att), B, gh * gw, nh, *prep)
                 elif isinstance(spec, NeighborhoodAttentionSpec):

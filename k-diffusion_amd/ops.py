@@ -61,7 +61,7 @@ def pack_weight(W, N, K, geglu, cache=True):
 
 def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scale=None, scale_stride=0,
          rows_per_sample=0, residual=None, grid=(0, 0), patch=(0, 0, 0), eps=1e-6, out_add=0.0,
-         sigma=None, sigma_data=1.0, fac=None, scale_ptr=None, precision=None):
+         sigma=None, sigma_data=1.0, fac=None, scale_ptr=None, precision=None, qk=None):
     """Fused GEMM (see KdGemm in include/kdiff_hip.h).  ``norm_scale`` may be a tensor or, with
     ``scale_ptr``, a raw device address inside a larger scale table.  ``precision``: nat.PREC_EXACT /
     nat.PREC_SPLIT3 (default: KDIFF_GEMM env, split3)."""
@@ -82,6 +82,9 @@ def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scal
     d.scale = scale_ptr if scale_ptr is not None else (None if norm_scale is None else _chk(norm_scale, "scale").data_ptr())
     d.sigma = None if sigma is None else _chk(sigma, "sigma").data_ptr()
     d.fac = None if fac is None else _chk(fac, "fac").data_ptr()
+    if qk is not None:          # EPI_QKV: (scale_h [nh], cos [T, nh, 16], sin [T, nh, 16], nh)
+        d.qk_scale, d.rope_cos, d.rope_sin = (_chk(t, n).data_ptr() for t, n in zip(qk[:3], ("qk_scale", "cos", "sin")))
+        d.n_heads = qk[3]
     nat.check(nat.lib().kd_gemm_f32(C.byref(d), _stream()), "kd_gemm_f32")
     return out
 
@@ -114,15 +117,17 @@ def rms_norm(x, scale, eps=1e-6, out=None):
     return out
 
 
-def norm_linear(x, scale, weight, *, rows_per_sample, epi=nat.EPI_STORE, out=None, eps=1e-6):
+def norm_linear(x, scale, weight, *, rows_per_sample, epi=nat.EPI_STORE, out=None, eps=1e-6, qk=None):
     """AdaRMSNorm/RMSNorm (:155-166) fused into the following Linear / LinearGEGLU.
-    ``scale``: [B, K] per-sample scales (AdaRMSNorm: Linear(cond) + 1) or [K] shared gain."""
+    ``scale``: [B, K] per-sample scales (AdaRMSNorm: Linear(cond) + 1) or [K] shared gain.
+    ``epi=EPI_QKV`` with ``qk=(scale_h, cos, sin, nh)``: qkv projection whose q, k come out prepared
+    (scale_for_cosine_sim + apply_rotary_emb_, :106-121, :187-231), ready for the attention cores with prep=None."""
     K = x.shape[-1]
     M = x.numel() // K
     Nn = weight.shape[0] // (2 if epi == nat.EPI_GEGLU else 1)
     out = torch.empty(*x.shape[:-1], Nn, device=x.device, dtype=x.dtype) if out is None else out
     return gemm(x, weight, out, M=M, N=Nn, K=K, epi=epi, norm_scale=scale, scale_stride=K if scale.dim() == 2 else 0,
-                rows_per_sample=rows_per_sample, eps=eps)
+                rows_per_sample=rows_per_sample, eps=eps, qk=qk)
 
 
 def token_merge(x, weight, out=None):

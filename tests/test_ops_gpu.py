@@ -87,6 +87,26 @@ def test_norm_linear_and_geglu(ops, gtol, golden):
     assert relerr(y, o["rms_norm.y"] @ w.T) < gtol
 
 
+def test_qkv_epilogue_prepares_q_and_k(ops, gtol):
+    """AdaRMSNorm -> qkv projection -> [cosine-sim scale + axial RoPE on q, k] in ONE GEMM (EPI_QKV), against the
+    oracle's separate steps (image_transformer_v2.py:370-392 up to the attention call)."""
+    B, H, W, nh = 2, 16, 8, 2
+    d = nh * 64
+    x, scale = rn(B, H, W, d, seed=1), 1 + 0.1 * rn(B, d, seed=2)
+    w = rn(3 * d, d, seed=3) / d ** 0.5
+    sh = torch.tensor([9.0, 12.5])
+    cos, sin = _tables(H, W, nh)
+    y = ops.norm_linear(g(x), g(scale), g(w), rows_per_sample=H * W, epi=5, qk=(g(sh), g(cos), g(sin), nh))
+    qkv = hdit.rms_norm(x, scale[:, None, None, :]) @ w.T
+    q, k, v = hdit.split_qkv(qkv, nh)
+    q, k = hdit.cosine_sim_scale(q, k, sh)
+    theta = hdit.rope_theta(hdit.axial_pos(H, W), hdit.rope_freqs(nh))
+    ref = torch.stack([hdit.apply_rope(q, theta), hdit.apply_rope(k, theta), v], dim=3).reshape(B, H, W, 3 * d)
+    assert relerr(y, ref) < gtol
+    with pytest.raises(RuntimeError, match="qkv epilogue"):
+        ops.norm_linear(g(x), g(scale), g(w[: 2 * d]), rows_per_sample=H * W, epi=5, qk=(g(sh), g(cos), g(sin), nh))
+
+
 def test_token_merge_split(ops, gtol, golden):
     o = golden["ops"]
     x = o["rms_norm.x"]
@@ -157,7 +177,7 @@ def test_attention_vs_reference_golden(ops, golden, fused):
         assert relerr(y, o[f"attn_window{shift}.o"]) < 2e-5, shift
     ref = hdit.na2d(o["qk.q_out"], o["qk.k_out"], o["qk.v"], 7, 1.0)
     y = ops.attn_na2d(qkv, 2, 7, **kw).view(2, 16, 16, 2, 64)
-    assert relerr(y, ref) < 2e-5
+    assert relerr(y, ref) < 1e-4            # split-bf16x3 MFMA products (K, Q, P, V each hi + lo)
 
 
 def test_window_attention_rect(ops, golden):
@@ -182,7 +202,7 @@ def test_attn_na2d_sizes(ops, H, W, nh, B):
     q, k, v = (rn(B, H, W, nh, 64, seed=s, scale=sc) for s, sc in ((1, 0.5), (2, 0.5), (3, 1.0)))
     ref = hdit.na2d(q, k, v, 7, 1.0)
     y = ops.attn_na2d(g(_pack(q, k, v)), nh, 7).view(B, H, W, nh, 64)
-    assert relerr(y, ref) < 2e-5
+    assert relerr(y, ref) < 1e-4
     # fused preparation path against oracle-prepared q, k
     scale = torch.linspace(5.0, 12.0, nh)
     cos, sin = _tables(H, W, nh)
@@ -190,7 +210,7 @@ def test_attn_na2d_sizes(ops, H, W, nh, B):
     qs, ks = hdit.cosine_sim_scale(q, k, scale)
     ref = hdit.na2d(hdit.apply_rope(qs, theta), hdit.apply_rope(ks, theta), v, 7, 1.0)
     y = ops.attn_na2d(g(_pack(q, k, v)), nh, 7, prep=(g(scale), g(cos), g(sin))).view(B, H, W, nh, 64)
-    assert relerr(y, ref) < 2e-5
+    assert relerr(y, ref) < 1e-4
     if H == 7:
         with pytest.raises(RuntimeError, match="smaller"):
             ops.attn_na2d(g(_pack(q, k, v))[:, :6].contiguous(), nh, 7)
