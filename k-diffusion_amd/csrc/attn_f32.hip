@@ -412,19 +412,25 @@ __global__ __launch_bounds__(128) void attn_na2d_kernel(const NaArgs a) {
   // ---- S^T = K Q^T over the wave's 5 key tiles ----------------------------------------------------------------------
   f32x16 S[NA_KT];
 #pragma unroll
-  for (int t = 0; t < NA_KT; ++t) {
+  for (int t = 0; t < NA_KT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
-    const int row = kbase + t * 32 + l31;
+  // step-major, term-major: consecutive MFMAs go to different key tiles (no back-to-back chain on one accumulator)
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      const int o = na_kswz(row, 2 * st + h2);
-      const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Khi + o);
-      const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Klo + o);
-      S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[st], S[t], 0, 0, 0);
-      S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[st], S[t], 0, 0, 0);
-      S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[st], S[t], 0, 0, 0);
+  for (int st = 0; st < 4; ++st) {
+    bf16x8 kh[NA_KT], kl[NA_KT];
+#pragma unroll
+    for (int t = 0; t < NA_KT; ++t) {
+      const int o = na_kswz(kbase + t * 32 + l31, 2 * st + h2);
+      kh[t] = *reinterpret_cast<const bf16x8*>(Khi + o);
+      kl[t] = *reinterpret_cast<const bf16x8*>(Klo + o);
     }
+#pragma unroll
+    for (int t = 0; t < NA_KT; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[t], qh[st], S[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NA_KT; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[t], ql[st], S[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NA_KT; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[t], qh[st], S[t], 0, 0, 0);
   }
 
   // ---- V halo prefetch (requested now, consumed after the softmax) ---------------------------------------------------------------
@@ -506,34 +512,48 @@ __global__ __launch_bounds__(128) void attn_na2d_kernel(const NaArgs a) {
   __syncthreads();
 
   // ---- O^T = V^T P^T ------------------------------------------------------------------------------------------------------
-  f32x16 O[2];
+  // four accumulators (head-dim half e x key-chunk parity u, summed at the end), issued term-major so that no MFMA
+  // follows another on the same accumulator
+  f32x16 O[2][2];
 #pragma unroll
   for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) O[e][i] = 0.f;
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) O[e][u][i] = 0.f;
 #pragma unroll
   for (int t = 0; t < NA_KT; ++t) {
+    bf16x8 ph[2], pl[2], vh[2][2], vl[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       // B operand: this lane's 8 probabilities of k-slots (regs 8u..8u+7 = keys 16u+4h2+{0..3} and 16u+8+4h2+{0..3})
       u32x2 ph0, pl0, ph1, pl1;
       split4_bf16(f32x4{S[t][8 * u], S[t][8 * u + 1], S[t][8 * u + 2], S[t][8 * u + 3]}, ph0, pl0);
       split4_bf16(f32x4{S[t][8 * u + 4], S[t][8 * u + 5], S[t][8 * u + 6], S[t][8 * u + 7]}, ph1, pl1);
-      const bf16x8 ph = __builtin_bit_cast(bf16x8, u32x4{ph0[0], ph0[1], ph1[0], ph1[1]});
-      const bf16x8 pl = __builtin_bit_cast(bf16x8, u32x4{pl0[0], pl0[1], pl1[0], pl1[1]});
+      ph[u] = __builtin_bit_cast(bf16x8, u32x4{ph0[0], ph0[1], ph1[0], ph1[1]});
+      pl[u] = __builtin_bit_cast(bf16x8, u32x4{pl0[0], pl0[1], pl1[0], pl1[1]});
       const int key0 = kbase + t * 32 + 16 * u + 4 * h2;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int o = (32 * e + l31) * NA_VT_STRIDE + key0 * 2;
         const u32x2 vh0 = *reinterpret_cast<const u32x2*>(Vhi + o), vh1 = *reinterpret_cast<const u32x2*>(Vhi + o + 16);
         const u32x2 vl0 = *reinterpret_cast<const u32x2*>(Vlo + o), vl1 = *reinterpret_cast<const u32x2*>(Vlo + o + 16);
-        const bf16x8 vh = __builtin_bit_cast(bf16x8, u32x4{vh0[0], vh0[1], vh1[0], vh1[1]});
-        const bf16x8 vl = __builtin_bit_cast(bf16x8, u32x4{vl0[0], vl0[1], vl1[0], vl1[1]});
-        O[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, O[e], 0, 0, 0);
-        O[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, O[e], 0, 0, 0);
-        O[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, O[e], 0, 0, 0);
+        vh[e][u] = __builtin_bit_cast(bf16x8, u32x4{vh0[0], vh0[1], vh1[0], vh1[1]});
+        vl[e][u] = __builtin_bit_cast(bf16x8, u32x4{vl0[0], vl0[1], vl1[0], vl1[1]});
       }
     }
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) O[e][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[e][u], ph[u], O[e][u], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) O[e][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[e][u], pl[u], O[e][u], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) O[e][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[e][u], ph[u], O[e][u], 0, 0, 0);
   }
 
   if (q_ok) {
@@ -543,7 +563,9 @@ __global__ __launch_bounds__(128) void attn_na2d_kernel(const NaArgs a) {
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        f32x4 v = {O[e][4 * g] * inv, O[e][4 * g + 1] * inv, O[e][4 * g + 2] * inv, O[e][4 * g + 3] * inv};
+        f32x4 v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (O[e][0][4 * g + u] + O[e][1][4 * g + u]) * inv;
         *reinterpret_cast<f32x4*>(op + e * 32 + 8 * g + 4 * h2) = v;
       }
   }

@@ -252,14 +252,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KdGemm p) {
           bh[i] = *reinterpret_cast<const bf16x8*>(st + 2 * IMG + bo);
           bl[i] = *reinterpret_cast<const bf16x8*>(st + 3 * IMG + bo);
         }
+        // term-major order: consecutive MFMAs hit DIFFERENT accumulators (a back-to-back chain on one accumulator
+        // stalls on its own result; with four in rotation each is revisited after three other issues)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          }
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
       }
     } else {
       const float* a_base = As + (buf * BM + wr * 64) * S + frag_off;
