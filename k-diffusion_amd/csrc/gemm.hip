@@ -29,6 +29,7 @@
 //   epilogue : store(+const) | + residual | GEGLU | 2x2 token split + lerp(skip) |
 //              NCHW un-patch * c_out + x * c_skip
 #include "kd_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace kd {
@@ -533,6 +534,8 @@ static int launch(const KdGemm& d, hipStream_t s) {
 
 }  // namespace kd
 
+namespace kd { int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc); }   // gemm_astat.hip
+
 using namespace kd;
 
 extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
@@ -557,6 +560,11 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
   // all rows of a 128-row tile share their scale vector: stage it in LDS once per tile
   e.scale_tab = e.norm && e.a_mode == KD_A_PLAIN && e.K <= SCALE_TAB_MAX_K && (e.scale_stride == 0 || e.rows_per_sample % BM == 0);
 
+  {
+    static const bool astat_on = !(getenv("KDIFF_ASTAT") && getenv("KDIFF_ASTAT")[0] == '0');
+    int rc = 0;
+    if (astat_on && !gemm_astat_try(e, s, &rc)) return rc;     // wide K <= 256 projections: A-stationary kernel
+  }
   if (e.precision != KD_PREC_EXACT && e.precision != KD_PREC_SPLIT3) return fail(KD_EINVAL, "kd_gemm_f32: unknown precision %d", e.precision);
   if (e.precision == KD_PREC_SPLIT3 && !e.Wp) return fail(KD_EINVAL, "kd_gemm_f32: split3 needs the packed weight image Wp (kd_pack_weight_bf16x3)");
 #define KD_CASE(AM, NO, EP)                                             \

@@ -1,0 +1,242 @@
+// "A-stationary" split-bf16x3 GEMM for the wide projections of the HDiT levels with K <= 256
+// (AdaRMSNorm -> qkv, AdaRMSNorm -> up-projection + GEGLU):  C = epilogue( norm(A) @ W^T ).
+//
+// Why a second GEMM kernel.  In the tiled kernel (gemm.hip) every 128x128 output tile re-reads, re-normalises and
+// re-splits its A panel: with N = 3..6 x the tile width that is 3..6 x the VALU work, LDS writes and L2->LDS traffic
+// of A, and at K = 128..256 the kernel is VALU/LDS bound at ~20-30 % MFMA utilisation (profiles/r01_gemm_pmc.md).
+// Here a workgroup owns a 128-row panel for ALL of N:
+//   * each of its 4 wave64s keeps its 32 rows of the normalised, scaled, bf16-split A panel IN REGISTERS as MFMA
+//     A-operand fragments (K/16 chunks x (hi + lo) x 4 VGPRs: 64 VGPRs at K = 128, 128 at K = 256): A is read
+//     from HBM exactly once and converted once;
+//   * W streams through a 4-stage LDS ring as the packed, pre-swizzled bf16 image of kd_pack_weight_bf16x3
+//     (16 KiB per (n-tile, 32-wide K-step)), moved by global_load_lds (no VGPRs, no ds_write pass), requested
+//     three stages ahead with counted s_waitcnt vmcnt so the ring never drains;
+//   * per n-tile the 32x128 accumulator block of a wave goes through the same wave-private transposing LDS strips
+//     as in gemm.hip (float4 row-segment stores; q/k preparation or GEGLU in the epilogue) while the next n-tile's
+//     W stages are already in flight.
+// vmcnt bookkeeping: on gfx9-class hardware stores share the vector-memory counter with loads, and a counted wait
+// behind the epilogue's stores would drain them.  The stages needed right after an epilogue are therefore confirmed
+// BEFORE it (they were requested 2-3 stages earlier), and the first wait that can see the stores comes two stages
+// later, when they have long been written.
+#include "kd_common.h"
+
+namespace kd {
+
+namespace astat {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr int BM = 128;                 // rows per workgroup (4 waves x 32)
+constexpr int BK = 32;                  // K per W stage
+constexpr int IMG = 128 * BK * 2;       // one bf16 image of a stage: [128 W rows][32 k] = 8 KiB
+constexpr int STAGE = 2 * IMG;          // hi + lo = 16 KiB  (== WP_BLOCK of gemm.hip)
+constexpr int NSTG = 4;                 // ring depth
+constexpr int LDS_RING = NSTG * STAGE;  // 64 KiB
+constexpr int LDS_BYTES = LDS_RING + 4 * 8 * 64 * 4 + BM * 4;   // + epilogue strips + row rsqrt table
+
+__device__ __forceinline__ int swz(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+  bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+  hi[0] = pack_bf16(v[0], v[1]);
+  hi[1] = pack_bf16(v[2], v[3]);
+  lo[0] = pack_bf16(v[0] - __uint_as_float(hi[0] << 16), v[1] - __uint_as_float(hi[0] & 0xFFFF0000u));
+  lo[1] = pack_bf16(v[2] - __uint_as_float(hi[1] << 16), v[3] - __uint_as_float(hi[1] & 0xFFFF0000u));
+}
+
+#define KD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define KD_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+// NC = K / 16 (8 or 16); EPI: KD_EPI_STORE / KD_EPI_QKV / KD_EPI_GEGLU
+template <int NC, int EPI>
+__global__ __launch_bounds__(256, NC == 8 ? 2 : 1) void gemm_astat_kernel(const KdGemm p) {
+  constexpr int K = NC * 16, NK = NC / 2;                 // NK: W stages per n-tile (multiple of NSTG)
+  constexpr bool GEGLU = EPI == KD_EPI_GEGLU;
+  constexpr int NCOL = GEGLU ? 64 : 128;                  // output columns per n-tile
+  static_assert(NK % NSTG == 0, "ring slot of a stage must be a compile-time constant");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;
+  float* strips = reinterpret_cast<float*>(smem + LDS_RING);
+  float* rs_tab = strips + 4 * 8 * 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int M = p.M, N = p.N;
+  const int n_tiles = N / NCOL;
+  const int total = n_tiles * NK;                         // W stages of this panel
+  const int m0 = blockIdx.x * BM;
+
+  // ---- W stage s -> ring slot s % NSTG (this wave's quarter: 4 x 1 KiB, lands at slot + wid*4 KiB + lane*16) ----------
+  const char* wp = reinterpret_cast<const char*>(p.Wp);
+  auto issue = [&](int s) {
+    const char* src = wp + (size_t)s * STAGE + wid * 4096 + lane * 16;
+    char* dst = ring + (s % NSTG) * STAGE + wid * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+  };
+  issue(0);
+  issue(1);
+  issue(2);
+
+  // ---- this wave's 32 rows of A -> normalise, scale, split -> MFMA A fragments in registers ---------------------------
+  // lane (row l31, half lh) holds k = 16c + 8lh .. +8 of chunk c
+  bf16x8 ah[NC], al[NC];
+  {
+    const int row = m0 + wid * 32 + l31;
+    const bool ok = row < M;
+    const float* ap = p.A + (long)(ok ? row : M - 1) * K + 8 * lh;
+    const float* sp = p.scale + (long)(m0 / p.rows_per_sample) * p.scale_stride + 8 * lh;
+    float ssq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      f32x4 x0 = *reinterpret_cast<const f32x4*>(ap + 16 * c), x1 = *reinterpret_cast<const f32x4*>(ap + 16 * c + 4);
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp + 16 * c), s1 = *reinterpret_cast<const f32x4*>(sp + 16 * c + 4);
+      if (!ok) { x0 = f32x4{0.f, 0.f, 0.f, 0.f}; x1 = x0; }
+      ssq += x0[0] * x0[0] + x0[1] * x0[1] + x0[2] * x0[2] + x0[3] * x0[3] + x1[0] * x1[0] + x1[1] * x1[1] + x1[2] * x1[2] + x1[3] * x1[3];
+      u32x2 h0, l0, h1, l1;
+      split4(x0 * s0, h0, l0);
+      split4(x1 * s1, h1, l1);
+      ah[c] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+      al[c] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+    }
+    ssq += __shfl_xor(ssq, 32, 64);
+    if (lh == 0) rs_tab[wid * 32 + l31] = rsqrtf(ssq / (float)K + p.eps);
+  }
+  __syncthreads();       // rs_tab visible (also drains this wave's first W stages: they are needed next anyway)
+  float rsv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rsv[r] = rs_tab[wid * 32 + mfma32_row(r, lane)];
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  float* strip = strips + wid * (8 * 64);
+
+  // ---- epilogue of n-tile nt: acc (32 rows x 128 W-rows) -> strips -> global ------------------------------------------------
+  auto epilogue = [&](int nt) {
+    const int n0 = nt * NCOL;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row_base = m0 + wid * 32 + 8 * g;
+#pragma unroll
+      for (int half = 0; half < (GEGLU ? 1 : 2); ++half) {
+        // registers of rows 8g..8g+7 -> strip[8][64]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 4 * g + q, row8 = q + 4 * lh;
+          if (GEGLU) {
+            strip[row8 * 64 + l31] = (acc[0][r] * rsv[r]) * gelu_erf_fast(acc[1][r] * rsv[r]);
+            strip[row8 * 64 + 32 + l31] = (acc[2][r] * rsv[r]) * gelu_erf_fast(acc[3][r] * rsv[r]);
+          } else {
+            strip[row8 * 64 + l31] = acc[2 * half][r] * rsv[r];
+            strip[row8 * 64 + 32 + l31] = acc[2 * half + 1][r] * rsv[r];
+          }
+        }
+        // strip -> global: lane owns (row8, 4 columns), 2 items per lane
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int idx = lane + 64 * t, row8 = idx >> 4, c4 = (idx & 15) * 4;
+          const int gm = row_base + row8, gn = n0 + half * 64 + c4;
+          const int gmc = min(gm, M - 1);
+          f32x4 v = *reinterpret_cast<const f32x4*>(strip + row8 * 64 + c4);
+          if (EPI == KD_EPI_QKV) {
+            // these 64 columns are ONE (q|k|v, head) vector of the row; 16 lanes hold it (4 dims each)
+            const int vec = (n0 + half * 64) >> 6, which = vec / p.n_heads, head = vec - which * p.n_heads;
+            if (which < 2) {
+              const long tr = ((long)(gmc % p.rows_per_sample) * p.n_heads + head) * KD_ROT;
+              v = prep_row16(v, lane & 15, sqrtf(p.qk_scale[head]), p.rope_cos + tr, p.rope_sin + tr, p.eps);
+            }
+          }
+          if (EPI == KD_EPI_STORE) v = v + p.out_add;
+          if (gm < M) *reinterpret_cast<f32x4*>(p.C + (long)gm * N + gn) = v;
+        }
+      }
+    }
+  };
+
+  // ---- main loop over n-tiles; the K-steps of a tile are unrolled so that A fragments have static register names ----------
+  for (int nt = 0; nt < n_tiles; ++nt) {
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const int s = nt * NK + ks;
+      // Stage s has landed?  Stages ks = 0, 1 of every tile but the first were confirmed before the previous epilogue.
+      if (nt == 0 || ks >= 2) {
+        if (s + 2 < total) KD_WAIT_VM(8); else if (s + 1 < total) KD_WAIT_VM(4); else KD_WAIT_VM(0);
+      }
+      KD_BARRIER();                      // every wave's quarter of stage s is in; everyone is done reading slot (s-1) % NSTG
+      if (s + 3 < total) issue(s + 3);   // refill the slot freed by stage s-1
+      const char* st = ring + (ks % NSTG) * STAGE;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = 2 * ks + h;
+        const int o = swz(l31, 2 * h + lh);
+        bf16x8 bh[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bh[j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 64 + o);
+          bl[j] = *reinterpret_cast<const bf16x8*>(st + IMG + j * 32 * 64 + o);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[c], bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c], bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c], bh[j], acc[j], 0, 0, 0);
+      }
+    }
+    // stages (nt+1, ks = 0, 1) were requested >= 2 stages ago: confirm them now, before the stores of this epilogue
+    // enter the vector-memory queue (outstanding after the last issue: stages s+1, s+2, s+3 -> leave only s+3)
+    if (nt + 1 < n_tiles) KD_WAIT_VM(4);
+    epilogue(nt);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  }
+}
+
+template <int NC, int EPI>
+static int launch(const KdGemm& d, hipStream_t s) {
+  auto kern = gemm_astat_kernel<NC, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  const double n_eff = (EPI == KD_EPI_GEGLU) ? 2.0 * d.N : (double)d.N;
+  char nm[96] = "gemm_astat";
+  if (prof_on()) snprintf(nm, sizeof(nm), "gemm_astat<e%d> M=%d N=%d K=%d", EPI, d.M, d.N, d.K);
+  LaunchScope prof(nm, 2.0 * d.M * n_eff * d.K, 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N), s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((d.M + BM - 1) / BM)), dim3(256), LDS_BYTES, s, d);
+  return check_launch("kd_gemm_f32(astat)");
+}
+
+}  // namespace astat
+
+// Eligibility + dispatch (called by kd_gemm_f32).  Returns 1 if the descriptor was not taken.
+int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
+  using namespace astat;
+  if (d.precision != KD_PREC_SPLIT3 || d.a_mode != KD_A_PLAIN || !d.norm || !d.Wp || d.debug) return 1;
+  if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_QKV && d.epi != KD_EPI_GEGLU) return 1;
+  if (d.K != 128 && d.K != 256) return 1;
+  const int ncol = d.epi == KD_EPI_GEGLU ? 64 : 128;
+  if (d.N % ncol || d.N / ncol < 2) return 1;                                   // one n-tile: nothing to amortise
+  if (!(d.scale_stride == 0 || d.rows_per_sample % BM == 0)) return 1;          // one scale vector per panel
+  if (d.M < 4 * BM) return 1;
+#define KD_AS(NCV, EP) if (d.K == NCV * 16 && d.epi == EP) { *rc = launch<NCV, EP>(d, s); return 0; }
+  KD_AS(8, KD_EPI_STORE) KD_AS(8, KD_EPI_QKV) KD_AS(8, KD_EPI_GEGLU)
+  KD_AS(16, KD_EPI_STORE) KD_AS(16, KD_EPI_QKV) KD_AS(16, KD_EPI_GEGLU)
+#undef KD_AS
+  return 1;
+}
+
+}  // namespace kd
