@@ -38,7 +38,7 @@ def gemm_cases(B):
     out = []
     for lv in range(3):
         M, w = T[lv], d[lv]
-        out += [(f"L{lv} qkv  norm", M, 3 * w, w, "norm"), (f"L{lv} out  +res", M, w, w, "res"),
+        out += [(f"L{lv} qkv  norm", M, 3 * w, w, "norm"), (f"L{lv} qkv  norm+prep", M, 3 * w, w, "qkv"), (f"L{lv} out  +res", M, w, w, "res"),
                 (f"L{lv} up   norm+geglu", M, 3 * w, w, "geglu"), (f"L{lv} down +res", M, w, 3 * w, "res")]
     return out
 
@@ -53,6 +53,17 @@ def run_gemm(args, res):
             out = torch.empty(M, N, device=DEV)
             fn = lambda: ops.norm_linear(x, scale, w, rows_per_sample=M // B, epi=nat.EPI_GEGLU, out=out)
             n_eff = 2 * N
+        elif kind == "qkv":
+            from oracle import hdit
+            nh, T = Kd // 64, M // B
+            h = int(T ** 0.5)
+            theta = hdit.rope_theta(hdit.axial_pos(h, h), hdit.rope_freqs(nh)).reshape(T, nh, 16)
+            qk = (10.0 * torch.ones(nh, device=DEV), torch.cos(theta).to(DEV).contiguous(), torch.sin(theta).to(DEV).contiguous(), nh)
+            w = torch.randn(N, Kd, device=DEV) / Kd ** 0.5
+            scale = 1 + 0.1 * torch.randn(B, Kd, device=DEV)
+            out = torch.empty(M, N, device=DEV)
+            fn = lambda: ops.norm_linear(x, scale, w, rows_per_sample=T, epi=nat.EPI_QKV, out=out, qk=qk)
+            n_eff = N
         elif kind == "norm":
             w = torch.randn(N, Kd, device=DEV) / Kd ** 0.5
             scale = 1 + 0.1 * torch.randn(B, Kd, device=DEV)

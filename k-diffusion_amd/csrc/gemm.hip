@@ -336,6 +336,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KdGemm p) {
   const bool vec_ok = (N & 3) == 0 &&
                       (EPI != KD_EPI_SPLIT_LERP || (N & 15) == 0) &&
                       (EPI != KD_EPI_UNPATCH_NCHW || (p.pw == 4 && N <= 64 && (p.gw & 7) == 0));
+  const int qk_vec = wn0 >> 6, qk_which = EPI == KD_EPI_QKV ? qk_vec / p.n_heads : 2, qk_head = EPI == KD_EPI_QKV ? qk_vec - qk_which * p.n_heads : 0;
+  const float qk_sqrt = (EPI == KD_EPI_QKV && qk_which < 2) ? sqrtf(p.qk_scale[qk_head]) : 1.0f;
   if (vec_ok) {
     float c_out[2] = {1.f, 1.f}, c_skip[2] = {0.f, 0.f};        // unpatch: Karras scalings of this lane's two samples
 #pragma unroll
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KdGemm p) {
         }
         // ---- strip -> global: lane owns (row8, 4 columns) ---------------------------------------------
         constexpr int PER_LANE = NW / 32;                       // float4 items per lane (8 rows * NW/4 items / 64 lanes)
-        f32x4 v[PER_LANE], rv[PER_LANE];
+        f32x4 v[PER_LANE], rv[PER_LANE], qcs[PER_LANE], qsn[PER_LANE];
         long off[PER_LANE];
         bool ok[PER_LANE];
 #pragma unroll
@@ -404,14 +406,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KdGemm p) {
             off[t] = (long)gmc * N + gnc;
           }
           if (EPI == KD_EPI_RESIDUAL || EPI == KD_EPI_SPLIT_LERP) rv[t] = *reinterpret_cast<const f32x4*>(p.R + off[t]);
-          if (EPI == KD_EPI_QKV) {
-            // this wave's 64 columns are ONE (q|k|v, head) vector of the row; 16 lanes hold it (4 dims each)
-            const int vec = wn0 >> 6, which = vec / p.n_heads, head = vec - which * p.n_heads;
-            if (which < 2) {
-              const long tr = ((long)(gmc % p.rows_per_sample) * p.n_heads + head) * KD_ROT;
-              v[t] = prep_row16(v[t], lane & 15, sqrtf(p.qk_scale[head]), p.rope_cos + tr, p.rope_sin + tr, p.eps);
-            }
+          if (EPI == KD_EPI_QKV && qk_which < 2) {
+            // this wave's 64 columns are ONE (q|k|v, head) vector of the row; 16 lanes hold it (4 dims each).
+            // RoPE chunks requested branch-free for both items before either is used.
+            const long tr = ((long)(gmc % p.rows_per_sample) * p.n_heads + qk_head) * KD_ROT + 4 * (lane & 3);
+            qcs[t] = *reinterpret_cast<const f32x4*>(p.rope_cos + tr);
+            qsn[t] = *reinterpret_cast<const f32x4*>(p.rope_sin + tr);
           }
+        }
+        if (EPI == KD_EPI_QKV && qk_which < 2) {
+#pragma unroll
+          for (int t = 0; t < PER_LANE; ++t) v[t] = prep_row16_regs(v[t], lane & 15, qk_sqrt, qcs[t], qsn[t], p.eps);
         }
 #pragma unroll
         for (int t = 0; t < PER_LANE; ++t) {

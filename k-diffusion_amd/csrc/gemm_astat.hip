@@ -34,7 +34,7 @@ constexpr int IMG = 128 * BK * 2;       // one bf16 image of a stage: [128 W row
 constexpr int STAGE = 2 * IMG;          // hi + lo = 16 KiB  (== WP_BLOCK of gemm.hip)
 constexpr int NSTG = 4;                 // ring depth
 constexpr int LDS_RING = NSTG * STAGE;  // 64 KiB
-constexpr int LDS_BYTES = LDS_RING + 4 * 8 * 64 * 4 + BM * 4;   // + epilogue strips + row rsqrt table
+constexpr int LDS_BYTES = LDS_RING + 4 * 8 * 64 * 4 + BM * 4 + 64;   // + epilogue strips + row rsqrt table + sqrt(qk scale) per head (<= 16)
 
 __device__ __forceinline__ int swz(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256, NC == 8 ? 2 : 1) void gemm_astat_kernel(const 
   char* ring = smem;
   float* strips = reinterpret_cast<float*>(smem + LDS_RING);
   float* rs_tab = strips + 4 * 8 * 64;
+  float* sq_tab = rs_tab + BM;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int M = p.M, N = p.N;
@@ -107,7 +108,9 @@ __global__ __launch_bounds__(256, NC == 8 ? 2 : 1) void gemm_astat_kernel(const 
     }
     ssq += __shfl_xor(ssq, 32, 64);
     if (lh == 0) rs_tab[wid * 32 + l31] = rsqrtf(ssq / (float)K + p.eps);
+    if (EPI == KD_EPI_QKV && tid < p.n_heads) sq_tab[tid] = sqrtf(p.qk_scale[tid]);
   }
+  const int tok0 = EPI == KD_EPI_QKV ? (m0 + wid * 32) % p.rows_per_sample : 0;   // token of this wave's first row (panels never straddle samples)
   __syncthreads();       // rs_tab visible (also drains this wave's first W stages: they are needed next anyway)
   float rsv[16];
 #pragma unroll
@@ -142,20 +145,27 @@ __global__ __launch_bounds__(256, NC == 8 ? 2 : 1) void gemm_astat_kernel(const 
           }
         }
         // strip -> global: lane owns (row8, 4 columns), 2 items per lane
+        const int vec = (n0 + half * 64) >> 6;                 // qkv: these 64 columns are ONE (q|k|v, head) vector of a row
+        const int which = EPI == KD_EPI_QKV ? vec / p.n_heads : 2, head = EPI == KD_EPI_QKV ? vec - which * p.n_heads : 0;
+        f32x4 cs[2], sn[2];
+        if (EPI == KD_EPI_QKV && which < 2) {
+          // RoPE table chunks of both items, requested before the strip round trip (branch-free: lanes >= 8 of a
+          // 16-lane row group re-read chunk c & 3, unused)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int row8 = (lane + 64 * t) >> 4;
+            const int tok = min(tok0 + 8 * g + row8, p.rows_per_sample - 1);
+            const long tr = ((long)tok * p.n_heads + head) * KD_ROT + 4 * (lane & 3);
+            cs[t] = *reinterpret_cast<const f32x4*>(p.rope_cos + tr);
+            sn[t] = *reinterpret_cast<const f32x4*>(p.rope_sin + tr);
+          }
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int idx = lane + 64 * t, row8 = idx >> 4, c4 = (idx & 15) * 4;
           const int gm = row_base + row8, gn = n0 + half * 64 + c4;
-          const int gmc = min(gm, M - 1);
           f32x4 v = *reinterpret_cast<const f32x4*>(strip + row8 * 64 + c4);
-          if (EPI == KD_EPI_QKV) {
-            // these 64 columns are ONE (q|k|v, head) vector of the row; 16 lanes hold it (4 dims each)
-            const int vec = (n0 + half * 64) >> 6, which = vec / p.n_heads, head = vec - which * p.n_heads;
-            if (which < 2) {
-              const long tr = ((long)(gmc % p.rows_per_sample) * p.n_heads + head) * KD_ROT;
-              v = prep_row16(v, lane & 15, sqrtf(p.qk_scale[head]), p.rope_cos + tr, p.rope_sin + tr, p.eps);
-            }
-          }
+          if (EPI == KD_EPI_QKV && which < 2) v = prep_row16_regs(v, lane & 15, sq_tab[head], cs[t], sn[t], p.eps);
           if (EPI == KD_EPI_STORE) v = v + p.out_add;
           if (gm < M) *reinterpret_cast<f32x4*>(p.C + (long)gm * N + gn) = v;
         }
@@ -231,6 +241,7 @@ int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
   const int ncol = d.epi == KD_EPI_GEGLU ? 64 : 128;
   if (d.N % ncol || d.N / ncol < 2) return 1;                                   // one n-tile: nothing to amortise
   if (!(d.scale_stride == 0 || d.rows_per_sample % BM == 0)) return 1;          // one scale vector per panel
+  if (d.epi == KD_EPI_QKV && (d.rows_per_sample % BM || d.n_heads > 16)) return 1;
   if (d.M < 4 * BM) return 1;
 #define KD_AS(NCV, EP) if (d.K == NCV * 16 && d.epi == EP) { *rc = launch<NCV, EP>(d, s); return 0; }
   KD_AS(8, KD_EPI_STORE) KD_AS(8, KD_EPI_QKV) KD_AS(8, KD_EPI_GEGLU)

@@ -76,22 +76,39 @@ __device__ __forceinline__ float erf_fast(float a) {
 __device__ __forceinline__ float gelu_erf_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
 constexpr int KD_ROT = 16;       // rotary angles per head: dims [0,16) pair with [16,32)
+// ---- DPP helpers: cross-lane moves inside a 16-lane row as plain VALU ops (no LDS round trip like ds_bpermute) ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_ROR4 = 0x124, DPP_ROR8 = 0x128, DPP_ROR12 = 0x12C;
+// sum over the 16 lanes of a row, result in every lane
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<DPP_ROR8>(v);
+  v += dpp_mov<DPP_ROR4>(v);
+  v += dpp_mov<DPP_XOR2>(v);
+  v += dpp_mov<DPP_XOR1>(v);
+  return v;
+}
+
 // ---- q/k row preparation, 16 lanes per 64-float row: lane c = lane & 15 owns dims [4c, 4c+4) -------
-// scale_for_cosine_sim (image_transformer_v2.py:106-114) then _apply_rotary_emb_inplace (:187-199).
-__device__ __forceinline__ f32x4 prep_row16(f32x4 v, int c, float sqrt_scale, const float* cs_row, const float* sn_row, float eps) {
-  float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-  ss = wave_sum_xor(ss, 16);
+// scale_for_cosine_sim (image_transformer_v2.py:106-114) then _apply_rotary_emb_inplace (:187-199): dims d < 16 pair
+// with d + 16, i.e. lane c < 4 with lane c + 4 (row_ror:12 brings lane c+4's value to lane c, row_ror:4 lane c-4's).
+// cs / sn: this lane's chunk (c & 3) of the row's 16 cos / sin values (lanes c >= 8 ignore them).
+__device__ __forceinline__ f32x4 prep_row16_regs(f32x4 v, int c, float sqrt_scale, f32x4 cs, f32x4 sn, float eps) {
+  const float ss = row16_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
   const float f = sqrt_scale * rsqrtf(ss + eps);
   v = v * f;
-  f32x4 o;
+  f32x4 up, dn;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) o[u] = __shfl_xor(v[u], 4, 64);
-  if (c < 8) {
-    const f32x4 cs = *reinterpret_cast<const f32x4*>(cs_row + 4 * (c & 3));
-    const f32x4 sn = *reinterpret_cast<const f32x4*>(sn_row + 4 * (c & 3));
-    v = (c < 4) ? (v * cs - o * sn) : (v * cs + o * sn);
-  }
-  return v;
+  for (int u = 0; u < 4; ++u) { up[u] = dpp_mov<DPP_ROR12>(v[u]); dn[u] = dpp_mov<DPP_ROR4>(v[u]); }
+  const f32x4 rot = (c < 4) ? (v * cs - up * sn) : (v * cs + dn * sn);
+  return c < 8 ? rot : v;
+}
+__device__ __forceinline__ f32x4 prep_row16(f32x4 v, int c, float sqrt_scale, const float* cs_row, const float* sn_row, float eps) {
+  const f32x4 cs = *reinterpret_cast<const f32x4*>(cs_row + 4 * (c & 3));
+  const f32x4 sn = *reinterpret_cast<const f32x4*>(sn_row + 4 * (c & 3));
+  return prep_row16_regs(v, c, sqrt_scale, cs, sn, eps);
 }
 
 // 32x32 MFMA C/D fragment: element `reg` of lane `lane` is C[row][col]
