@@ -24,8 +24,10 @@ sys.path.insert(0, REPO)
 
 import k_diffusion_amd as K  # noqa: E402
 
-FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-HBM_PEAK_GBS = 8000.0
+# /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+FP32_MFMA_PEAK_TFLOPS = 157.3      # v_mfma_f32_32x32x2_f32 dense peak (KDIFF_GEMM=exact)
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak (split3 mode executes 3 bf16 products per fp32 product)
+HBM_PEAK_GBS = 8000.0              # HBM3E spec (6.3 TB/s is the measured streaming ceiling)
 
 
 def parse():
@@ -67,6 +69,50 @@ def kernel_table():
         g["bytes"] += by.value
     lib.kd_prof_reset()
     return groups
+
+
+def family_roofline(name, g, split3, total_ms):
+    """Roofline entry of one kernel family from its summed algorithmic work and HIP-event time.  A family is bound by
+    whichever of (algorithmic bytes / HBM peak, executed MFMA flops / MFMA peak) needs longer."""
+    sec = g["ms"] * 1e-3
+    gbs = g["bytes"] / sec / 1e9
+    is_gemm, is_attn = name.startswith("gemm"), name.startswith("attn")
+    # executed matrix flops per algorithmic flop: 3 bf16 products per fp32 product in the split kernels; the dense
+    # attention cores (global / window) run on the exact fp32 MFMA; the neighbourhood core is a split-bf16 kernel too
+    if is_gemm:
+        mult, peak = (3.0, BF16_MFMA_PEAK_TFLOPS) if split3 and not name.startswith("gemm_f32") else (1.0, FP32_MFMA_PEAK_TFLOPS)
+    elif name.startswith("attn_na2d"):
+        mult, peak = 3.0, BF16_MFMA_PEAK_TFLOPS
+    elif is_attn:
+        mult, peak = 1.0, FP32_MFMA_PEAK_TFLOPS
+    else:
+        mult, peak = 0.0, BF16_MFMA_PEAK_TFLOPS
+    tfl_alg = g["flops"] / sec / 1e12
+    t_hbm, t_mfma = g["bytes"] / (HBM_PEAK_GBS * 1e9), g["flops"] * mult / (peak * 1e12)
+    common = {"kernel": name, "launches": g["launches"], "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 5),
+              "share_of_kernel_time": round(g["ms"] / total_ms, 4) if total_ms else None,
+              "algorithmic_gbs": round(gbs, 1), "algorithmic_tflops": round(tfl_alg, 2)}
+    if t_hbm >= t_mfma:
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), **common,
+                "note": "algorithmic bytes (inputs once + outputs once, DESIGN.md section 4) of every launch of this family in the "
+                        "profiled pass / sum of their HIP-event durations"}
+    return {"bound": "mfma", "achieved": round(tfl_alg * mult, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tfl_alg * mult / peak, 4), **common,
+            "note": f"executed matrix flops = {mult:g} x algorithmic 2*M*N*K (split-bf16x3: three bf16 MFMA products per fp32 product) "
+                    "/ sum of HIP-event durations; dense MFMA peak of the executing instruction"}
+
+
+def pmc_traffic(kernel_family):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE
+    passes, gfx950 FETCH x2 correction: profiles/summarize_pmc.py); None when the summary has no matching entry."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    if not kernel_family or not os.path.exists(path):
+        return None
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    ent = table.get(kernel_family.split(" ")[0].split("<")[0])
+    return ent.get("hbm_bytes_per_launch") if ent else None
 
 
 def cpu_baseline(cfg, seed, sampler_steps, target_seconds):
@@ -152,20 +198,19 @@ def main():
         total_ms = sum(g["ms"] for g in groups.values())
         fam = {}
         for name, g in groups.items():
-            f = fam.setdefault(name.split(" ")[0], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            f = fam.setdefault(name.split(" ")[0].split("<")[0], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             for k in f:
                 f[k] += g[k]
         if not fam:
             fam = {"(no kernel events recorded)": {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}}
-        dom_name, dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
-        tflops = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] else 0.0
-        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(tflops, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tflops / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 5), "launches": dom["launches"],
-                    "share_of_kernel_time": round(dom["ms"] / total_ms, 4) if total_ms else None,
-                    "measured_on": "one extra identical pass immediately after the timed region (HIP events per launch)",
-                    "note": "algorithmic 2*M*N*K flops of every launch of this kernel family in the profiled pass / sum of their "
-                            "HIP-event durations (events recorded on the launch stream); fp32-input MFMA peak"}
+        split3 = K._native.default_precision() == K._native.PREC_SPLIT3
+        rooflines = {name: family_roofline(name, g, split3, total_ms) for name, g in fam.items() if g["ms"] > 0}
+        dom_name = max(rooflines, key=lambda n: fam[n]["ms"]) if rooflines else None
+        roofline = dict(rooflines[dom_name]) if dom_name else {"bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0}
+        roofline["traffic"] = pmc_traffic(dom_name)
+        roofline["measured_on"] = "one extra identical pass right after the timed region, a HIP event pair on the launch stream around every launch"
+        roofline["other_kernels"] = {n: {k: r[k] for k in ("bound", "achieved", "unit", "frac", "share_of_kernel_time", "avg_launch_ms")}
+                                     for n, r in sorted(rooflines.items(), key=lambda kv: -fam[kv[0]]["ms"])[1:6]}
         if args.kernel_table:
             with open(args.kernel_table, "w") as f:
                 json.dump({"families": fam, "kernels": groups, "timed_seconds": dt}, f, indent=1)
@@ -177,10 +222,14 @@ def main():
             "metric": "images/sec, 256x256 image_transformer_v2, 50-step DPM++2M (whole job)",
             "value": round(n_img / dt, 3), "unit": "images/sec", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded noise, random-init weights incl. re-randomised zero-init projections)",
+            "dtype": "f32",
+            "dtype_note": ("fp32 in HBM, fp32 accumulation everywhere; matrix products as 3 split-bf16 MFMA terms per fp32 product "
+                           "(hi*hi + hi*lo + lo*hi, per-product error <= ~2^-15; KDIFF_GEMM=exact selects the fp32-input MFMA)") if split3
+                          else "exact fp32-input MFMA (KDIFF_GEMM=exact)",
+            "data": "synthetic (seeded noise, random-init weights incl. re-randomised zero-init projections)",
             "per_gpu": round(n_img / dt / args.gpus, 3),
             "config": {"workload": f"{os.path.basename(args.config)} {mc['input_size'][0]}x{mc['input_size'][1]}, {args.sampler} "
-                                   f"{args.sampler_steps} steps, batch {B}/GPU, fp32 parity mode, all-gather of finished images",
+                                   f"{args.sampler_steps} steps, batch {B}/GPU, all-gather of finished images",
                        "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus} (independent images, one final all-gather)"},
             "algorithmic_tflops": round(n_img * 2 * mac * (nfe or 0) / dt / 1e12, 2) if nfe else None,
             "roofline": roofline,

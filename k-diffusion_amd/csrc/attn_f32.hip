@@ -647,7 +647,9 @@ extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, 
   NaArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H, W, nh, eps};
   const long nb = (long)batch * nh * ((H + NA_TILE - 1) / NA_TILE) * ((W + NA_TILE - 1) / NA_TILE);
   hipStream_t s = (hipStream_t)stream;
-  LaunchScope prof("attn_na2d_f32", 4.0 * batch * (double)H * W * nh * DH * ks * ks, 16.0 * batch * (double)H * W * nh * DH, s);
+  char nm[64] = "attn_na2d";
+  if (prof_on()) snprintf(nm, sizeof(nm), "attn_na2d %dx%d nh=%d", H, W, nh);
+  LaunchScope prof(nm, 4.0 * batch * (double)H * W * nh * DH * ks * ks, 16.0 * batch * (double)H * W * nh * DH, s);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);

@@ -532,7 +532,9 @@ static int launch(const KdGemm& d, hipStream_t s) {
   const double n_eff = (EPI == KD_EPI_GEGLU) ? 2.0 * d.N : (double)d.N;
   char nm[96] = "gemm";
   if (prof_on()) snprintf(nm, sizeof(nm), "gemm_%s<a%d,n%d,e%d> M=%d N=%d K=%d", PREC == KD_PREC_SPLIT3 ? "bf16x3" : "f32", AMODE, (int)NORM, EPI, d.M, d.N, d.K);
-  LaunchScope prof(nm, 2.0 * d.M * n_eff * d.K, 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N), s);
+  // algorithmic bytes: A once, W once, C once (+ the residual / skip / x_in operand of the epilogues that read one)
+  const double r_bytes = (EPI == KD_EPI_RESIDUAL || EPI == KD_EPI_SPLIT_LERP || (EPI == KD_EPI_UNPATCH_NCHW && d.sigma)) ? 4.0 * d.M * d.N : 0.0;
+  LaunchScope prof(nm, 2.0 * d.M * n_eff * d.K, 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N) + r_bytes, s);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), LDS_BYTES, s, d);
   return check_launch("kd_gemm_f32");
 }

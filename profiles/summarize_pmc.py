@@ -3,7 +3,7 @@
 into per-kernel HBM traffic per launch.
 
     python profiles/summarize_pmc.py gpurun_out/pmc_fetch/f_counter_collection.csv \
-           gpurun_out/pmc_write/w_counter_collection.csv profiles/rNN_pmc_summary.json
+           gpurun_out/pmc_write/w_counter_collection.csv profiles/rNN_pmc_summary.json [profiles/rNN_pmc_traffic.json]
 
 Units / corrections (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 this
 rocprofv3 reports exactly 1/2 of the bytes of a wide coalesced streaming read (128-B requests tallied at
@@ -28,6 +28,17 @@ def load(path, counter):
     return acc
 
 
+def family_of(symbol):
+    """rocprof kernel symbol -> the family name bench.py reports (LaunchScope names in csrc/)."""
+    for needle, name in (("gemm_astat_kernel", "gemm_astat"), ("attn_na2d_kernel", "attn_na2d"), ("attn_dense_kernel<0", "attn_global_f32"),
+                         ("attn_dense_kernel<1", "attn_window_f32"), ("sampler_step_kernel", "sampler_step_f32")):
+        if needle in symbol:
+            return name
+    if "gemm_kernel<" in symbol:
+        return "gemm_bf16x3" if symbol.rstrip(">(KdGemm) ").endswith("1") else "gemm_f32"
+    return None
+
+
 def main():
     fetch, write, out = sys.argv[1:4]
     fe, wr = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
@@ -43,6 +54,20 @@ def main():
                      "write_bytes_per_launch": round(w_bytes), "hbm_bytes_per_launch": round(f_bytes + w_bytes)})
     json.dump({"note": "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE x1, KiB -> bytes; per launch averages", "kernels": rows},
               open(out, "w"), indent=1)
+    # per kernel FAMILY (bench.py's grouping: all shapes of one kernel), average over every launch of the profiled run
+    fam = {}
+    for r in rows:
+        name = family_of(r["kernel"])
+        if name:
+            f = fam.setdefault(name, {"launches": 0, "fetch": 0.0, "write": 0.0})
+            f["launches"] += r["dispatches"]
+            f["fetch"] += r["fetch_bytes_per_launch"] * r["dispatches"]
+            f["write"] += r["write_bytes_per_launch"] * r["dispatches"]
+    table = {k: {"launches": v["launches"], "fetch_bytes_per_launch": round(v["fetch"] / v["launches"]),
+                 "write_bytes_per_launch": round(v["write"] / v["launches"]),
+                 "hbm_bytes_per_launch": round((v["fetch"] + v["write"]) / v["launches"])} for k, v in fam.items() if v["launches"]}
+    if len(sys.argv) > 4:
+        json.dump(table, open(sys.argv[4], "w"), indent=1)
     for r in sorted(rows, key=lambda r: -r["hbm_bytes_per_launch"])[:25]:
         print(f'{r["kernel"][:60]:60s} grid={r["grid_size"]:8d} n={r["dispatches"]:4d} fetch={r["fetch_bytes_per_launch"]/1e6:9.1f} MB write={r["write_bytes_per_launch"]/1e6:9.1f} MB')
 
