@@ -240,22 +240,25 @@ __global__ __launch_bounds__(MAXT * 64) void attn_dense_kernel(const DenseArgs a
 }
 
 // ---- neighbourhood core -----------------------------------------------------------------------------
-// One 128-thread workgroup (2 wave64s) per (sample, head, 8x8 query tile).  The 14x14 key halo of the tile is
-// staged in LDS ONCE, K first (cosine-sim scale + RoPE applied on the way in), then V in the same buffer, both as
-// split bf16 (hi = bf16(x), lo = bf16(x - hi)): the two products of the tile then run on the bf16 MFMA with the
-// 3-term split (hi*hi + hi*lo + lo*hi, fp32 accumulate; per-product error <= ~2^-15, like the GEMMs).
-//   wave w owns query rows 4w..4w+3 (32 queries = the MFMA's 32 columns); its clamped 7x7 windows lie inside 10
-//   halo rows = 140 keys -> 5 key tiles of 32
+// One 256-thread workgroup (4 wave64s) per (sample, head, 8x16 query tile).  The 14x22 key halo of the tile is
+// staged in LDS ONCE, K first (cosine-sim scale + RoPE applied on the way in when prep != 0), then V in the same
+// buffer, both as split bf16 (hi = bf16(x), lo = bf16(x - hi)): the two products of the tile then run on the bf16
+// MFMA with the 3-term split (hi*hi + hi*lo + lo*hi, fp32 accumulate; per-product error <= ~2^-15, like the GEMMs).
+//   wave (wy, wx) owns the 4x8 query block at rows 4wy.., columns 8wx.. (32 queries = the MFMA's 32 columns); the
+//   clamped 7x7 windows of its queries lie inside a 10-row x 16-column patch of the halo, walked as 160 "local keys"
+//   kl = 16*r + c  ->  5 key tiles of 32
 //   S^T[key][query] = K Q^T : K rows are the A operand (8 consecutive head dims per lane, 16-byte LDS reads from
 //                     128-byte rows, chunk index XOR-swizzled with (row>>1)&7), Q the B operand from registers
-//   mask (window test per (key, query) from indices; nothing materialised) + softmax, in registers: a lane owns ONE
-//                     query (column) and 16 keys per tile, so the row reductions are in-lane plus one cross-half shuffle
+//   mask            : 5 bit-words per lane (7 runs of 7 bits), applied as an additive 0 / -inf bias; softmax in
+//                     registers: a lane owns ONE query (column) and 16 keys per tile, so the row reductions are
+//                     in-lane plus one cross-half shuffle
 //   O^T[e][query]   = V^T P^T: the P registers feed the B operand directly (an MFMA contracts over 16 keys in the
 //                     k-slot order [4h..4h+3, 8+4h..8+4h+3] of lane-half h; any order is valid as long as A uses
-//                     the same one), so V is staged TRANSPOSED ([e][key], 456-byte rows: conflict-free 8-byte reads)
-// The V halo is prefetched into registers before the QK^T phase so that its HBM latency hides behind the MFMAs.
-// Against a dense MFMA tiling the masked keys waste ~65% of the matrix work, but at the bf16 rate that is ~13 us
-// per launch at the largest level; the kernel is bound by staging (HBM/L2 -> LDS) and LDS traffic instead.
+//                     the same one; 4-key groups never straddle a patch row because rows are 16 keys wide), so V is
+//                     staged TRANSPOSED ([e][key], 632-byte rows: conflict-free 8-byte reads)
+// LDS: 80 896 B per workgroup -> two workgroups (8 waves) per CU.  The V halo is requested right after the QK^T
+// MFMAs so that its latency hides behind the softmax.  Against a dense tiling the masked keys waste ~70% of the matrix
+// work, but at the bf16 rate that is ~15 us per launch at the largest level; the kernel is bound by staging instead.
 struct NaArgs {
   const float* qkv; float* out;
   const float* scale_h; const float* cos_t; const float* sin_t;
@@ -263,18 +266,18 @@ struct NaArgs {
   float eps;
 };
 
-constexpr int NA_K = 7, NA_TILE = 8, NA_HALO = NA_TILE + NA_K - 1;   // 14
-constexpr int NA_KEYS = NA_HALO * NA_HALO;                           // 196
-constexpr int NA_ROWS = 224;                                         // halo rows padded to 7 key tiles of 32
+constexpr int NA_K = 7, NA_TH = 8, NA_TW = 16;
+constexpr int NA_HR = NA_TH + NA_K - 1, NA_HC = NA_TW + NA_K - 1;    // 14 x 22 halo
+constexpr int NA_KEYS = NA_HR * NA_HC;                               // 308
+constexpr int NA_KROWS = 310;                                        // K image rows (a patch may poke 2 keys past the halo)
 constexpr int NA_KT = 5;                                             // key tiles per wave
-constexpr int NA_STAGE_IT = (NA_KEYS + 7) / 8;                       // 25 staging rounds of 8 rows (16 lanes per row)
-constexpr int NA_VT_STRIDE = 456;                                    // bytes per e-row of the transposed V image
-constexpr int NA_IMG_K = NA_ROWS * 128;                              // bytes of one K image  [224][64] bf16
-constexpr int NA_IMG_V = DH * NA_VT_STRIDE;                          // bytes of one V^T image [64][228] bf16
+constexpr int NA_STAGE_IT = (NA_KROWS + 15) / 16;                    // 20 staging rounds of 16 rows (16 lanes per row)
+constexpr int NA_VT_STRIDE = 632;                                    // bytes per e-row of the transposed V image (316 keys)
+constexpr int NA_IMG_K = NA_KROWS * 128;                             // bytes of one K image  [310][64] bf16
+constexpr int NA_IMG_V = DH * NA_VT_STRIDE;                          // bytes of one V^T image [64][316] bf16
 constexpr int NA_LDS = 2 * (NA_IMG_K > NA_IMG_V ? NA_IMG_K : NA_IMG_V);
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
@@ -295,11 +298,12 @@ __device__ __forceinline__ void split4_bf16(const f32x4 v, u32x2& hi, u32x2& lo)
 __device__ __forceinline__ int na_kswz(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 
 template <bool PREP>
-__global__ __launch_bounds__(128) void attn_na2d_kernel(const NaArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
   extern __shared__ __attribute__((aligned(16))) char na_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h2 = lane >> 5;
-  const int tiles_x = (a.W + NA_TILE - 1) / NA_TILE, tiles_y = (a.H + NA_TILE - 1) / NA_TILE;
+  const int wy_ = wid >> 1, wx_ = wid & 1;                            // this wave's 4x8 query block
+  const int tiles_x = (a.W + NA_TW - 1) / NA_TW, tiles_y = (a.H + NA_TH - 1) / NA_TH;
   int r = blockIdx.x;
   const int tx = r % tiles_x; r /= tiles_x;
   const int ty = r % tiles_y; r /= tiles_y;
@@ -308,19 +312,20 @@ __global__ __launch_bounds__(128) void attn_na2d_kernel(const NaArgs a) {
   const long row_stride = 3L * a.nh * DH;
   const float* base = a.qkv + (long)b * T * row_stride + head * DH;
   const float sqrt_scale = PREP ? sqrtf(a.scale_h[head]) : 1.f;
-  const int ty0 = ty * NA_TILE, tx0 = tx * NA_TILE;
-  const int hy0 = clampi(ty0 - NA_K / 2, 0, max(0, a.H - NA_HALO));
-  const int hx0 = clampi(tx0 - NA_K / 2, 0, max(0, a.W - NA_HALO));
+  const int ty0 = ty * NA_TH, tx0 = tx * NA_TW;
+  const int hy0 = clampi(ty0 - NA_K / 2, 0, max(0, a.H - NA_HR));
+  const int hx0 = clampi(tx0 - NA_K / 2, 0, max(0, a.W - NA_HC));
 
-  // ---- halo loads: 16 lanes per key row, 8 rows per round; all rounds requested before any is consumed --------
+  // ---- halo loads: 16 lanes per key row, 16 rows per round --------------------------------------------------------
   const int c16 = tid & 15, rsub = tid >> 4;
   auto halo_tok = [&](int it) -> int {       // token index of this thread's row in round `it`, -1 outside the image / halo
-    const int hr = it * 8 + rsub;
-    const int ky = hy0 + hr / NA_HALO, kx = hx0 + hr % NA_HALO;
+    const int hr = it * 16 + rsub;
+    const int ky = hy0 + hr / NA_HC, kx = hx0 + hr % NA_HC;
     return (hr < NA_KEYS && ky < a.H && kx < a.W) ? ky * a.W + kx : -1;
   };
-  // ---- this lane's query (column l31 of wave wid): 32 of its 64 dims, 8-wide chunks 2*step + h2 ----------------
-  const int qy_raw = ty0 + 4 * wid + (l31 >> 3), qx_raw = tx0 + (l31 & 7);
+
+  // ---- this lane's query (column l31 of its wave): 32 of its 64 dims, 8-wide chunks 2*step + h2 ----------------
+  const int qy_raw = ty0 + 4 * wy_ + (l31 >> 3), qx_raw = tx0 + 8 * wx_ + (l31 & 7);
   const bool q_ok = qy_raw < a.H && qx_raw < a.W;
   const int qy = min(qy_raw, a.H - 1), qx = min(qx_raw, a.W - 1);     // overhanging lanes shadow a real query, never store
   const int q_tok = qy * a.W + qx;
@@ -349,27 +354,24 @@ __global__ __launch_bounds__(128) void attn_na2d_kernel(const NaArgs a) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int tok = halo_tok(IT0 + i);
-      const int hr = (IT0 + i) * 8 + rsub;
+      const int hr = (IT0 + i) * 16 + rsub;
       f32x4 v = kreg[i];
       if (tok < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
       if (PREP) {
         const int tk = tok < 0 ? 0 : tok;
         v = prep_row16(v, c16, sqrt_scale, a.cos_t + ((long)tk * a.nh + head) * ROT, a.sin_t + ((long)tk * a.nh + head) * ROT, a.eps);
       }
-      u32x2 hi, lo;
-      split4_bf16(v, hi, lo);
-      const int o = na_kswz(hr, c16 >> 1) + (c16 & 1) * 8;
-      *reinterpret_cast<u32x2*>(Khi + o) = hi;
-      *reinterpret_cast<u32x2*>(Klo + o) = lo;
+      if (hr < NA_KROWS) {
+        u32x2 hi, lo;
+        split4_bf16(v, hi, lo);
+        const int o = na_kswz(hr, c16 >> 1) + (c16 & 1) * 8;
+        *reinterpret_cast<u32x2*>(Khi + o) = hi;
+        *reinterpret_cast<u32x2*>(Klo + o) = lo;
+      }
     }
   };
-  stage_k(std::integral_constant<int, 0>{}, std::integral_constant<int, 13>{});
-  stage_k(std::integral_constant<int, 13>{}, std::integral_constant<int, NA_STAGE_IT - 13>{});
-  // rows 200..223 are read by the last key tile of wave 1 (always masked): keep them finite
-  for (int i = tid; i < (NA_ROWS - 200) * 8; i += 128) {
-    *reinterpret_cast<u32x4*>(Khi + 200 * 128 + i * 16) = u32x4{0u, 0u, 0u, 0u};
-    *reinterpret_cast<u32x4*>(Klo + 200 * 128 + i * 16) = u32x4{0u, 0u, 0u, 0u};
-  }
+  stage_k(std::integral_constant<int, 0>{}, std::integral_constant<int, 10>{});
+  stage_k(std::integral_constant<int, 10>{}, std::integral_constant<int, NA_STAGE_IT - 10>{});
 
   // ---- q preparation + split into B-operand fragments --------------------------------------------------------------
   if (PREP) {
@@ -401,12 +403,14 @@ __global__ __launch_bounds__(128) void attn_na2d_kernel(const NaArgs a) {
     ql[st] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
   }
 
-  // clamped window start (NATTEN semantics, dilation 1), relative to the halo origin; first halo row of this wave
+  // clamped window start (NATTEN semantics, dilation 1), relative to the halo origin; origin of this wave's 10x16 key
+  // patch (at the bottom / right border the halo is pulled in, so the patch is clamped into it; the column origin is
+  // rounded down to an even key so that the 8-byte V^T reads stay 4-byte aligned)
   const int wy = clampi(qy - NA_K / 2, 0, a.H - NA_K) - hy0;
   const int wx = clampi(qx - NA_K / 2, 0, a.W - NA_K) - hx0;
-  // (at the bottom border the halo is pulled up, so the wave's 10 rows are clamped into the halo's 14)
-  const int row_lo = min(clampi(min(ty0 + 4 * wid, a.H - 1) - NA_K / 2, 0, a.H - NA_K) - hy0, NA_HALO - 10);
-  const int kbase = row_lo * NA_HALO;            // first key (halo index) of this wave's 160-key range
+  const int row_lo = min(clampi(min(ty0 + 4 * wy_, a.H - 1) - NA_K / 2, 0, a.H - NA_K) - hy0, NA_HR - 10);
+  const int col_lo = min(clampi(min(tx0 + 8 * wx_, a.W - 1) - NA_K / 2, 0, a.W - NA_K) - hx0, NA_HC - 14) & ~1;
+  const int korg = row_lo * NA_HC + col_lo;      // halo index of the patch's key (0, 0); local key 16r + c is korg + 22r + c
   __syncthreads();
 
   // ---- S^T = K Q^T over the wave's 5 key tiles ----------------------------------------------------------------------
@@ -416,12 +420,13 @@ __global__ __launch_bounds__(128) void attn_na2d_kernel(const NaArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
   // step-major, term-major: consecutive MFMAs go to different key tiles (no back-to-back chain on one accumulator)
+  const int krow0 = korg + (l31 >> 4) * NA_HC + (l31 & 15);          // this lane's K row of tile 0 (tile t: + 2*22*t)
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
     bf16x8 kh[NA_KT], kl[NA_KT];
 #pragma unroll
     for (int t = 0; t < NA_KT; ++t) {
-      const int o = na_kswz(kbase + t * 32 + l31, 2 * st + h2);
+      const int o = na_kswz(krow0 + 2 * NA_HC * t, 2 * st + h2);
       kh[t] = *reinterpret_cast<const bf16x8*>(Khi + o);
       kl[t] = *reinterpret_cast<const bf16x8*>(Klo + o);
     }
@@ -433,29 +438,30 @@ __global__ __launch_bounds__(128) void attn_na2d_kernel(const NaArgs a) {
     for (int t = 0; t < NA_KT; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[t], qh[st], S[t], 0, 0, 0);
   }
 
-  // ---- V halo prefetch (requested now, consumed after the softmax) ---------------------------------------------------------------
-  f32x4 vreg[NA_STAGE_IT];
+  // ---- V halo prefetch: the first half of the rounds is requested now and consumed after the softmax (its latency
+  // hides behind the mask / exp work); the second half is requested once those registers are free again ------------
+  constexpr int NA_VH = NA_STAGE_IT / 2;
+  f32x4 vreg[NA_VH];
 #pragma unroll
-  for (int it = 0; it < NA_STAGE_IT; ++it) {
+  for (int it = 0; it < NA_VH; ++it) {
     const int tok = halo_tok(it);
     vreg[it] = *reinterpret_cast<const f32x4*>(base + (long)(tok < 0 ? 0 : tok) * row_stride + 2 * a.nh * DH + 4 * c16);
   }
 
   // ---- window mask + softmax over keys (the mask enters as an additive 0 / -inf bias) ----
-  // validity of the wave's 160 keys for THIS lane's query as 5 x 32-bit words: the window is 7 runs of 7 consecutive
-  // halo keys; bit j of word t <=> key kbase + 32t + j is inside the window
+  // validity of the wave's 160 local keys for THIS lane's query as 5 x 32-bit words (word t = patch rows 2t, 2t+1):
+  // the window is 7 runs of 7 consecutive keys, one per patch row wy-row_lo .. +6, starting at column wx-col_lo
   unsigned vw[NA_KT];
 #pragma unroll
   for (int t = 0; t < NA_KT; ++t) vw[t] = 0u;
   {
-    const int s0 = (wy - row_lo) * NA_HALO + wx;
+    const int r0 = wy - row_lo, c0 = wx - col_lo;
 #pragma unroll
     for (int rr = 0; rr < NA_K; ++rr) {
-      const int s_ = s0 + rr * NA_HALO, word = s_ >> 5;
-      const unsigned long long run = 0x7Full << (s_ & 31);
+      const int pr = r0 + rr;
+      const unsigned run = 0x7Fu << ((pr & 1) * 16 + c0);
 #pragma unroll
-      for (int t = 0; t < NA_KT; ++t)
-        vw[t] |= (word == t ? (unsigned)run : 0u) | (word + 1 == t ? (unsigned)(run >> 32) : 0u);
+      for (int t = 0; t < NA_KT; ++t) vw[t] |= ((pr >> 1) == t) ? run : 0u;
     }
 #pragma unroll
     for (int t = 0; t < NA_KT; ++t) vw[t] >>= 4 * h2;         // accumulator element i of this lane is key (i&3) + 8*(i>>2) + 4*h2
@@ -487,12 +493,10 @@ __global__ __launch_bounds__(128) void attn_na2d_kernel(const NaArgs a) {
   __syncthreads();                       // every wave is done reading K
   char* Vhi = na_smem;
   char* Vlo = na_smem + NA_IMG_V;
-#pragma unroll
-  for (int it = 0; it < NA_STAGE_IT; ++it) {
+  auto stage_v = [&](int it, f32x4 v) {
     const int tok = halo_tok(it);
-    const int hr = it * 8 + rsub;
-    if (hr < NA_KEYS) {
-      f32x4 v = vreg[it];
+    const int hr = it * 16 + rsub;
+    if (hr < NA_VT_STRIDE / 2) {           // keys 308..315 (read by patches at the halo's corner, always masked): zero
       if (tok < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
       u32x2 hi, lo;
       split4_bf16(v, hi, lo);
@@ -503,11 +507,18 @@ __global__ __launch_bounds__(128) void attn_na2d_kernel(const NaArgs a) {
         *reinterpret_cast<unsigned short*>(Vlo + o) = (unsigned short)(lo[u >> 1] >> (16 * (u & 1)));
       }
     }
-  }
-  for (int i = tid; i < DH * (NA_ROWS - NA_KEYS) / 4; i += 128) {     // keys 196..223 of every e-row: zero (8-byte pieces)
-    const int e = i / ((NA_ROWS - NA_KEYS) / 4), kq = i % ((NA_ROWS - NA_KEYS) / 4);
-    *reinterpret_cast<u32x2*>(Vhi + e * NA_VT_STRIDE + (NA_KEYS + 4 * kq) * 2) = u32x2{0u, 0u};
-    *reinterpret_cast<u32x2*>(Vlo + e * NA_VT_STRIDE + (NA_KEYS + 4 * kq) * 2) = u32x2{0u, 0u};
+  };
+  {
+    f32x4 vreg2[NA_STAGE_IT - NA_VH];
+#pragma unroll
+    for (int it = NA_VH; it < NA_STAGE_IT; ++it) {
+      const int tok = halo_tok(it);
+      vreg2[it - NA_VH] = *reinterpret_cast<const f32x4*>(base + (long)(tok < 0 ? 0 : tok) * row_stride + 2 * a.nh * DH + 4 * c16);
+    }
+#pragma unroll
+    for (int it = 0; it < NA_VH; ++it) stage_v(it, vreg[it]);
+#pragma unroll
+    for (int it = NA_VH; it < NA_STAGE_IT; ++it) stage_v(it, vreg2[it - NA_VH]);
   }
   __syncthreads();
 
@@ -526,13 +537,14 @@ __global__ __launch_bounds__(128) void attn_na2d_kernel(const NaArgs a) {
     bf16x8 ph[2], pl[2], vh[2][2], vl[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      // B operand: this lane's 8 probabilities of k-slots (regs 8u..8u+7 = keys 16u+4h2+{0..3} and 16u+8+4h2+{0..3})
+      // B operand: this lane's 8 probabilities of k-slots (regs 8u..8u+7 = local keys 32t+16u+4h2+{0..3} and +8):
+      // patch row 2t+u, columns 4h2.. and 8+4h2..
       u32x2 ph0, pl0, ph1, pl1;
       split4_bf16(f32x4{S[t][8 * u], S[t][8 * u + 1], S[t][8 * u + 2], S[t][8 * u + 3]}, ph0, pl0);
       split4_bf16(f32x4{S[t][8 * u + 4], S[t][8 * u + 5], S[t][8 * u + 6], S[t][8 * u + 7]}, ph1, pl1);
       ph[u] = __builtin_bit_cast(bf16x8, u32x4{ph0[0], ph0[1], ph1[0], ph1[1]});
       pl[u] = __builtin_bit_cast(bf16x8, u32x4{pl0[0], pl0[1], pl1[0], pl1[1]});
-      const int key0 = kbase + t * 32 + 16 * u + 4 * h2;
+      const int key0 = korg + (2 * t + u) * NA_HC + 4 * h2;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int o = (32 * e + l31) * NA_VT_STRIDE + key0 * 2;
@@ -645,7 +657,7 @@ extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, 
   if (H < ks || W < ks) return fail(KD_EINVAL, "kd_attn_na2d_f32: grid %dx%d smaller than the %dx%d neighbourhood", H, W, ks, ks);
   if (int e = check_prep(prep, scale_h, cos_t, sin_t, "kd_attn_na2d_f32")) return e;
   NaArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H, W, nh, eps};
-  const long nb = (long)batch * nh * ((H + NA_TILE - 1) / NA_TILE) * ((W + NA_TILE - 1) / NA_TILE);
+  const long nb = (long)batch * nh * ((H + NA_TH - 1) / NA_TH) * ((W + NA_TW - 1) / NA_TW);
   hipStream_t s = (hipStream_t)stream;
   char nm[64] = "attn_na2d";
   if (prof_on()) snprintf(nm, sizeof(nm), "attn_na2d %dx%d nh=%d", H, W, nh);
@@ -656,7 +668,7 @@ extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
     attr_set = true;
   }
-  if (prep) hipLaunchKernelGGL(attn_na2d_kernel<true>, dim3((unsigned)nb), dim3(128), NA_LDS, s, a);
-  else hipLaunchKernelGGL(attn_na2d_kernel<false>, dim3((unsigned)nb), dim3(128), NA_LDS, s, a);
+  if (prep) hipLaunchKernelGGL(attn_na2d_kernel<true>, dim3((unsigned)nb), dim3(256), NA_LDS, s, a);
+  else hipLaunchKernelGGL(attn_na2d_kernel<false>, dim3((unsigned)nb), dim3(256), NA_LDS, s, a);
   return check_launch("kd_attn_na2d_f32");
 }
