@@ -318,12 +318,17 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
 
   // ---- halo loads: 16 lanes per key row, 16 rows per round --------------------------------------------------------
   const int c16 = tid & 15, rsub = tid >> 4;
-  auto halo_tok = [&](int it) -> int {       // token index of this thread's row in round `it`, -1 outside the image / halo
-    const int hr = it * 16 + rsub;
-    const int ky = hy0 + hr / NA_HC, kx = hx0 + hr % NA_HC;
-    return (hr < NA_KEYS && ky < a.H && kx < a.W) ? ky * a.W + kx : -1;
+  // round `it` of a staging pass handles halo key hr = 16*it + rsub; (ky, kx) advance incrementally (16 < 22 columns:
+  // at most one row wrap per round) instead of a divide per round
+  struct HaloIt {
+    int ky, kx, hr;
+    __device__ __forceinline__ void next() { hr += 16; kx += 16; if (kx >= NA_HC) { kx -= NA_HC; ++ky; } }
   };
-
+  const HaloIt halo0{rsub / NA_HC, rsub % NA_HC, rsub};       // rsub < 16 < 22: row 0
+  auto halo_tok = [&](const HaloIt& h) -> int {       // token index of the key, -1 outside the image / halo
+    const int ky = hy0 + h.ky, kx = hx0 + h.kx;
+    return (h.hr < NA_KEYS && ky < a.H && kx < a.W) ? ky * a.W + kx : -1;
+  };
   // ---- this lane's query (column l31 of its wave): 32 of its 64 dims, 8-wide chunks 2*step + h2 ----------------
   const int qy_raw = ty0 + 4 * wy_ + (l31 >> 3), qx_raw = tx0 + 8 * wx_ + (l31 & 7);
   const bool q_ok = qy_raw < a.H && qx_raw < a.W;
@@ -343,18 +348,20 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
   // two batches of rounds, each requested in full before it is consumed (memory-level parallelism vs registers)
   char* Khi = na_smem;
   char* Klo = na_smem + NA_IMG_K;
-  auto stage_k = [&](auto it0_tag, auto n_tag) {
-    constexpr int IT0 = decltype(it0_tag)::value, N = decltype(n_tag)::value;
+  HaloIt hk_load = halo0, hk_use = halo0;
+  auto stage_k = [&](auto n_tag) {
+    constexpr int N = decltype(n_tag)::value;
     f32x4 kreg[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const int tok = halo_tok(IT0 + i);
+      const int tok = halo_tok(hk_load);
       kreg[i] = *reinterpret_cast<const f32x4*>(base + (long)(tok < 0 ? 0 : tok) * row_stride + a.nh * DH + 4 * c16);
+      hk_load.next();
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const int tok = halo_tok(IT0 + i);
-      const int hr = (IT0 + i) * 16 + rsub;
+      const int tok = halo_tok(hk_use);
+      const int hr = hk_use.hr;
       f32x4 v = kreg[i];
       if (tok < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
       if (PREP) {
@@ -368,10 +375,11 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
         *reinterpret_cast<u32x2*>(Khi + o) = hi;
         *reinterpret_cast<u32x2*>(Klo + o) = lo;
       }
+      hk_use.next();
     }
   };
-  stage_k(std::integral_constant<int, 0>{}, std::integral_constant<int, 10>{});
-  stage_k(std::integral_constant<int, 10>{}, std::integral_constant<int, NA_STAGE_IT - 10>{});
+  stage_k(std::integral_constant<int, 10>{});
+  stage_k(std::integral_constant<int, NA_STAGE_IT - 10>{});
 
   // ---- q preparation + split into B-operand fragments --------------------------------------------------------------
   if (PREP) {
@@ -440,12 +448,28 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
 
   // ---- V halo prefetch: the first half of the rounds is requested now and consumed after the softmax (its latency
   // hides behind the mask / exp work); the second half is requested once those registers are free again ------------
-  constexpr int NA_VH = NA_STAGE_IT / 2;
-  f32x4 vreg[NA_VH];
+  // V staging walks key PAIRS (2p, 2p+1: same halo row, 22 is even): round j handles pair 16j + rsub, 10 rounds
+  constexpr int NA_VR = (NA_VT_STRIDE / 2 / 2 + 15) / 16, NA_VH = NA_VR / 2;      // 10 rounds, 5 per half
+  struct PairIt {
+    int ky, kx, key;                       // halo coordinates / index of the pair's even key
+    __device__ __forceinline__ void next() { key += 32; kx += 10; ++ky; if (kx >= NA_HC) { kx -= NA_HC; ++ky; } }
+  };
+  const PairIt pair0{(2 * rsub) / NA_HC, (2 * rsub) % NA_HC, 2 * rsub};
+  auto pair_tok = [&](const PairIt& h) -> int {      // token of the even key; the odd key is the next token (or invalid)
+    const int ky = hy0 + h.ky, kx = hx0 + h.kx;
+    return (h.key < NA_KEYS && ky < a.H && kx < a.W) ? ky * a.W + kx : -1;
+  };
+  auto pair_odd_ok = [&](const PairIt& h) -> bool { return hx0 + h.kx + 1 < a.W; };
+  const float* vbase = base + 2 * a.nh * DH + 4 * c16;
+  f32x4 vreg[2 * NA_VH];
+  PairIt hv_load = pair0, hv_use = pair0;
 #pragma unroll
-  for (int it = 0; it < NA_VH; ++it) {
-    const int tok = halo_tok(it);
-    vreg[it] = *reinterpret_cast<const f32x4*>(base + (long)(tok < 0 ? 0 : tok) * row_stride + 2 * a.nh * DH + 4 * c16);
+  for (int j = 0; j < NA_VH; ++j) {
+    const int tok = pair_tok(hv_load);
+    const long o = (long)(tok < 0 ? 0 : tok) * row_stride;
+    vreg[2 * j] = *reinterpret_cast<const f32x4*>(vbase + o);
+    vreg[2 * j + 1] = *reinterpret_cast<const f32x4*>(vbase + o + (tok >= 0 && pair_odd_ok(hv_load) ? row_stride : 0));
+    hv_load.next();
   }
 
   // ---- window mask + softmax over keys (the mask enters as an additive 0 / -inf bias) ----
@@ -493,32 +517,43 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
   __syncthreads();                       // every wave is done reading K
   char* Vhi = na_smem;
   char* Vlo = na_smem + NA_IMG_V;
-  auto stage_v = [&](int it, f32x4 v) {
-    const int tok = halo_tok(it);
-    const int hr = it * 16 + rsub;
-    if (hr < NA_VT_STRIDE / 2) {           // keys 308..315 (read by patches at the halo's corner, always masked): zero
-      if (tok < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      u32x2 hi, lo;
-      split4_bf16(v, hi, lo);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int o = (4 * c16 + u) * NA_VT_STRIDE + hr * 2;
-        *reinterpret_cast<unsigned short*>(Vhi + o) = (unsigned short)(hi[u >> 1] >> (16 * (u & 1)));
-        *reinterpret_cast<unsigned short*>(Vlo + o) = (unsigned short)(lo[u >> 1] >> (16 * (u & 1)));
-      }
+  // one pair -> 4 dwords (hi) + 4 dwords (lo): Vt[e][2p], Vt[e][2p+1] packed in one 32-bit LDS word per e
+  auto stage_v = [&](f32x4 v0, f32x4 v1) {
+    const int tok = pair_tok(hv_use);
+    if (hv_use.key < NA_VT_STRIDE / 2) {           // keys 308..315 (read by patches at the halo's corner, always masked): zero
+      if (tok < 0) v0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (tok < 0 || !pair_odd_ok(hv_use)) v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x2 h0, l0, h1, l1;
+      split4_bf16(v0, h0, l0);
+      split4_bf16(v1, h1, l1);
+      char* ph_ = Vhi + (4 * c16) * NA_VT_STRIDE + hv_use.key * 2;
+      char* pl_ = Vlo + (4 * c16) * NA_VT_STRIDE + hv_use.key * 2;
+      // e = 4c16+0: low halves, +1: high halves of word 0; +2, +3: word 1   (v_perm_b32 selects)
+      *reinterpret_cast<unsigned*>(ph_) = __builtin_amdgcn_perm(h1[0], h0[0], 0x05040100u);
+      *reinterpret_cast<unsigned*>(ph_ + NA_VT_STRIDE) = __builtin_amdgcn_perm(h1[0], h0[0], 0x07060302u);
+      *reinterpret_cast<unsigned*>(ph_ + 2 * NA_VT_STRIDE) = __builtin_amdgcn_perm(h1[1], h0[1], 0x05040100u);
+      *reinterpret_cast<unsigned*>(ph_ + 3 * NA_VT_STRIDE) = __builtin_amdgcn_perm(h1[1], h0[1], 0x07060302u);
+      *reinterpret_cast<unsigned*>(pl_) = __builtin_amdgcn_perm(l1[0], l0[0], 0x05040100u);
+      *reinterpret_cast<unsigned*>(pl_ + NA_VT_STRIDE) = __builtin_amdgcn_perm(l1[0], l0[0], 0x07060302u);
+      *reinterpret_cast<unsigned*>(pl_ + 2 * NA_VT_STRIDE) = __builtin_amdgcn_perm(l1[1], l0[1], 0x05040100u);
+      *reinterpret_cast<unsigned*>(pl_ + 3 * NA_VT_STRIDE) = __builtin_amdgcn_perm(l1[1], l0[1], 0x07060302u);
     }
+    hv_use.next();
   };
   {
-    f32x4 vreg2[NA_STAGE_IT - NA_VH];
+    f32x4 vreg2[2 * (NA_VR - NA_VH)];
 #pragma unroll
-    for (int it = NA_VH; it < NA_STAGE_IT; ++it) {
-      const int tok = halo_tok(it);
-      vreg2[it - NA_VH] = *reinterpret_cast<const f32x4*>(base + (long)(tok < 0 ? 0 : tok) * row_stride + 2 * a.nh * DH + 4 * c16);
+    for (int j = 0; j < NA_VR - NA_VH; ++j) {
+      const int tok = pair_tok(hv_load);
+      const long o = (long)(tok < 0 ? 0 : tok) * row_stride;
+      vreg2[2 * j] = *reinterpret_cast<const f32x4*>(vbase + o);
+      vreg2[2 * j + 1] = *reinterpret_cast<const f32x4*>(vbase + o + (tok >= 0 && pair_odd_ok(hv_load) ? row_stride : 0));
+      hv_load.next();
     }
 #pragma unroll
-    for (int it = 0; it < NA_VH; ++it) stage_v(it, vreg[it]);
+    for (int j = 0; j < NA_VH; ++j) stage_v(vreg[2 * j], vreg[2 * j + 1]);
 #pragma unroll
-    for (int it = NA_VH; it < NA_STAGE_IT; ++it) stage_v(it, vreg2[it - NA_VH]);
+    for (int j = 0; j < NA_VR - NA_VH; ++j) stage_v(vreg2[2 * j], vreg2[2 * j + 1]);
   }
   __syncthreads();
 
