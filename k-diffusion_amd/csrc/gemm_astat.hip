@@ -52,7 +52,9 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
 #define KD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define KD_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-// NC = K / 16 (8 or 16); EPI: KD_EPI_STORE / KD_EPI_QKV / KD_EPI_GEGLU
+// NC = K / 16 (8, 16 or 32); EPI: KD_EPI_STORE / KD_EPI_QKV / KD_EPI_GEGLU.  gridDim.y splits the n-tiles of a panel over
+// several workgroups when M alone gives too few panels to fill the chip (each re-normalises the A panel: cheap next to
+// its share of W).  K = 512 keeps 256 VGPRs of A fragments per lane: one workgroup per CU, unified VGPR/AGPR file.
 template <int NC, int EPI>
 __global__ __launch_bounds__(256, NC == 8 ? 2 : 1) void gemm_astat_kernel(const KdGemm p) {
   constexpr int K = NC * 16, NK = NC / 2;                 // NK: W stages per n-tile (multiple of NSTG)
@@ -67,12 +69,14 @@ __global__ __launch_bounds__(256, NC == 8 ? 2 : 1) void gemm_astat_kernel(const 
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int M = p.M, N = p.N;
-  const int n_tiles = N / NCOL;
-  const int total = n_tiles * NK;                         // W stages of this panel
+  const int n_tiles_all = N / NCOL;
+  const int nt_begin = (int)((long)n_tiles_all * blockIdx.y / gridDim.y), nt_end = (int)((long)n_tiles_all * (blockIdx.y + 1) / gridDim.y);
+  const int n_tiles = nt_end - nt_begin;                  // n-tiles of this workgroup
+  const int total = n_tiles * NK;                         // its W stages
   const int m0 = blockIdx.x * BM;
 
   // ---- W stage s -> ring slot s % NSTG (this wave's quarter: 4 x 1 KiB, lands at slot + wid*4 KiB + lane*16) ----------
-  const char* wp = reinterpret_cast<const char*>(p.Wp);
+  const char* wp = reinterpret_cast<const char*>(p.Wp) + (size_t)nt_begin * NK * STAGE;
   auto issue = [&](int s) {
     const char* src = wp + (size_t)s * STAGE + wid * 4096 + lane * 16;
     char* dst = ring + (s % NSTG) * STAGE + wid * 4096;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256, NC == 8 ? 2 : 1) void gemm_astat_kernel(const 
 
   // ---- epilogue of n-tile nt: acc (32 rows x 128 W-rows) -> strips -> global ------------------------------------------------
   auto epilogue = [&](int nt) {
-    const int n0 = nt * NCOL;
+    const int n0 = (nt_begin + nt) * NCOL;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int row_base = m0 + wid * 32 + 8 * g;
@@ -226,7 +230,11 @@ static int launch(const KdGemm& d, hipStream_t s) {
   char nm[96] = "gemm_astat";
   if (prof_on()) snprintf(nm, sizeof(nm), "gemm_astat<e%d> M=%d N=%d K=%d", EPI, d.M, d.N, d.K);
   LaunchScope prof(nm, 2.0 * d.M * n_eff * d.K, 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N), s);
-  hipLaunchKernelGGL(kern, dim3((unsigned)((d.M + BM - 1) / BM)), dim3(256), LDS_BYTES, s, d);
+  // panels x n-splits: aim at >= 256 workgroups (one per CU) while every split keeps >= 2 n-tiles
+  const int panels = (d.M + BM - 1) / BM, n_tiles = d.N / (EPI == KD_EPI_GEGLU ? 64 : 128);
+  int splits = 1;
+  while (panels * splits < 256 && n_tiles / (splits * 2) >= 2) splits *= 2;
+  hipLaunchKernelGGL(kern, dim3((unsigned)panels, (unsigned)splits), dim3(256), LDS_BYTES, s, d);
   return check_launch("kd_gemm_f32(astat)");
 }
 
@@ -237,7 +245,7 @@ int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
   using namespace astat;
   if (d.precision != KD_PREC_SPLIT3 || d.a_mode != KD_A_PLAIN || !d.norm || !d.Wp || d.debug) return 1;
   if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_QKV && d.epi != KD_EPI_GEGLU) return 1;
-  if (d.K != 128 && d.K != 256) return 1;
+  if (d.K != 128 && d.K != 256 && d.K != 512) return 1;
   const int ncol = d.epi == KD_EPI_GEGLU ? 64 : 128;
   if (d.N % ncol || d.N / ncol < 2) return 1;                                   // one n-tile: nothing to amortise
   if (!(d.scale_stride == 0 || d.rows_per_sample % BM == 0)) return 1;          // one scale vector per panel
@@ -246,6 +254,7 @@ int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
 #define KD_AS(NCV, EP) if (d.K == NCV * 16 && d.epi == EP) { *rc = launch<NCV, EP>(d, s); return 0; }
   KD_AS(8, KD_EPI_STORE) KD_AS(8, KD_EPI_QKV) KD_AS(8, KD_EPI_GEGLU)
   KD_AS(16, KD_EPI_STORE) KD_AS(16, KD_EPI_QKV) KD_AS(16, KD_EPI_GEGLU)
+  KD_AS(32, KD_EPI_STORE) KD_AS(32, KD_EPI_QKV) KD_AS(32, KD_EPI_GEGLU)
 #undef KD_AS
   return 1;
 }

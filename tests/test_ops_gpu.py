@@ -107,6 +107,44 @@ def test_qkv_epilogue_prepares_q_and_k(ops, gtol):
         ops.norm_linear(g(x), g(scale), g(w[: 2 * d]), rows_per_sample=H * W, epi=5, qk=(g(sh), g(cos), g(sin), nh))
 
 
+@pytest.mark.parametrize("M,K,N,kind", [(1024, 128, 384, "qkv"), (1000, 128, 768, "geglu"), (4096, 256, 768, "qkv"), (640, 256, 1536, "geglu"),
+                                        (8192, 512, 1536, "qkv"), (2048, 512, 3072, "geglu"), (768, 512, 512, "store"), (520, 128, 256, "store")])
+def test_wide_projections_a_stationary(ops, monkeypatch, M, K, N, kind):
+    """The A-stationary kernel (gemm_astat.hip: K in {128, 256, 512}, >= 2 n-tiles, M >= 512) against the oracle at
+    shapes that exercise its n-split grids (few panels), a ragged last panel, per-sample and shared norm scales, and all
+    three epilogues (store, GEGLU, qkv with q/k preparation)."""
+    monkeypatch.setenv("KDIFF_GEMM", "split3")
+    B = 4 if M % 4 == 0 and (M // 4) % 128 == 0 else 1
+    T = M // B
+    x = rn(M, K, seed=1)
+    scale = 1 + 0.1 * rn(B, K, seed=2) if B > 1 else 1 + 0.1 * rn(K, seed=2)
+    xn = hdit.rms_norm(x.view(B, T, K), scale.view(B, 1, K) if B > 1 else scale).view(M, K)
+    if kind == "geglu":
+        w = rn(2 * N, K, seed=3) / K ** 0.5
+        y = ops.norm_linear(g(x), g(scale), g(w), rows_per_sample=T, epi=2)
+        ref = hdit.linear_geglu(xn, w)
+    elif kind == "store":
+        w = rn(N, K, seed=3) / K ** 0.5
+        y = ops.norm_linear(g(x), g(scale), g(w), rows_per_sample=T)
+        ref = xn @ w.T
+    else:
+        nh = N // 192
+        w = rn(N, K, seed=3) / K ** 0.5
+        sh = torch.linspace(6.0, 12.0, nh)
+        h = 1
+        while h * h < T:
+            h += 1
+        assert h * h == T or T % 128 == 0
+        hh, ww = (h, h) if h * h == T else (T // 16, 16)
+        theta = hdit.rope_theta(hdit.axial_pos(hh, ww), hdit.rope_freqs(nh))
+        cos, sin = torch.cos(theta).reshape(T, nh, 16), torch.sin(theta).reshape(T, nh, 16)
+        y = ops.norm_linear(g(x), g(scale), g(w), rows_per_sample=T, epi=5, qk=(g(sh), g(cos), g(sin), nh))
+        q, k, v = hdit.split_qkv((xn @ w.T).view(B, hh, ww, N), nh)
+        q, k = hdit.cosine_sim_scale(q, k, sh)
+        ref = torch.stack([hdit.apply_rope(q, theta), hdit.apply_rope(k, theta), v], dim=3).reshape(M, N)
+    assert relerr(y, ref) < 1e-4
+
+
 def test_token_merge_split(ops, gtol, golden):
     o = golden["ops"]
     x = o["rms_norm.x"]
