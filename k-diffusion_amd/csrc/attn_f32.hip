@@ -255,8 +255,8 @@ __global__ __launch_bounds__(MAXT * 64) void attn_dense_kernel(const DenseArgs a
 //   O^T[e][query]   = V^T P^T: the P registers feed the B operand directly (an MFMA contracts over 16 keys in the
 //                     k-slot order [4h..4h+3, 8+4h..8+4h+3] of lane-half h; any order is valid as long as A uses
 //                     the same one; 4-key groups never straddle a patch row because rows are 16 keys wide), so V is
-//                     staged TRANSPOSED ([e][key], 632-byte rows: conflict-free 8-byte reads)
-// LDS: 80 896 B per workgroup -> two workgroups (8 waves) per CU.  The V halo is requested right after the QK^T
+//                     staged TRANSPOSED ([e][key], 636-byte rows: conflict-free dword-pair reads)
+// LDS: 81 408 B per workgroup -> two workgroups (8 waves) per CU.  The V halo is requested right after the QK^T
 // MFMAs so that its latency hides behind the softmax.  Against a dense tiling the masked keys waste ~70% of the matrix
 // work, but at the bf16 rate that is ~15 us per launch at the largest level; the kernel is bound by staging instead.
 struct NaArgs {
@@ -272,7 +272,7 @@ constexpr int NA_KEYS = NA_HR * NA_HC;                               // 308
 constexpr int NA_KROWS = 310;                                        // K image rows (a patch may poke 2 keys past the halo)
 constexpr int NA_KT = 5;                                             // key tiles per wave
 constexpr int NA_STAGE_IT = (NA_KROWS + 15) / 16;                    // 20 staging rounds of 16 rows (16 lanes per row)
-constexpr int NA_VT_STRIDE = 632;                                    // bytes per e-row of the transposed V image (316 keys)
+constexpr int NA_VT_STRIDE = 636;                                    // bytes per e-row of the transposed V image (318 keys; 159 dwords: odd, so the 32 e-rows of a fragment read hit 32 different banks)
 constexpr int NA_IMG_K = NA_KROWS * 128;                             // bytes of one K image  [310][64] bf16
 constexpr int NA_IMG_V = DH * NA_VT_STRIDE;                          // bytes of one V^T image [64][316] bf16
 constexpr int NA_LDS = 2 * (NA_IMG_K > NA_IMG_V ? NA_IMG_K : NA_IMG_V);
@@ -583,10 +583,11 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int o = (32 * e + l31) * NA_VT_STRIDE + key0 * 2;
-        const u32x2 vh0 = *reinterpret_cast<const u32x2*>(Vhi + o), vh1 = *reinterpret_cast<const u32x2*>(Vhi + o + 16);
-        const u32x2 vl0 = *reinterpret_cast<const u32x2*>(Vlo + o), vl1 = *reinterpret_cast<const u32x2*>(Vlo + o + 16);
-        vh[e][u] = __builtin_bit_cast(bf16x8, u32x4{vh0[0], vh0[1], vh1[0], vh1[1]});
-        vl[e][u] = __builtin_bit_cast(bf16x8, u32x4{vl0[0], vl0[1], vl1[0], vl1[1]});
+        // 4-byte aligned only (the patch origin is an even key): dword reads (ds_read2_b32), never a misaligned b64
+        const unsigned* hp = reinterpret_cast<const unsigned*>(Vhi + o);
+        const unsigned* lp = reinterpret_cast<const unsigned*>(Vlo + o);
+        vh[e][u] = __builtin_bit_cast(bf16x8, u32x4{hp[0], hp[1], hp[4], hp[5]});
+        vl[e][u] = __builtin_bit_cast(bf16x8, u32x4{lp[0], lp[1], lp[4], lp[5]});
       }
     }
 #pragma unroll
