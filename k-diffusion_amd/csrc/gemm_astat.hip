@@ -19,6 +19,7 @@
 // BEFORE it (they were requested 2-3 stages earlier), and the first wait that can see the stores comes two stages
 // later, when they have long been written.
 #include "kd_common.h"
+#include <cstdlib>
 
 namespace kd {
 
@@ -245,7 +246,8 @@ int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
   using namespace astat;
   if (d.precision != KD_PREC_SPLIT3 || d.a_mode != KD_A_PLAIN || !d.norm || !d.Wp || d.debug) return 1;
   if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_QKV && d.epi != KD_EPI_GEGLU) return 1;
-  if (d.K != 128 && d.K != 256 && d.K != 512) return 1;
+  static const int max_k = getenv("KDIFF_ASTAT_MAXK") ? atoi(getenv("KDIFF_ASTAT_MAXK")) : 512;    // A/B switch for benchmarks/
+  if ((d.K != 128 && d.K != 256 && d.K != 512) || d.K > max_k) return 1;
   const int ncol = d.epi == KD_EPI_GEGLU ? 64 : 128;
   if (d.N % ncol || d.N / ncol < 2) return 1;                                   // one n-tile: nothing to amortise
   if (!(d.scale_stride == 0 || d.rows_per_sample % BM == 0)) return 1;          // one scale vector per panel
