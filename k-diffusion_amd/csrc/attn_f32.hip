@@ -23,6 +23,7 @@
 // (16 head dims each, two DPP shuffles per score); the 14x14 key halo of an 8x8 query tile is staged
 // in LDS, K first, then V in the same buffer.
 #include "kd_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace kd {
@@ -619,6 +620,255 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
   }
 }
 
+// ---- global core on the split-bf16 MFMA ------------------------------------------------------------------------------
+// Dense softmax attention per (sample, head) over T <= 256 tokens, same 3-term bf16 split and the same operand scheme
+// as the neighbourhood core (S^T = K Q^T with K rows from swizzled LDS, O^T = V^T P^T with P from registers and V staged
+// transposed), without halo or window mask: NT = ceil(T/32) waves, wave w owns queries 32w..32w+31 and all NT key tiles
+// (the whole score row lives in registers: no online softmax).  K and then V^T occupy the same LDS buffer.
+template <int NT, bool PREP>
+__global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char gs_smem[];
+  constexpr int TP = NT * 32, NTHR = NT * 64;
+  constexpr int VSTR = TP * 2 + 4;                       // bytes per e-row of V^T: odd dword count -> conflict-free dword-pair reads
+  constexpr int IMG_K = TP * 128, IMG_V = DH * VSTR;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h2 = lane >> 5;
+  const int head = blockIdx.x % a.nh, b = blockIdx.x / a.nh;
+  const int T = a.T;
+  const long row_stride = 3L * a.nh * DH;
+  const float* base = a.qkv + (long)b * T * row_stride + head * DH;
+  const float sqrt_scale = PREP ? sqrtf(a.scale_h[head]) : 1.f;
+  const int c16 = tid & 15, rsub = tid >> 4;             // staging: 16 lanes per key row, NTHR/16 rows per round, 8 rounds
+
+  // ---- this lane's query: 32 of its 64 dims, 8-wide chunks 2*step + h2 -------------------------------------------------
+  const int q_slot = wid * 32 + l31;
+  const bool q_ok = q_slot < T;
+  const int q_tok = min(q_slot, T - 1);
+  f32x4 qf[8];
+  {
+    const float* rp = base + (long)q_tok * row_stride;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      qf[2 * st] = *reinterpret_cast<const f32x4*>(rp + 16 * st + 8 * h2);
+      qf[2 * st + 1] = *reinterpret_cast<const f32x4*>(rp + 16 * st + 8 * h2 + 4);
+    }
+  }
+
+  // ---- K -> LDS (all rounds requested before any is consumed) -------------------------------------------------------------
+  char* Khi = gs_smem;
+  char* Klo = gs_smem + IMG_K;
+  {
+    f32x4 kreg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int slot = i * (NTHR / 16) + rsub;
+      kreg[i] = *reinterpret_cast<const f32x4*>(base + (long)min(slot, T - 1) * row_stride + a.nh * DH + 4 * c16);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int slot = i * (NTHR / 16) + rsub;
+      f32x4 v = kreg[i];
+      if (PREP) {
+        const int tk = min(slot, T - 1);
+        v = prep_row16(v, c16, sqrt_scale, a.cos_t + ((long)tk * a.nh + head) * ROT, a.sin_t + ((long)tk * a.nh + head) * ROT, a.eps);
+      }
+      if (slot >= T) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x2 hi, lo;
+      split4_bf16(v, hi, lo);
+      const int o = na_kswz(slot, c16 >> 1) + (c16 & 1) * 8;
+      *reinterpret_cast<u32x2*>(Khi + o) = hi;
+      *reinterpret_cast<u32x2*>(Klo + o) = lo;
+    }
+  }
+
+  // ---- V prefetch as key pairs (2p, 2p+1): pair index j*(NTHR/16) + rsub, 4 rounds ------------------------------------------
+  const float* vbase = base + 2 * a.nh * DH + 4 * c16;
+  f32x4 vreg[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int key = 2 * (j * (NTHR / 16) + rsub);
+    vreg[2 * j] = *reinterpret_cast<const f32x4*>(vbase + (long)min(key, T - 1) * row_stride);
+    vreg[2 * j + 1] = *reinterpret_cast<const f32x4*>(vbase + (long)min(key + 1, T - 1) * row_stride);
+  }
+
+  // ---- q preparation + split into B-operand fragments -------------------------------------------------------------------------
+  if (PREP) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += qf[i][0] * qf[i][0] + qf[i][1] * qf[i][1] + qf[i][2] * qf[i][2] + qf[i][3] * qf[i][3];
+    ss += __shfl_xor(ss, 32, 64);
+    const float f = sqrt_scale * rsqrtf(ss + a.eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qf[i] = qf[i] * f;
+    const float* cs = a.cos_t + ((long)q_tok * a.nh + head) * ROT + 8 * h2;
+    const float* sn = a.sin_t + ((long)q_tok * a.nh + head) * ROT + 8 * h2;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const f32x4 cc = *reinterpret_cast<const f32x4*>(cs + 4 * u), sc = *reinterpret_cast<const f32x4*>(sn + 4 * u);
+      const f32x4 x1 = qf[u], x2 = qf[2 + u];
+      qf[u] = x1 * cc - x2 * sc;
+      qf[2 + u] = x2 * cc + x1 * sc;
+    }
+  }
+  bf16x8 qh[4], ql[4];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    u32x2 h0, l0, h1, l1;
+    split4_bf16(qf[2 * st], h0, l0);
+    split4_bf16(qf[2 * st + 1], h1, l1);
+    qh[st] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+    ql[st] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+  }
+  __syncthreads();
+
+  // ---- S^T = K Q^T over all NT key tiles (step-major, term-major issue order) ------------------------------------------------------
+  f32x16 S[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += 4) {          // groups of 4 tiles: fragment registers stay bounded at NT = 8
+      bf16x8 kh[4], kl[4];
+#pragma unroll
+      for (int t = 0; t < 4 && t0 + t < NT; ++t) {
+        const int o = na_kswz((t0 + t) * 32 + l31, 2 * st + h2);
+        kh[t] = *reinterpret_cast<const bf16x8*>(Khi + o);
+        kl[t] = *reinterpret_cast<const bf16x8*>(Klo + o);
+      }
+#pragma unroll
+      for (int t = 0; t < 4 && t0 + t < NT; ++t) S[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[t], qh[st], S[t0 + t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4 && t0 + t < NT; ++t) S[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[t], ql[st], S[t0 + t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4 && t0 + t < NT; ++t) S[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[t], qh[st], S[t0 + t], 0, 0, 0);
+    }
+  }
+
+  // ---- softmax over keys (keys >= T masked by an additive -inf) ----------------------------------------------------------------------
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (t * 32 + 32 > T) S[t][i] += (t * 32 + mfma32_row(i, lane) < T) ? 0.f : -INFINITY;
+      m = fmaxf(m, S[t][i]);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float pv = __expf(S[t][i] - m);
+      S[t][i] = pv;
+      l += pv;
+    }
+  l += __shfl_xor(l, 32, 64);
+
+  // ---- V -> LDS, transposed and pair-packed: Vt[e][key] --------------------------------------------------------------------------------
+  __syncthreads();                       // every wave is done reading K
+  char* Vhi = gs_smem;
+  char* Vlo = gs_smem + IMG_V;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int key = 2 * (j * (NTHR / 16) + rsub);
+    f32x4 v0 = vreg[2 * j], v1 = vreg[2 * j + 1];
+    if (key >= T) v0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (key + 1 >= T) v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x2 h0, l0, h1, l1;
+    split4_bf16(v0, h0, l0);
+    split4_bf16(v1, h1, l1);
+    char* ph_ = Vhi + (4 * c16) * VSTR + key * 2;
+    char* pl_ = Vlo + (4 * c16) * VSTR + key * 2;
+    *reinterpret_cast<unsigned*>(ph_) = __builtin_amdgcn_perm(h1[0], h0[0], 0x05040100u);
+    *reinterpret_cast<unsigned*>(ph_ + VSTR) = __builtin_amdgcn_perm(h1[0], h0[0], 0x07060302u);
+    *reinterpret_cast<unsigned*>(ph_ + 2 * VSTR) = __builtin_amdgcn_perm(h1[1], h0[1], 0x05040100u);
+    *reinterpret_cast<unsigned*>(ph_ + 3 * VSTR) = __builtin_amdgcn_perm(h1[1], h0[1], 0x07060302u);
+    *reinterpret_cast<unsigned*>(pl_) = __builtin_amdgcn_perm(l1[0], l0[0], 0x05040100u);
+    *reinterpret_cast<unsigned*>(pl_ + VSTR) = __builtin_amdgcn_perm(l1[0], l0[0], 0x07060302u);
+    *reinterpret_cast<unsigned*>(pl_ + 2 * VSTR) = __builtin_amdgcn_perm(l1[1], l0[1], 0x05040100u);
+    *reinterpret_cast<unsigned*>(pl_ + 3 * VSTR) = __builtin_amdgcn_perm(l1[1], l0[1], 0x07060302u);
+  }
+  __syncthreads();
+
+  // ---- O^T = V^T P^T --------------------------------------------------------------------------------------------------------------------
+  f32x16 O[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) O[e][u][i] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    bf16x8 ph[2], pl[2], vh[2][2], vl[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      u32x2 ph0, pl0, ph1, pl1;
+      split4_bf16(f32x4{S[t][8 * u], S[t][8 * u + 1], S[t][8 * u + 2], S[t][8 * u + 3]}, ph0, pl0);
+      split4_bf16(f32x4{S[t][8 * u + 4], S[t][8 * u + 5], S[t][8 * u + 6], S[t][8 * u + 7]}, ph1, pl1);
+      ph[u] = __builtin_bit_cast(bf16x8, u32x4{ph0[0], ph0[1], ph1[0], ph1[1]});
+      pl[u] = __builtin_bit_cast(bf16x8, u32x4{pl0[0], pl0[1], pl1[0], pl1[1]});
+      const int key0 = t * 32 + 16 * u + 4 * h2;          // k-slots: keys key0..+3 and key0+8..+11
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int o = (32 * e + l31) * VSTR + key0 * 2;
+        const unsigned* hp = reinterpret_cast<const unsigned*>(Vhi + o);
+        const unsigned* lp = reinterpret_cast<const unsigned*>(Vlo + o);
+        vh[e][u] = __builtin_bit_cast(bf16x8, u32x4{hp[0], hp[1], hp[4], hp[5]});
+        vl[e][u] = __builtin_bit_cast(bf16x8, u32x4{lp[0], lp[1], lp[4], lp[5]});
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) O[e][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[e][u], ph[u], O[e][u], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) O[e][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[e][u], pl[u], O[e][u], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) O[e][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[e][u], ph[u], O[e][u], 0, 0, 0);
+  }
+
+  if (q_ok) {
+    const float inv = 1.0f / l;
+    float* op = a.out + ((long)b * T + q_tok) * (a.nh * DH) + head * DH;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (O[e][0][4 * g + u] + O[e][1][4 * g + u]) * inv;
+        *reinterpret_cast<f32x4*>(op + e * 32 + 8 * g + 4 * h2) = v;
+      }
+  }
+}
+
+template <int NT>
+static int launch_global_split(const DenseArgs& a, int prep, long nblocks, hipStream_t s) {
+  constexpr int TP = NT * 32, VSTR = TP * 2 + 4;
+  constexpr int lds = 2 * (TP * 128 > DH * VSTR ? TP * 128 : DH * VSTR);
+  LaunchScope prof("attn_global_bf16x3", 4.0 * (double)nblocks * a.T * a.T * DH, 4.0 * (double)a.batch * a.T * a.nh * DH * 4.0, s);
+  if (prep) {
+    auto k = attn_global_split_kernel<NT, true>;
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(NT * 64), lds, s, a);
+  } else {
+    auto k = attn_global_split_kernel<NT, false>;
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(NT * 64), lds, s, a);
+  }
+  return check_launch("kd_attn_global_f32");
+}
+
 template <int MODE, int MAXT>
 static int launch_dense(const DenseArgs& a, int prep, long nblocks, const char* name, hipStream_t s) {
   const size_t lds = (size_t)2 * MAXT * 32 * LDS_ROW * sizeof(float);
@@ -669,6 +919,14 @@ extern "C" int kd_attn_global_f32(const float* qkv, float* out, int batch, int T
   DenseArgs a{qkv, out, scale_h, cos_t, sin_t, batch, T, nh, 0, 0, 0, 0, eps};
   const long nb = (long)batch * nh;
   hipStream_t s = (hipStream_t)stream;
+  // default: split-bf16x3 MFMA core (like the GEMMs); KDIFF_GEMM=exact keeps the exact-fp32 MFMA core
+  const char* mode = getenv("KDIFF_GEMM");                    // read per call (tests switch modes inside one process)
+  const bool exact = mode && !strcmp(mode, "exact");
+  if (!exact) {
+    if (T <= 64) return launch_global_split<2>(a, prep, nb, s);
+    if (T <= 128) return launch_global_split<4>(a, prep, nb, s);
+    return launch_global_split<8>(a, prep, nb, s);
+  }
   if (T <= 64) return launch_dense<MODE_GLOBAL, 2>(a, prep, nb, "attn_global_f32", s);
   if (T <= 128) return launch_dense<MODE_GLOBAL, 4>(a, prep, nb, "attn_global_f32", s);
   return launch_dense<MODE_GLOBAL, 8>(a, prep, nb, "attn_global_f32", s);

@@ -189,7 +189,7 @@ class _Plan:
             d.M, d.N, d.K, d.a_mode, d.epi = M, N, K, a_mode, epi
             d.precision = precision
             if precision == nat.PREC_SPLIT3:
-                d.Wp = ops.pack_weight(Wt, N, K, epi == nat.EPI_GEGLU).data_ptr()
+                d.Wp = m._packed_image(Wt, N, K, epi == nat.EPI_GEGLU).data_ptr()
             d.norm = 1 if scale_ptr is not None else 0
             d.rows_per_sample, d.scale_stride = rows_per_sample, scale_stride
             d.gh, d.gw = grid
@@ -357,7 +357,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
                                      for a, b in zip(levels[:-1], levels[1:])])
         self.out_norm = _rms_scale(levels[0].width)
         self.patch_out = _Holder(proj=_linear_weight(out_channels * ph * pw, levels[0].width, zero=True))
-        self._plans, self._fingerprint = {}, None
+        self._plans, self._fingerprint, self._packed = {}, None, {}
 
     # ---- bookkeeping ---------------------------------------------------------------------------
     def _ada_norm_modules(self):
@@ -382,6 +382,16 @@ class ImageTransformerDenoiserModelV2(nn.Module):
             pos = axial_rope.downscale_pos(pos)
         cos_t, sin_t = axial_rope.rope_tables(pos, sa.pos_emb.freqs)
         return cos_t.to(device), sin_t.to(device)
+
+    def _packed_image(self, W, N, K, geglu):
+        """Packed split-bf16 image of a weight, shared by all plans of this model.  The entry keeps the source tensor
+        alive, so its address cannot be recycled under the cached image; the dict is dropped with the plans whenever
+        the weights change (``_weights_fingerprint``)."""
+        key = (id(W), N, K, bool(geglu))
+        ent = self._packed.get(key)
+        if ent is None:
+            ent = self._packed[key] = (W, ops.pack_weight(W, N, K, geglu, cache=False))
+        return ent[1]
 
     def _weights_fingerprint(self):
         return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
@@ -416,7 +426,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         B, _, H, W = x.shape
         fp = self._weights_fingerprint()
         if fp != self._fingerprint:
-            self._plans, self._fingerprint = {}, fp
+            self._plans, self._fingerprint, self._packed = {}, fp, {}
         has_class = self.class_emb is not None
         key = (B, H, W, aug_cond is not None, has_class, self.mapping_cond_in_proj is not None, x.device, nat.default_precision())
         plan = self._plans.get(key)

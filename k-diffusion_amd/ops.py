@@ -12,6 +12,7 @@ The op names mirror the reference functions they replace
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -43,19 +44,26 @@ _GEMM_DEBUG = int(os.environ.get("KD_GEMM_DEBUG", "0"))      # profiling ablatio
 
 
 def pack_weight(W, N, K, geglu, cache=True):
-    """Packed split-bf16 image of a weight for KD_PREC_SPLIT3 (uint8 tensor).  Weights are static while
-    sampling, so the image is cached per (storage, version, shape)."""
-    key = (W.data_ptr(), W._version, tuple(W.shape), N, K, bool(geglu))
-    img = _packed.get(key) if cache else None
-    if img is None:
-        _chk(W, "W")
-        lib = nat.lib()
-        img = torch.empty(lib.kd_packed_weight_bytes(N, K, int(geglu)), device=W.device, dtype=torch.uint8)
-        nat.check(lib.kd_pack_weight_bf16x3(_p(W), _p(img), N, K, int(geglu), _stream()), "kd_pack_weight_bf16x3")
-        if cache:
+    """Packed split-bf16 image of a weight for KD_PREC_SPLIT3 (uint8 tensor).  Weights are static while sampling, so
+    the image is cached per tensor OBJECT (weak reference + version counter: a new tensor that happens to reuse the
+    address of a freed one never hits a stale image)."""
+    key = id(W)
+    ent = _packed.get(key) if cache else None
+    if ent is not None:
+        ref, version, meta, img = ent
+        if ref() is W and version == W._version and meta == (tuple(W.shape), N, K, bool(geglu), W.data_ptr()):
+            return img
+    _chk(W, "W")
+    lib = nat.lib()
+    img = torch.empty(lib.kd_packed_weight_bytes(N, K, int(geglu)), device=W.device, dtype=torch.uint8)
+    nat.check(lib.kd_pack_weight_bf16x3(_p(W), _p(img), N, K, int(geglu), _stream()), "kd_pack_weight_bf16x3")
+    if cache:
+        if len(_packed) > 512:
+            for k in [k for k, e in _packed.items() if e[0]() is None]:
+                del _packed[k]
             if len(_packed) > 512:
                 _packed.clear()
-            _packed[key] = img
+        _packed[key] = (weakref.ref(W), W._version, (tuple(W.shape), N, K, bool(geglu), W.data_ptr()), img)
     return img
 
 

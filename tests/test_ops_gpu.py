@@ -198,7 +198,7 @@ def test_qk_prep_inplace(ops, golden):
 
 
 @pytest.mark.parametrize("fused", [False, True])
-def test_attention_vs_reference_golden(ops, golden, fused):
+def test_attention_vs_reference_golden(ops, golden, gtol, fused):
     o = golden["ops"]
     cos, sin = _tables(16, 16, 2)
     prep = (g(o["qk.scale"]), g(cos), g(sin))
@@ -209,7 +209,7 @@ def test_attention_vs_reference_golden(ops, golden, fused):
         qkv = g(_pack(o["qk.q_out"], o["qk.k_out"], o["qk.v"]))
         kw = {}
     y = ops.attn_global(qkv.view(2, 256, -1), 2, **kw).view(2, 16, 16, 2, 64)
-    assert relerr(y, o["attn_global.o"]) < 2e-5
+    assert relerr(y, o["attn_global.o"]) < gtol        # exact: fp32 MFMA core; split3: bf16x3 core
     for shift in (0, 4):
         y = ops.attn_window(qkv, 2, 8, shift, **kw).view(2, 16, 16, 2, 64)
         assert relerr(y, o[f"attn_window{shift}.o"]) < 2e-5, shift
@@ -226,11 +226,11 @@ def test_window_attention_rect(ops, golden):
 
 
 @pytest.mark.parametrize("T,nh,B", [(49, 4, 3), (64, 8, 2), (100, 1, 2), (256, 2, 2), (7, 1, 1)])
-def test_attn_global_sizes(ops, T, nh, B):
+def test_attn_global_sizes(ops, gtol, T, nh, B):
     q, k, v = (rn(B, 1, T, nh, 64, seed=s, scale=sc) for s, sc in ((1, 0.6), (2, 0.6), (3, 1.0)))
     ref = hdit.attn_global(q, k, v, 1.0)
     y = ops.attn_global(g(_pack(q, k, v)).view(B, T, -1), nh).view(B, 1, T, nh, 64)
-    assert relerr(y, ref) < 2e-5
+    assert relerr(y, ref) < gtol
     with pytest.raises(RuntimeError, match="256"):
         ops.attn_global(g(rn(1, 300, 192)), 1)
 
