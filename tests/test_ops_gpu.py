@@ -146,7 +146,7 @@ def test_wide_projections_a_stationary(ops, monkeypatch, M, K, N, kind):
 
 
 @pytest.mark.parametrize("M,K,N", [(1024, 256, 256), (2048, 512, 512), (700, 128, 256)])
-def test_a_stationary_residual(ops, monkeypatch, M, K, N):
+def test_residual_in_place_multi_tile(ops, monkeypatch, M, K, N):
     monkeypatch.setenv("KDIFF_GEMM", "split3")
     x, w, r = rn(M, K, seed=1), rn(N, K, seed=2) / K ** 0.5, rn(M, N, seed=3)
     assert relerr(ops.linear(g(x), g(w), residual=g(r)), x @ w.T + r) < 1e-4
@@ -155,8 +155,8 @@ def test_a_stationary_residual(ops, monkeypatch, M, K, N):
 
 
 @pytest.mark.parametrize("B,h,w,K,C", [(2, 16, 16, 256, 128), (1, 32, 16, 512, 256), (3, 16, 12, 128, 64)])
-def test_a_stationary_token_split(ops, monkeypatch, B, h, w, K, C):
-    """TokenSplit (Linear -> depth-to-space -> lerp with the skip) through the A-stationary kernel's scatter epilogue."""
+def test_token_split_multi_tile(ops, monkeypatch, B, h, w, K, C):
+    """TokenSplit (Linear -> depth-to-space -> lerp with the skip) at multi-tile shapes (several m- and n-tiles)."""
     monkeypatch.setenv("KDIFF_GEMM", "split3")
     x, wt, skip = rn(B, h, w, K, seed=1), rn(4 * C, K, seed=2) / K ** 0.5, rn(B, 2 * h, 2 * w, C, seed=3)
     for fac in (0.3, 0.75):
