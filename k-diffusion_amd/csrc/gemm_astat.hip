@@ -132,49 +132,65 @@ __global__ __launch_bounds__(256, NC == 8 ? 2 : 1) void gemm_astat_kernel(const 
   // ---- epilogue of n-tile nt: acc (32 rows x 128 W-rows) -> strips -> global ------------------------------------------------
   auto epilogue = [&](int nt) {
     const int n0 = (nt_begin + nt) * NCOL;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int row_base = m0 + wid * 32 + 8 * g;
-#pragma unroll
-      for (int half = 0; half < (GEGLU ? 1 : 2); ++half) {
-        // registers of rows 8g..8g+7 -> strip[8][64]
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = 4 * g + q, row8 = q + 4 * lh;
-          if (GEGLU) {
-            strip[row8 * 64 + l31] = (acc[0][r] * rsv[r]) * gelu_erf_fast(acc[1][r] * rsv[r]);
-            strip[row8 * 64 + 32 + l31] = (acc[2][r] * rsv[r]) * gelu_erf_fast(acc[3][r] * rsv[r]);
-          } else {
-            strip[row8 * 64 + l31] = acc[2 * half][r] * rsv[r];
-            strip[row8 * 64 + 32 + l31] = acc[2 * half + 1][r] * rsv[r];
-          }
-        }
-        // strip -> global: lane owns (row8, 4 columns), 2 items per lane
-        const int vec = (n0 + half * 64) >> 6;                 // qkv: these 64 columns are ONE (q|k|v, head) vector of a row
-        const int which = EPI == KD_EPI_QKV ? vec / p.n_heads : 2, head = EPI == KD_EPI_QKV ? vec - which * p.n_heads : 0;
-        f32x4 cs[2], sn[2];
-        if (EPI == KD_EPI_QKV && which < 2) {
-          // RoPE table chunks of both items, requested before the strip round trip (branch-free: lanes >= 8 of a
-          // 16-lane row group re-read chunk c & 3, unused)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const int row8 = (lane + 64 * t) >> 4;
-            const int tok = min(tok0 + 8 * g + row8, p.rows_per_sample - 1);
-            const long tr = ((long)tok * p.n_heads + head) * KD_ROT + 4 * (lane & 3);
-            cs[t] = *reinterpret_cast<const f32x4*>(p.rope_cos + tr);
-            sn[t] = *reinterpret_cast<const f32x4*>(p.rope_sin + tr);
-          }
-        }
+    constexpr int NPASS = GEGLU ? 4 : 8;                       // (8-row group g, 64-column half) passes
+    // qkv: the 64 columns of a pass are ONE (q|k|v, head) vector of a row.  The RoPE table chunks of pass i+1 are
+    // requested while pass i goes through its strip (one pass ahead: 16 VGPRs), so that their latency -- and the
+    // in-order wait behind the W stages still in flight -- is paid once per n-tile instead of once per pass.
+    auto qk_of = [&](int half, int& which, int& head) {
+      const int vec = (n0 + half * 64) >> 6;
+      which = vec / p.n_heads;
+      head = vec - which * p.n_heads;
+    };
+    auto load_tab = [&](int pass, f32x4 (&cs)[2], f32x4 (&sn)[2]) {
+      const int g = GEGLU ? pass : pass >> 1, half = GEGLU ? 0 : pass & 1;
+      int which, head;
+      qk_of(half, which, head);
+      if (which < 2) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const int idx = lane + 64 * t, row8 = idx >> 4, c4 = (idx & 15) * 4;
-          const int gm = row_base + row8, gn = n0 + half * 64 + c4;
-          f32x4 v = *reinterpret_cast<const f32x4*>(strip + row8 * 64 + c4);
-          if (EPI == KD_EPI_QKV && which < 2) v = prep_row16_regs(v, lane & 15, sq_tab[head], cs[t], sn[t], p.eps);
-          if (EPI == KD_EPI_STORE) v = v + p.out_add;
-          if (gm < M) *reinterpret_cast<f32x4*>(p.C + (long)gm * N + gn) = v;
+          const int row8 = (lane + 64 * t) >> 4;
+          const int tok = min(tok0 + 8 * g + row8, p.rows_per_sample - 1);
+          const long tr = ((long)tok * p.n_heads + head) * KD_ROT + 4 * (lane & 3);   // lanes >= 8 of a row group re-read chunk c & 3, unused
+          cs[t] = *reinterpret_cast<const f32x4*>(p.rope_cos + tr);
+          sn[t] = *reinterpret_cast<const f32x4*>(p.rope_sin + tr);
         }
       }
+    };
+    f32x4 csA[2], snA[2], csB[2], snB[2];
+    if (EPI == KD_EPI_QKV) load_tab(0, csA, snA);
+    auto one_pass = [&](int pass, f32x4 (&cs)[2], f32x4 (&sn)[2], f32x4 (&cs_next)[2], f32x4 (&sn_next)[2]) {
+      const int g = GEGLU ? pass : pass >> 1, half = GEGLU ? 0 : pass & 1;
+      const int row_base = m0 + wid * 32 + 8 * g;
+      if (EPI == KD_EPI_QKV && pass + 1 < NPASS) load_tab(pass + 1, cs_next, sn_next);
+      // registers of rows 8g..8g+7 -> strip[8][64]
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 4 * g + q, row8 = q + 4 * lh;
+        if (GEGLU) {
+          strip[row8 * 64 + l31] = (acc[0][r] * rsv[r]) * gelu_erf_fast(acc[1][r] * rsv[r]);
+          strip[row8 * 64 + 32 + l31] = (acc[2][r] * rsv[r]) * gelu_erf_fast(acc[3][r] * rsv[r]);
+        } else {
+          strip[row8 * 64 + l31] = acc[2 * half][r] * rsv[r];
+          strip[row8 * 64 + 32 + l31] = acc[2 * half + 1][r] * rsv[r];
+        }
+      }
+      int which = 2, head = 0;
+      if (EPI == KD_EPI_QKV) qk_of(half, which, head);
+      // strip -> global: lane owns (row8, 4 columns), 2 items per lane
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int idx = lane + 64 * t, row8 = idx >> 4, c4 = (idx & 15) * 4;
+        const int gm = row_base + row8, gn = n0 + half * 64 + c4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(strip + row8 * 64 + c4);
+        if (EPI == KD_EPI_QKV && which < 2) v = prep_row16_regs(v, lane & 15, sq_tab[head], cs[t], sn[t], p.eps);
+        if (EPI == KD_EPI_STORE) v = v + p.out_add;
+        if (gm < M) *reinterpret_cast<f32x4*>(p.C + (long)gm * N + gn) = v;
+      }
+    };
+#pragma unroll
+    for (int pass = 0; pass < NPASS; pass += 2) {
+      one_pass(pass, csA, snA, csB, snB);
+      one_pass(pass + 1, csB, snB, csA, snA);
     }
   };
 

@@ -32,6 +32,12 @@ class Denoiser(nn.Module):
     def loss(self, *args, **kwargs):
         raise NotImplementedError('training losses are outside this package\'s scope (sampling hot path only)')
 
+    def prefetch_conditioning(self, x_like, sigma, **kwargs):
+        """Solver-loop hint (see ImageTransformerDenoiserModelV2.prefetch_conditioning); a no-op for foreign inner models."""
+        hint = getattr(self.inner_model, 'prefetch_conditioning', None)
+        if hint is not None:
+            hint(x_like, sigma, **kwargs)
+
     def forward(self, input, sigma, **kwargs):
         inner = self.inner_model
         fused = getattr(inner, 'forward_preconditioned', None)

@@ -15,12 +15,15 @@ device->host sync per step, sampling.py:594-606):
   * the per-step sigma vectors handed to the model are rows of one table uploaded before the loop.
 """
 import math
+import os
 
 import torch
 from tqdm.auto import trange
 
 from . import _native as nat
 from . import ops, utils
+
+_COND_PREFETCH = os.environ.get('KDIFF_COND_PREFETCH', '1') != '0'      # A/B switch (benchmarks/): side-stream conditioning
 
 # --------------------------------------------------------------------------------- schedules
 
@@ -159,8 +162,16 @@ class _Loop:
         v = torch.stack([torch.as_tensor(s, dtype=torch.float32).reshape(()) for s in values])
         return v.to(self.x.device)[:, None].expand(len(values), self.B).contiguous()
 
-    def denoise(self, sigma_row, x=None):
-        return self.model(self.x if x is None else x, sigma_row, **self.extra).contiguous()
+    def denoise(self, sigma_row, x=None, next_row=None):
+        """model(x, sigma).  ``next_row``: the sigma vector of the NEXT model call, when the loop knows it: the
+        conditioning chain of that call (a function of sigma / class / ... only) is then started on a side stream now,
+        behind the main chain just enqueued."""
+        den = self.model(self.x if x is None else x, sigma_row, **self.extra).contiguous()
+        if next_row is not None and _COND_PREFETCH:
+            hint = getattr(self.model, 'prefetch_conditioning', None)
+            if hint is not None:
+                hint(self.x, next_row, **self.extra)
+        return den
 
     def report(self, i, denoised, sigma_hat=None):
         if self.callback is not None:
@@ -205,7 +216,7 @@ def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None,
     rows = lp.sigma_rows(hats)
     for i in trange(len(lp), disable=disable):
         _apply_churn(lp, i, gammas[i], hats[i], s_noise)
-        den = lp.denoise(rows[i])
+        den = lp.denoise(rows[i], next_row=rows[i + 1] if i + 1 < len(lp) else None)
         lp.report(i, den, hats[i])
         lp.update(nat.STEP_EULER, den, c0=hats[i], c1=sig[i + 1] - hats[i])
     return lp.x
@@ -238,14 +249,15 @@ def sample_heun(model, x, sigmas, extra_args=None, callback=None, disable=None, 
     d, x_2 = lp.fresh(), lp.fresh()
     for i in trange(len(lp), disable=disable):
         _apply_churn(lp, i, gammas[i], hats[i], s_noise)
-        den = lp.denoise(rows[i])
+        last = sig[i + 1] == 0
+        den = lp.denoise(rows[i], next_row=None if last else rows_next[i])
         lp.report(i, den, hats[i])
         dt = sig[i + 1] - hats[i]
-        if sig[i + 1] == 0:
+        if last:
             lp.update(nat.STEP_EULER, den, c0=hats[i], c1=dt)
         else:
             ops.sampler_step(nat.STEP_HEUN_PRED, lp.x, den, out=x_2, aux=d, c0=_f(hats[i]), c1=_f(dt))
-            den_2 = lp.denoise(rows_next[i], x_2)
+            den_2 = lp.denoise(rows_next[i], x_2, next_row=rows[i + 1] if i + 1 < len(lp) else None)
             lp.update(nat.STEP_HEUN_CORR, den_2, in2=x_2, aux=d, c0=sig[i + 1], c1=dt)
     return lp.x
 
@@ -424,7 +436,7 @@ def sample_dpmpp_2m(model, x, sigmas, extra_args=None, callback=None, disable=No
     rows = lp.sigma_rows(sig[:-1])
     old = None
     for i in trange(len(lp), disable=disable):
-        den = lp.denoise(rows[i])
+        den = lp.denoise(rows[i], next_row=rows[i + 1] if i + 1 < len(lp) else None)
         lp.report(i, den)
         t, t_next = t_fn(sig[i]), t_fn(sig[i + 1])
         h = t_next - t
