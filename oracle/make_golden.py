@@ -78,6 +78,10 @@ def scalar_kats():
     it = iter(noise)
     kat["solver_toy_euler_ancestral_recorded"] = hexf(
         S.sample_euler_ancestral(toy, xt, sig20, disable=True, noise_sampler=lambda a, b: next(it)))
+    it = iter(noise)
+    kat["solver_toy_3m_sde_recorded"] = hexf(S.sample_dpmpp_3m_sde(toy, xt, sig20, disable=True, noise_sampler=lambda a, b: next(it)))
+    it = iter(noise)
+    kat["solver_toy_2m_sde_recorded"] = hexf(S.sample_dpmpp_2m_sde(toy, xt, sig20, disable=True, noise_sampler=lambda a, b: next(it)))
     # the reference's merged configs (config.py:23-146 defaulting) for the four shipped v2 configs
     kat["merged_configs"] = {}
     for name in ("config_mnist_transformer.json", "config_cifar10_transformer.json",
