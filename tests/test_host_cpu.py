@@ -89,6 +89,34 @@ def test_configs_merge_like_the_reference(KD, golden):
         assert got["dataset"]["num_classes"] == ref["dataset"]["num_classes"], name
 
 
+def test_checkpoint_tools_round_trip(KD, tmp_path):
+    """Training checkpoint -> slim inference checkpoint (safetensors + config metadata) -> config / weights back
+    (convert_for_inference.py, config_from_inference.py, config.py:113-115, sample.py:33,44)."""
+    import json
+    import safetensors.torch as safetorch
+    sys.path.insert(0, REPO)
+    import config_from_inference
+    import convert_for_inference
+    raw = json.load(open(os.path.join(REPO, "configs", "config_mnist_transformer.json")))
+    model = KD.config.make_model(KD.config.load_config(raw))
+    sd = KD.synth.synth_state_dict(model.state_dict(), seed=3)
+    pth = tmp_path / "run_00001000.pth"
+    torch.save({"config": raw, "model_ema": sd, "step": 1000}, pth)
+    convert_for_inference.main([str(pth), "--dtype", "bf16"])
+    slim = pth.with_suffix(".safetensors")
+    assert slim.exists()
+    cfg = KD.config.load_config(slim)                                 # config straight from the checkpoint's metadata
+    assert cfg["model"]["widths"] == raw["model"]["widths"]
+    loaded = safetorch.load_file(str(slim))
+    assert set(loaded) == set(sd) and all(v.dtype == torch.bfloat16 for k, v in loaded.items() if sd[k].is_floating_point())
+    model.load_state_dict(loaded)                                     # upcast to the fp32 parameters on load
+    assert model.patch_in.proj.weight.dtype == torch.float32
+    config_from_inference.main([str(slim), "-o", str(tmp_path / "c.json")])
+    assert json.load(open(tmp_path / "c.json")) == raw
+    with pytest.raises(ValueError, match="No configuration"):
+        KD.checkpoint.write_inference_checkpoint(sd, None, tmp_path / "x.safetensors")
+
+
 def test_sample_cli_contract():
     sys.path.insert(0, REPO)
     import sample
