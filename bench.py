@@ -81,7 +81,7 @@ def family_roofline(name, g, split3, total_ms):
     # attention cores (global / window) run on the exact fp32 MFMA; the neighbourhood core is a split-bf16 kernel too
     if is_gemm:
         mult, peak = (3.0, BF16_MFMA_PEAK_TFLOPS) if split3 and not name.startswith("gemm_f32") else (1.0, FP32_MFMA_PEAK_TFLOPS)
-    elif name.startswith("attn_na2d"):
+    elif name.startswith("attn_na2d") or "bf16x3" in name:
         mult, peak = 3.0, BF16_MFMA_PEAK_TFLOPS
     elif is_attn:
         mult, peak = 1.0, FP32_MFMA_PEAK_TFLOPS
