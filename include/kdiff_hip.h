@@ -161,6 +161,13 @@ int kd_precond_in_f32(const float* x, const float* sigma, float* y, float sigma_
 int kd_precond_out_f32(const float* f, const float* x, const float* sigma, float* y, float sigma_data, int batch,
                        long long per_sample, void* stream);
 
+/* Foreign-model wrappers (k_diffusion/external.py): the image-sized arithmetic of their forward()s,
+ *   y[b, :] = f[b, :] * a[b] (+ x[b, :] * c[b] when x != NULL)          (:38, :113, :162)
+ * and the discrete schedule's sigma <-> t maps over an ascending table log_sigmas[n] (:66-84). */
+int kd_rows_affine_f32(const float* f, const float* x, const float* a, const float* c, float* y, int batch, long long per_sample, void* stream);
+int kd_sigma_to_t_f32(const float* sigma, const float* log_sigmas, float* t, int count, int n, int quantize, void* stream);
+int kd_t_to_sigma_f32(const float* t, const float* log_sigmas, float* sigma, int count, int n, void* stream);
+
 /* Brownian-interval noise (stands in for torchsde.BrownianTree behind
  * k_diffusion/sampling.py:65-114): out[b, i] = sign * (W_b,i(t1) - W_b,i(t0)) * inv_norm where W is
  * a virtual Brownian tree on [T0, T1] (depth-`depth` dyadic bridge, Philox4x32-10 keyed by

@@ -5,7 +5,7 @@ K.sampling, K.layers / K.Denoiser, K.config, K.models, K.evaluation, K.utils (+ 
 K.ops, K.synth).  Importing the package never needs a GPU; the first kernel call loads
 csrc/libkdiff_hip.so and fails loudly if it is missing (there is no CPU fallback).
 """
-from . import _native, checkpoint, config, distributed, evaluation, layers, models, ops, sampling, synth, utils  # noqa: F401
+from . import _native, checkpoint, config, distributed, evaluation, external, layers, models, ops, sampling, synth, utils  # noqa: F401
 from .layers import Denoiser  # noqa: F401
 
 __version__ = "0.1.0"

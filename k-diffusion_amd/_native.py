@@ -59,6 +59,9 @@ SIGNATURES = {
     "kd_sampler_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _ll, _vp],
     "kd_precond_in_f32": [_vp, _vp, _vp, _f, _i, _ll, _vp],
     "kd_precond_out_f32": [_vp, _vp, _vp, _vp, _f, _i, _ll, _vp],
+    "kd_rows_affine_f32": [_vp, _vp, _vp, _vp, _vp, _i, _ll, _vp],
+    "kd_sigma_to_t_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "kd_t_to_sigma_f32": [_vp, _vp, _vp, _i, _i, _vp],
     "kd_brownian_f32": [_vp, _vp, _i, _ll, _d, _d, _d, _d, _f, _i, _vp],
     "kd_to_uint8": [_vp, _vp, _ll, _vp],
     "kd_prof_enable": [_i],

@@ -89,6 +89,51 @@ __global__ __launch_bounds__(EW_BLOCK) void precond_out_kernel(const float* __re
   }
 }
 
+// y = f * a[b] (+ x * c[b]): the image-sized part of the foreign-model wrappers (k_diffusion/external.py forward()s)
+__global__ __launch_bounds__(EW_BLOCK) void rows_affine_kernel(const float* __restrict__ f, const float* __restrict__ x, const float* __restrict__ a,
+                                                               const float* __restrict__ c, float* y, int batch, long per_sample) {
+  const long n = (long)batch * per_sample;
+  for (long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * EW_BLOCK) {
+    const long b = i / per_sample;
+    const float v = mul(f[i], a[b]);
+    y[i] = x ? add(v, mul(x[i], c[b])) : v;
+  }
+}
+
+// DiscreteSchedule.sigma_to_t (external.py:66-78): position of log(sigma) in the ascending table log_sigmas[n], linearly
+// interpolated (clamped to the table) or, quantized, the index of the nearest entry
+__global__ __launch_bounds__(256) void sigma_to_t_kernel(const float* __restrict__ sigma, const float* __restrict__ log_sigmas, float* t, int count, int n, int quantize) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const float ls = logf(sigma[i]);
+  int lo = 0, hi = n;                       // number of table entries <= ls (upper bound)
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (log_sigmas[mid] <= ls) lo = mid + 1; else hi = mid; }
+  if (quantize) {
+    int best = lo > 0 ? lo - 1 : 0;         // nearest of the two neighbours; ties resolve to the lower index like argmin
+    if (lo < n && (lo == 0 || fabsf(log_sigmas[lo] - ls) < fabsf(ls - log_sigmas[lo - 1]))) best = lo;
+    t[i] = (float)best;
+    return;
+  }
+  int low_idx = lo > 0 ? lo - 1 : 0;
+  if (low_idx > n - 2) low_idx = n - 2;
+  const float low = log_sigmas[low_idx], high = log_sigmas[low_idx + 1];
+  float w = dvd(sub(low, ls), sub(low, high));
+  w = fminf(fmaxf(w, 0.f), 1.f);
+  t[i] = add(mul(sub(1.f, w), (float)low_idx), mul(w, (float)(low_idx + 1)));
+}
+
+// DiscreteSchedule.t_to_sigma (external.py:80-84)
+__global__ __launch_bounds__(256) void t_to_sigma_kernel(const float* __restrict__ t, const float* __restrict__ log_sigmas, float* sigma, int count, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const float tv = t[i];
+  const float fl = floorf(tv), w = sub(tv, fl);
+  int lo = (int)fl, hi = (int)ceilf(tv);
+  lo = lo < 0 ? 0 : (lo > n - 1 ? n - 1 : lo);
+  hi = hi < 0 ? 0 : (hi > n - 1 ? n - 1 : hi);
+  sigma[i] = expf(add(mul(sub(1.f, w), log_sigmas[lo]), mul(w, log_sigmas[hi])));
+}
+
 // one wave per row
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ scale, float* y, int rows, int d, float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -180,6 +225,27 @@ extern "C" int kd_precond_out_f32(const float* f, const float* x, const float* s
   LaunchScope prof("precond_out_f32", 0, 12.0 * batch * per_sample, s);
   hipLaunchKernelGGL(precond_out_kernel, dim3(ew_grid((long)batch * per_sample)), dim3(EW_BLOCK), 0, s, f, x, sigma, y, sigma_data, batch, (long)per_sample);
   return check_launch("kd_precond_out_f32");
+}
+
+extern "C" int kd_rows_affine_f32(const float* f, const float* x, const float* a, const float* c, float* y, int batch, long long per_sample,
+                                  void* stream) {
+  if (!f || !a || !y || batch <= 0 || per_sample <= 0 || (x && !c)) return fail(KD_EINVAL, "kd_rows_affine_f32: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope prof("rows_affine_f32", 0, (x ? 12.0 : 8.0) * batch * per_sample, s);
+  hipLaunchKernelGGL(rows_affine_kernel, dim3(ew_grid((long)batch * per_sample)), dim3(EW_BLOCK), 0, s, f, x, a, c, y, batch, (long)per_sample);
+  return check_launch("kd_rows_affine_f32");
+}
+
+extern "C" int kd_sigma_to_t_f32(const float* sigma, const float* log_sigmas, float* t, int count, int n, int quantize, void* stream) {
+  if (!sigma || !log_sigmas || !t || count <= 0 || n < 2) return fail(KD_EINVAL, "kd_sigma_to_t_f32: bad arguments (table needs >= 2 entries)");
+  hipLaunchKernelGGL(sigma_to_t_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, sigma, log_sigmas, t, count, n, quantize);
+  return check_launch("kd_sigma_to_t_f32");
+}
+
+extern "C" int kd_t_to_sigma_f32(const float* t, const float* log_sigmas, float* sigma, int count, int n, void* stream) {
+  if (!t || !log_sigmas || !sigma || count <= 0 || n < 1) return fail(KD_EINVAL, "kd_t_to_sigma_f32: bad arguments");
+  hipLaunchKernelGGL(t_to_sigma_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, log_sigmas, sigma, count, n);
+  return check_launch("kd_t_to_sigma_f32");
 }
 
 extern "C" int kd_rmsnorm_f32(const float* x, const float* scale, float* y, int rows, int d, float eps, void* stream) {

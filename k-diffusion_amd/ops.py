@@ -291,6 +291,30 @@ def precond_out(f, x, sigma, sigma_data, out=None):
     return out
 
 
+def rows_affine(f, a, x=None, c=None, out=None):
+    """y[b] = f[b] * a[b] (+ x[b] * c[b]): per-sample scalars over image-sized tensors (external.py forward()s)."""
+    out = torch.empty_like(f) if out is None else out
+    B = f.shape[0]
+    nat.check(nat.lib().kd_rows_affine_f32(_p(_chk(f, "f")), _p(None if x is None else _chk(x, "x")), _p(_chk(a, "a")),
+                                       _p(None if c is None else _chk(c, "c")), _p(_chk(out, "y")), B, f.numel() // B, _stream()),
+            "kd_rows_affine_f32")
+    return out
+
+
+def sigma_to_t(sigma, log_sigmas, quantize):
+    out = torch.empty(sigma.shape, device=sigma.device, dtype=torch.float32)
+    nat.check(nat.lib().kd_sigma_to_t_f32(_p(_chk(sigma.contiguous(), "sigma")), _p(_chk(log_sigmas, "log_sigmas")), _p(out), sigma.numel(),
+                                      log_sigmas.numel(), int(bool(quantize)), _stream()), "kd_sigma_to_t_f32")
+    return out
+
+
+def t_to_sigma(t, log_sigmas):
+    out = torch.empty(t.shape, device=t.device, dtype=torch.float32)
+    nat.check(nat.lib().kd_t_to_sigma_f32(_p(_chk(t.contiguous(), "t")), _p(_chk(log_sigmas, "log_sigmas")), _p(out), t.numel(), log_sigmas.numel(),
+                                      _stream()), "kd_t_to_sigma_f32")
+    return out
+
+
 def brownian(out, seeds, T0, T1, t0, t1, mult, depth=36):
     """out[b, ...] = (W_b(t1) - W_b(t0)) * mult, one virtual Brownian tree per batch item (seeds: uint64 [B])."""
     B = out.shape[0]

@@ -82,6 +82,21 @@ def scalar_kats():
     kat["solver_toy_3m_sde_recorded"] = hexf(S.sample_dpmpp_3m_sde(toy, xt, sig20, disable=True, noise_sampler=lambda a, b: next(it)))
     it = iter(noise)
     kat["solver_toy_2m_sde_recorded"] = hexf(S.sample_dpmpp_2m_sde(toy, xt, sig20, disable=True, noise_sampler=lambda a, b: next(it)))
+    # foreign-model wrappers (external.py) on a linear-beta DDPM schedule with analytic inner models
+    E = K.external
+    acp = torch.cumprod(1 - torch.linspace(1e-4, 2e-2, 1000), dim=0)
+    inner = lambda x, t, **kw: torch.tanh(x) * (1 + t.float().view(-1, 1, 1, 1) / 1000)
+    sq = torch.tensor([0.03, 0.5, 2.7, 14.0, 200.0, 0.001])
+    tq = torch.tensor([0.0, 0.5, 10.25, 998.9, 999.0])
+    xe = torch.randn(2, 3, 4, 4, generator=torch.Generator().manual_seed(9)) * 5
+    se = torch.tensor([0.7, 9.0])
+    eps_w, v_w, vd = E.DiscreteEpsDDPMDenoiser(inner, acp, quantize=False), E.DiscreteVDDPMDenoiser(inner, acp, quantize=False), E.VDenoiser(inner)
+    kat["external"] = {
+        "sigma_to_t": hexf(eps_w.sigma_to_t(sq)), "sigma_to_t_quantized": hexf(eps_w.sigma_to_t(sq, quantize=True).float()),
+        "t_to_sigma": hexf(eps_w.t_to_sigma(tq)), "get_sigmas_10": hexf(eps_w.get_sigmas(10)), "sigma_min_max": hexf([eps_w.sigma_min, eps_w.sigma_max]),
+        "eps_forward": hexf(eps_w(xe, se)), "v_forward": hexf(v_w(xe, se)), "vdenoiser_forward": hexf(vd(xe, se)),
+        "eps_forward_quantized": hexf(E.DiscreteEpsDDPMDenoiser(inner, acp, quantize=True)(xe, se)),
+    }
     # the reference's merged configs (config.py:23-146 defaulting) for the four shipped v2 configs
     kat["merged_configs"] = {}
     for name in ("config_mnist_transformer.json", "config_cifar10_transformer.json",
