@@ -305,7 +305,15 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
   const int l31 = lane & 31, h2 = lane >> 5;
   const int wy_ = wid >> 1, wx_ = wid & 1;                            // this wave's 4x8 query block
   const int tiles_x = (a.W + NA_TW - 1) / NA_TW, tiles_y = (a.H + NA_TH - 1) / NA_TH;
-  int r = blockIdx.x;
+  // XCD-aware tile order: consecutive workgroups are dealt round-robin over the 8 XCDs (private L2s); give every XCD a
+  // CONTIGUOUS run of tiles so that the halos of neighbouring tiles (2.4x re-read of K and V) hit ONE L2 instead of
+  // being fetched from HBM by eight of them.  Bijective for any grid size; placement never affects correctness.
+  int r;
+  {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int q = nwg >> 3, rem = nwg & 7;
+    r = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
+  }
   const int tx = r % tiles_x; r /= tiles_x;
   const int ty = r % tiles_y; r /= tiles_y;
   const int head = r % a.nh; const int b = r / a.nh;
