@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time for the baseline sample")
     p.add_argument("--no-kernel-events", action="store_true", help="do not record per-launch HIP events in the timed region")
     p.add_argument("--kernel-table", default=None, help="write the per-kernel event timings to this JSON file")
+    p.add_argument("--no-other-configs", action="store_true", help="skip the short secondary measurement of the shifted-window config")
     return p.parse_args()
 
 
@@ -142,6 +143,26 @@ def cpu_baseline(cfg, seed, sampler_steps, target_seconds):
                       f"{dt:.1f} s measured, scaled to {sampler_steps} steps"}
 
 
+def secondary_config(path, dev, args, sampler):
+    cfg = K.config.load_config(os.path.join(REPO, path))
+    mc = cfg["model"]
+    model = build_model(cfg, dev, args.seed)
+    den = K.Denoiser(model, sigma_data=mc["sigma_data"])
+    shape = (mc["input_channels"], *mc["input_size"])
+    x0 = torch.stack([K.synth.synth_noise(shape, args.seed, g, mc["sigma_max"]) for g in range(args.batch)]).to(dev)
+    sigmas = K.sampling.get_sigmas_karras(args.sampler_steps, mc["sigma_min"], mc["sigma_max"], rho=7., device=dev)
+    sampler(den, x0, sigmas, disable=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        out = sampler(den, x0, sigmas, disable=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    return {"value": round(2 * args.batch / dt, 3), "unit": "images/sec", "steps": 2, "warmup": 1, "batch": args.batch,
+            "workload": f"{os.path.basename(path)} {mc['input_size'][0]}x{mc['input_size'][1]}, {args.sampler} {args.sampler_steps} steps"}
+
+
 def main():
     args = parse()
     ctx = K.distributed.RankContext()
@@ -234,6 +255,11 @@ def main():
             "algorithmic_tflops": round(n_img * 2 * mac * (nfe or 0) / dt / 1e12, 2) if nfe else None,
             "roofline": roofline,
         }
+        if args.gpus == 1 and not args.no_other_configs and os.path.basename(args.config) == "config_oxford_flowers.json":
+            # BASELINE configs[2] (the single-GPU 256x256 DPM++2M case with shifted-window attention): same sampler, same
+            # batch, 1 warm-up + 2 timed passes.  Reported beside the headline (configs[3] at 32 images / GPU), not as `value`.
+            result["other_configs"] = {"config_oxford_flowers_shifted_window.json": secondary_config(
+                "configs/config_oxford_flowers_shifted_window.json", dev, args, sampler)}
         if not args.no_cpu_baseline and args.gpus == 1:
             result["cpu_baseline"] = cpu_baseline(cfg, args.seed, args.sampler_steps, args.cpu_seconds)
         print(json.dumps(result), flush=True)

@@ -10,7 +10,7 @@ OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --steps 3 --warmup 1 --kernel-table $OUT/kt_full.json > $OUT/bench_full.json 2> $OUT/bench_full.err
 tail -c 3000 $OUT/bench_full.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o st -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > $OUT/prof_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python $R/bench.py --steps 1 --warmup 0 --sampler-steps 3 --no-cpu-baseline --no-kernel-events > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python $R/bench.py --steps 1 --warmup 0 --sampler-steps 3 --no-cpu-baseline --no-kernel-events > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o st -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-other-configs > $OUT/prof_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python $R/bench.py --steps 1 --warmup 0 --sampler-steps 3 --no-cpu-baseline --no-kernel-events --no-other-configs > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python $R/bench.py --steps 1 --warmup 0 --sampler-steps 3 --no-cpu-baseline --no-kernel-events --no-other-configs > $OUT/pmc_write.log 2>&1
 ls -la $OUT/prof_stats $OUT/pmc_fetch $OUT/pmc_write
