@@ -633,24 +633,34 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
 // as the neighbourhood core (S^T = K Q^T with K rows from swizzled LDS, O^T = V^T P^T with P from registers and V staged
 // transposed), without halo or window mask: NT = ceil(T/32) waves, wave w owns queries 32w..32w+31 and all NT key tiles
 // (the whole score row lives in registers: no online softmax).  K and then V^T occupy the same LDS buffer.
-template <int NT, bool PREP>
+template <int MODE, int NT, bool PREP>
 __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseArgs a) {
   extern __shared__ __attribute__((aligned(16))) char gs_smem[];
   constexpr int TP = NT * 32, NTHR = NT * 64;
   constexpr int VSTR = TP * 2 + 4;                       // bytes per e-row of V^T: odd dword count -> conflict-free dword-pair reads
   constexpr int IMG_K = TP * 128, IMG_V = DH * VSTR;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h2 = lane >> 5;
-  const int head = blockIdx.x % a.nh, b = blockIdx.x / a.nh;
-  const int T = a.T;
+  int b, head, wi = 0, wj = 0;
+  if (MODE == MODE_GLOBAL) {
+    head = blockIdx.x % a.nh; b = blockIdx.x / a.nh;
+  } else {                                               // one workgroup per (sample, head, 8x8 window): 64 slots, NT == 2
+    const int nww = a.W >> 3, nwh = a.H >> 3;
+    int r = blockIdx.x;
+    wj = r % nww; r /= nww; wi = r % nwh; r /= nwh; head = r % a.nh; b = r / a.nh;
+  }
+  const int T = MODE == MODE_GLOBAL ? a.T : 64;          // slots of this problem
   const long row_stride = 3L * a.nh * DH;
-  const float* base = a.qkv + (long)b * T * row_stride + head * DH;
+  const float* base = a.qkv + (long)b * a.T * row_stride + head * DH;
   const float sqrt_scale = PREP ? sqrtf(a.scale_h[head]) : 1.f;
   const int c16 = tid & 15, rsub = tid >> 4;             // staging: 16 lanes per key row, NTHR/16 rows per round, 8 rounds
+  auto tok_of = [&](int slot) -> int {                   // slot (clamped into the problem) -> token index inside the sample
+    return slot_token<MODE>(a, min(slot, T - 1), wi, wj);
+  };
 
   // ---- this lane's query: 32 of its 64 dims, 8-wide chunks 2*step + h2 -------------------------------------------------
   const int q_slot = wid * 32 + l31;
   const bool q_ok = q_slot < T;
-  const int q_tok = min(q_slot, T - 1);
+  const int q_tok = tok_of(q_slot);
   f32x4 qf[8];
   {
     const float* rp = base + (long)q_tok * row_stride;
@@ -669,14 +679,14 @@ __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseA
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int slot = i * (NTHR / 16) + rsub;
-      kreg[i] = *reinterpret_cast<const f32x4*>(base + (long)min(slot, T - 1) * row_stride + a.nh * DH + 4 * c16);
+      kreg[i] = *reinterpret_cast<const f32x4*>(base + (long)tok_of(slot) * row_stride + a.nh * DH + 4 * c16);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int slot = i * (NTHR / 16) + rsub;
       f32x4 v = kreg[i];
       if (PREP) {
-        const int tk = min(slot, T - 1);
+        const int tk = tok_of(slot);
         v = prep_row16(v, c16, sqrt_scale, a.cos_t + ((long)tk * a.nh + head) * ROT, a.sin_t + ((long)tk * a.nh + head) * ROT, a.eps);
       }
       if (slot >= T) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -694,8 +704,8 @@ __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseA
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int key = 2 * (j * (NTHR / 16) + rsub);
-    vreg[2 * j] = *reinterpret_cast<const f32x4*>(vbase + (long)min(key, T - 1) * row_stride);
-    vreg[2 * j + 1] = *reinterpret_cast<const f32x4*>(vbase + (long)min(key + 1, T - 1) * row_stride);
+    vreg[2 * j] = *reinterpret_cast<const f32x4*>(vbase + (long)tok_of(key) * row_stride);
+    vreg[2 * j + 1] = *reinterpret_cast<const f32x4*>(vbase + (long)tok_of(key + 1) * row_stride);
   }
 
   // ---- q preparation + split into B-operand fragments -------------------------------------------------------------------------
@@ -754,13 +764,18 @@ __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseA
     }
   }
 
+  const int q_region = (MODE == MODE_WINDOW) ? slot_region(min(q_slot, 63), wi, wj, a.shift) : 0;
   // ---- softmax over keys (keys >= T masked by an additive -inf) ----------------------------------------------------------------------
   float m = -INFINITY;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      if (t * 32 + 32 > T) S[t][i] += (t * 32 + mfma32_row(i, lane) < T) ? 0.f : -INFINITY;
+      if (MODE == MODE_GLOBAL) {
+        if (t * 32 + 32 > T) S[t][i] += (t * 32 + mfma32_row(i, lane) < T) ? 0.f : -INFINITY;
+      } else if (a.shift) {      // shifted windows: a key counts only if it lies in the query's wrapped region (:285-316)
+        S[t][i] += (slot_region(t * 32 + mfma32_row(i, lane), wi, wj, a.shift) == q_region) ? 0.f : -INFINITY;
+      }
       m = fmaxf(m, S[t][i]);
     }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -845,7 +860,7 @@ __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseA
 
   if (q_ok) {
     const float inv = 1.0f / l;
-    float* op = a.out + ((long)b * T + q_tok) * (a.nh * DH) + head * DH;
+    float* op = a.out + ((long)b * a.T + q_tok) * (a.nh * DH) + head * DH;
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -858,18 +873,20 @@ __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseA
   }
 }
 
-template <int NT>
+template <int MODE, int NT>
 static int launch_global_split(const DenseArgs& a, int prep, long nblocks, hipStream_t s) {
   constexpr int TP = NT * 32, VSTR = TP * 2 + 4;
   constexpr int lds = 2 * (TP * 128 > DH * VSTR ? TP * 128 : DH * VSTR);
-  LaunchScope prof("attn_global_bf16x3", 4.0 * (double)nblocks * a.T * a.T * DH, 4.0 * (double)a.batch * a.T * a.nh * DH * 4.0, s);
+  const int n_slots = MODE == MODE_GLOBAL ? a.T : 64;
+  LaunchScope prof(MODE == MODE_GLOBAL ? "attn_global_bf16x3" : "attn_window_bf16x3", 4.0 * (double)nblocks * n_slots * n_slots * DH,
+                   4.0 * (double)a.batch * a.T * a.nh * DH * 4.0, s);
   if (prep) {
-    auto k = attn_global_split_kernel<NT, true>;
+    auto k = attn_global_split_kernel<MODE, NT, true>;
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(NT * 64), lds, s, a);
   } else {
-    auto k = attn_global_split_kernel<NT, false>;
+    auto k = attn_global_split_kernel<MODE, NT, false>;
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(NT * 64), lds, s, a);
@@ -931,9 +948,9 @@ extern "C" int kd_attn_global_f32(const float* qkv, float* out, int batch, int T
   const char* mode = getenv("KDIFF_GEMM");                    // read per call (tests switch modes inside one process)
   const bool exact = mode && !strcmp(mode, "exact");
   if (!exact) {
-    if (T <= 64) return launch_global_split<2>(a, prep, nb, s);
-    if (T <= 128) return launch_global_split<4>(a, prep, nb, s);
-    return launch_global_split<8>(a, prep, nb, s);
+    if (T <= 64) return launch_global_split<MODE_GLOBAL, 2>(a, prep, nb, s);
+    if (T <= 128) return launch_global_split<MODE_GLOBAL, 4>(a, prep, nb, s);
+    return launch_global_split<MODE_GLOBAL, 8>(a, prep, nb, s);
   }
   if (T <= 64) return launch_dense<MODE_GLOBAL, 2>(a, prep, nb, "attn_global_f32", s);
   if (T <= 128) return launch_dense<MODE_GLOBAL, 4>(a, prep, nb, "attn_global_f32", s);
@@ -949,6 +966,8 @@ extern "C" int kd_attn_window_f32(const float* qkv, float* out, int batch, int H
   if (int e = check_prep(prep, scale_h, cos_t, sin_t, "kd_attn_window_f32")) return e;
   DenseArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H * W, nh, H, W, ws, shift, eps};
   const long nb = (long)batch * nh * (H / ws) * (W / ws);
+  const char* mode = getenv("KDIFF_GEMM");
+  if (!(mode && !strcmp(mode, "exact"))) return launch_global_split<MODE_WINDOW, 2>(a, prep, nb, (hipStream_t)stream);
   return launch_dense<MODE_WINDOW, 2>(a, prep, nb, "attn_window_f32", (hipStream_t)stream);
 }
 

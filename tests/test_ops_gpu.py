@@ -232,17 +232,17 @@ def test_attention_vs_reference_golden(ops, golden, gtol, fused):
     assert relerr(y, o["attn_global.o"]) < gtol        # exact: fp32 MFMA core; split3: bf16x3 core
     for shift in (0, 4):
         y = ops.attn_window(qkv, 2, 8, shift, **kw).view(2, 16, 16, 2, 64)
-        assert relerr(y, o[f"attn_window{shift}.o"]) < 2e-5, shift
+        assert relerr(y, o[f"attn_window{shift}.o"]) < gtol, shift
     ref = hdit.na2d(o["qk.q_out"], o["qk.k_out"], o["qk.v"], 7, 1.0)
     y = ops.attn_na2d(qkv, 2, 7, **kw).view(2, 16, 16, 2, 64)
     assert relerr(y, ref) < 1e-4            # split-bf16x3 MFMA products (K, Q, P, V each hi + lo)
 
 
-def test_window_attention_rect(ops, golden):
+def test_window_attention_rect(ops, gtol, golden):
     o = golden["ops"]
     qkv = g(_pack(o["attn_window_rect.q"], o["attn_window_rect.k"], o["attn_window_rect.v"]))
     y = ops.attn_window(qkv, 1, 8, 4).view(1, 8, 24, 1, 64)
-    assert relerr(y, o["attn_window_rect.o"]) < 2e-5
+    assert relerr(y, o["attn_window_rect.o"]) < gtol
 
 
 @pytest.mark.parametrize("T,nh,B", [(49, 4, 3), (64, 8, 2), (100, 1, 2), (256, 2, 2), (7, 1, 1)])
