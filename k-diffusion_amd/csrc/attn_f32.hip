@@ -288,17 +288,24 @@ __device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
   bf16x2 v = {(__bf16)a, (__bf16)b};
   return __builtin_bit_cast(unsigned, v);
 }
-// 4 floats -> (hi, lo) bf16 quads
+// 4 floats -> (hi, lo) bf16 quads.  The residuals are formed with packed fp32 arithmetic (v_pk_add_f32: two lanes' worth
+// per issue): these conversions are the bulk of the VALU work of the staging phases.
 __device__ __forceinline__ void split4_bf16(const f32x4 v, u32x2& hi, u32x2& lo) {
+  using f32x2 = __attribute__((ext_vector_type(2))) float;
   hi[0] = pack2_bf16(v[0], v[1]);
   hi[1] = pack2_bf16(v[2], v[3]);
-  lo[0] = pack2_bf16(v[0] - __uint_as_float(hi[0] << 16), v[1] - __uint_as_float(hi[0] & 0xFFFF0000u));
-  lo[1] = pack2_bf16(v[2] - __uint_as_float(hi[1] << 16), v[3] - __uint_as_float(hi[1] & 0xFFFF0000u));
+  const f32x2 h01 = {__uint_as_float(hi[0] << 16), __uint_as_float(hi[0] & 0xFFFF0000u)};
+  const f32x2 h23 = {__uint_as_float(hi[1] << 16), __uint_as_float(hi[1] & 0xFFFF0000u)};
+  const f32x2 r01 = f32x2{v[0], v[1]} - h01, r23 = f32x2{v[2], v[3]} - h23;
+  lo[0] = pack2_bf16(r01[0], r01[1]);
+  lo[1] = pack2_bf16(r23[0], r23[1]);
 }
 // byte offset of (row, 16-byte chunk c of 8) in a [rows][64] bf16 image with 128-byte rows
 __device__ __forceinline__ int na_kswz(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 
-template <bool PREP>
+// FULL: the image is at least as large as the halo (H >= 14, W >= 22), so every halo key lies inside the image and only
+// the pad rows past key 307 need zeroing: no per-key bounds tests / selects in the staging loops.
+template <bool PREP, bool FULL>
 __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
   extern __shared__ __attribute__((aligned(16))) char na_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -336,8 +343,14 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
   const HaloIt halo0{rsub / NA_HC, rsub % NA_HC, rsub};       // rsub < 16 < 22: row 0
   auto halo_tok = [&](const HaloIt& h) -> int {       // token index of the key, -1 outside the image / halo
     const int ky = hy0 + h.ky, kx = hx0 + h.kx;
+    if (FULL) return h.hr < NA_KEYS ? ky * a.W + kx : -1;
     return (h.hr < NA_KEYS && ky < a.H && kx < a.W) ? ky * a.W + kx : -1;
   };
+  // byte offset of a token's row inside this (sample, head) slice: 32-bit (a sample's qkv is far below 2 GiB), so the
+  // loads are "scalar base + 32-bit lane offset" instead of 64-bit pointer arithmetic per load
+  const unsigned row_bytes = (unsigned)(row_stride * sizeof(float));
+  const char* kbase_c = reinterpret_cast<const char*>(base + a.nh * DH + 4 * c16);
+  const char* vbase_c = reinterpret_cast<const char*>(base + 2 * a.nh * DH + 4 * c16);
   // ---- this lane's query (column l31 of its wave): 32 of its 64 dims, 8-wide chunks 2*step + h2 ----------------
   const int qy_raw = ty0 + 4 * wy_ + (l31 >> 3), qx_raw = tx0 + 8 * wx_ + (l31 & 7);
   const bool q_ok = qy_raw < a.H && qx_raw < a.W;
@@ -364,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int tok = halo_tok(hk_load);
-      kreg[i] = *reinterpret_cast<const f32x4*>(base + (long)(tok < 0 ? 0 : tok) * row_stride + a.nh * DH + 4 * c16);
+      kreg[i] = *reinterpret_cast<const f32x4*>(kbase_c + (unsigned)max(tok, 0) * row_bytes);
       hk_load.next();
     }
 #pragma unroll
@@ -466,18 +479,18 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
   const PairIt pair0{(2 * rsub) / NA_HC, (2 * rsub) % NA_HC, 2 * rsub};
   auto pair_tok = [&](const PairIt& h) -> int {      // token of the even key; the odd key is the next token (or invalid)
     const int ky = hy0 + h.ky, kx = hx0 + h.kx;
+    if (FULL) return h.key < NA_KEYS ? ky * a.W + kx : -1;
     return (h.key < NA_KEYS && ky < a.H && kx < a.W) ? ky * a.W + kx : -1;
   };
-  auto pair_odd_ok = [&](const PairIt& h) -> bool { return hx0 + h.kx + 1 < a.W; };
-  const float* vbase = base + 2 * a.nh * DH + 4 * c16;
+  auto pair_odd_ok = [&](const PairIt& h) -> bool { return FULL || hx0 + h.kx + 1 < a.W; };
   f32x4 vreg[2 * NA_VH];
   PairIt hv_load = pair0, hv_use = pair0;
 #pragma unroll
   for (int j = 0; j < NA_VH; ++j) {
     const int tok = pair_tok(hv_load);
-    const long o = (long)(tok < 0 ? 0 : tok) * row_stride;
-    vreg[2 * j] = *reinterpret_cast<const f32x4*>(vbase + o);
-    vreg[2 * j + 1] = *reinterpret_cast<const f32x4*>(vbase + o + (tok >= 0 && pair_odd_ok(hv_load) ? row_stride : 0));
+    const unsigned o = (unsigned)max(tok, 0) * row_bytes;
+    vreg[2 * j] = *reinterpret_cast<const f32x4*>(vbase_c + o);
+    vreg[2 * j + 1] = *reinterpret_cast<const f32x4*>(vbase_c + o + (tok >= 0 && pair_odd_ok(hv_load) ? row_bytes : 0u));
     hv_load.next();
   }
 
@@ -554,9 +567,9 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
 #pragma unroll
     for (int j = 0; j < NA_VR - NA_VH; ++j) {
       const int tok = pair_tok(hv_load);
-      const long o = (long)(tok < 0 ? 0 : tok) * row_stride;
-      vreg2[2 * j] = *reinterpret_cast<const f32x4*>(vbase + o);
-      vreg2[2 * j + 1] = *reinterpret_cast<const f32x4*>(vbase + o + (tok >= 0 && pair_odd_ok(hv_load) ? row_stride : 0));
+      const unsigned o = (unsigned)max(tok, 0) * row_bytes;
+      vreg2[2 * j] = *reinterpret_cast<const f32x4*>(vbase_c + o);
+      vreg2[2 * j + 1] = *reinterpret_cast<const f32x4*>(vbase_c + o + (tok >= 0 && pair_odd_ok(hv_load) ? row_bytes : 0u));
       hv_load.next();
     }
 #pragma unroll
@@ -985,11 +998,16 @@ extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, 
   LaunchScope prof(nm, 4.0 * batch * (double)H * W * nh * DH * ks * ks, 16.0 * batch * (double)H * W * nh * DH, s);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
     attr_set = true;
   }
-  if (prep) hipLaunchKernelGGL(attn_na2d_kernel<true>, dim3((unsigned)nb), dim3(256), NA_LDS, s, a);
-  else hipLaunchKernelGGL(attn_na2d_kernel<false>, dim3((unsigned)nb), dim3(256), NA_LDS, s, a);
+  const bool full = H >= NA_HR && W >= NA_HC;      // every halo key is inside the image
+  if (prep && full) hipLaunchKernelGGL((attn_na2d_kernel<true, true>), dim3((unsigned)nb), dim3(256), NA_LDS, s, a);
+  else if (prep) hipLaunchKernelGGL((attn_na2d_kernel<true, false>), dim3((unsigned)nb), dim3(256), NA_LDS, s, a);
+  else if (full) hipLaunchKernelGGL((attn_na2d_kernel<false, true>), dim3((unsigned)nb), dim3(256), NA_LDS, s, a);
+  else hipLaunchKernelGGL((attn_na2d_kernel<false, false>), dim3((unsigned)nb), dim3(256), NA_LDS, s, a);
   return check_launch("kd_attn_na2d_f32");
 }
