@@ -171,9 +171,15 @@ int kd_t_to_sigma_f32(const float* t, const float* log_sigmas, float* sigma, int
 /* Brownian-interval noise (stands in for torchsde.BrownianTree behind
  * k_diffusion/sampling.py:65-114): out[b, i] = sign * (W_b,i(t1) - W_b,i(t0)) * inv_norm where W is
  * a virtual Brownian tree on [T0, T1] (depth-`depth` dyadic bridge, Philox4x32-10 keyed by
- * seeds[b], counter = (element index, tree node)); path-consistent across nested queries. */
+ * seeds[b], counter = (element index, tree node)); path-consistent across nested queries.
+ * kd_brownian_cached_f32 is the same function with the end-point values W(t0) / W(t1) kept by the
+ * caller (the tensors torchsde's tree caches on the host, sampling.py:72-79): have0 / have1 != 0
+ * reads that end point from w0 / w1 [batch, per_sample] instead of descending the tree; otherwise it
+ * is computed and, when the pointer is non-NULL, stored there for a later query. */
 int kd_brownian_f32(float* out, const unsigned long long* seeds, int batch, long long per_sample,
                     double T0, double T1, double t0, double t1, float mult, int depth, void* stream);
+int kd_brownian_cached_f32(float* out, float* w0, float* w1, int have0, int have1, const unsigned long long* seeds, int batch,
+                           long long per_sample, double T0, double T1, double t0, double t1, float mult, int depth, void* stream);
 
 /* Final image conversion (k_diffusion/utils.py:27-34 to_pil_image): u8 = trunc((clamp(x,-1,1)+1)/2*255)
  * (torchvision's to_pil_image does mul(255).byte(), i.e. truncation) */

@@ -63,6 +63,7 @@ SIGNATURES = {
     "kd_sigma_to_t_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "kd_t_to_sigma_f32": [_vp, _vp, _vp, _i, _i, _vp],
     "kd_brownian_f32": [_vp, _vp, _i, _ll, _d, _d, _d, _d, _f, _i, _vp],
+    "kd_brownian_cached_f32": [_vp, _vp, _vp, _i, _i, _vp, _i, _ll, _d, _d, _d, _d, _f, _i, _vp],
     "kd_to_uint8": [_vp, _vp, _ll, _vp],
     "kd_prof_enable": [_i],
     "kd_prof_count": [],

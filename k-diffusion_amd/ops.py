@@ -324,6 +324,20 @@ def brownian(out, seeds, T0, T1, t0, t1, mult, depth=36):
     return out
 
 
+def brownian_cached(out, w0, have0, w1, have1, seeds, T0, T1, t0, t1, mult, depth=36):
+    """As ``brownian`` with the end-point tensors W(t0) / W(t1) kept by the caller: ``have*`` says the
+    buffer already holds that end point (read, no descent); otherwise it is computed and stored."""
+    B = out.shape[0]
+    _chk(seeds, "seeds", torch.int64)
+    for w in (w0, w1):
+        if w is not None and _chk(w, "w").numel() != out.numel():
+            raise ValueError("end-point buffers must match out")
+    nat.check(nat.lib().kd_brownian_cached_f32(_p(_chk(out, "out")), _p(w0) if w0 is not None else None, _p(w1) if w1 is not None else None,
+                                           int(bool(have0)), int(bool(have1)), _p(seeds), B, out.numel() // B, float(T0), float(T1),
+                                           float(t0), float(t1), float(mult), depth, _stream()), "kd_brownian_cached_f32")
+    return out
+
+
 def to_uint8(x, out=None):
     out = torch.empty(x.shape, device=x.device, dtype=torch.uint8) if out is None else out
     nat.check(nat.lib().kd_to_uint8(_p(_chk(x, "x")), _p(_chk(out, "y", torch.uint8)), x.numel(), _stream()), "kd_to_uint8")

@@ -102,6 +102,10 @@ class BatchedBrownianTree:
         self.shape, self.device = tuple(x.shape), x.device
         self.depth = int(kwargs.get('depth', 36))
         self.seeds = torch.tensor([s & 0x7FFFFFFFFFFFFFFF for s in seeds], dtype=torch.int64, device=x.device)
+        # W(t) tensors of the most recent end points (torchsde caches its visited nodes on the host,
+        # sampling.py:72-79): each sigma_i bounds 2-4 queries, so most descents are skipped
+        self.cache_points = int(kwargs.get('cache_points', 3))
+        self._points = []                                        # [t, tensor], most recently used last
 
     @staticmethod
     def sort(a, b):
@@ -119,8 +123,29 @@ class BatchedBrownianTree:
         t0, t1, sign = self.sort(self._clip(_f(t0)), self._clip(_f(t1)))
         out = torch.empty(self.shape, device=self.device, dtype=torch.float32)
         view = out if self.batched else out.view(1, -1)
-        ops.brownian(view, self.seeds, self.t0, self.t1, t0, t1, mult * self.sign * sign, self.depth)
+        if self.cache_points < 2:
+            ops.brownian(view, self.seeds, self.t0, self.t1, t0, t1, mult * self.sign * sign, self.depth)
+            return out
+        w0, have0 = self._point(t0, None)
+        w1, have1 = (w0, have0) if t1 == t0 else self._point(t1, w0)
+        ops.brownian_cached(view, w0.view(view.shape), have0, w1.view(view.shape), have1, self.seeds, self.t0, self.t1, t0, t1,
+                            mult * self.sign * sign, self.depth)
         return out
+
+    def _point(self, t, keep):
+        """Buffer for W(t) and whether it is already filled; recycles the least recently used buffer
+        (never ``keep``, the other end point of the query being served)."""
+        for k, entry in enumerate(self._points):
+            if entry[0] == t:
+                self._points.append(self._points.pop(k))
+                return entry[1], True
+        if len(self._points) < self.cache_points:
+            buf = torch.empty(self.shape, device=self.device, dtype=torch.float32)
+        else:
+            k = 0 if self._points[0][1] is not keep else 1
+            buf = self._points.pop(k)[1]
+        self._points.append([t, buf])
+        return buf, False
 
     def __call__(self, t0, t1):
         return self.increment(t0, t1)

@@ -8,8 +8,10 @@ sites rely on, and what the tests check, is (a) unit-variance normalised increme
 consistency over nested/adjacent intervals (sample_dpmpp_sde queries (sigma_i, sigma_mid) then
 (sigma_i, sigma_next), sampling.py:572,580), (c) determinism per seed, (d) sign/sort handling
 (sampling.py:82-89).  This file restates, in numpy, the algorithm the HIP kernel implements
-(k-diffusion_amd/csrc/brownian.hip): integer Philox4x32-10 (bit-exact) + float32 Box-Muller and
-bridge arithmetic (tolerance 2e-5 absolute against the device's libm).
+(k-diffusion_amd/csrc/brownian.hip): integer Philox4x32-10 (bit-exact; one block per two tree
+levels) + float32 Box-Muller and bridge arithmetic.  The device evaluates log2 / sqrt / cos with the
+hardware v_log_f32 / v_sqrt_f32 / v_cos_f32 (about 1e-6 absolute), so the comparison tolerance is
+1e-4 absolute on values of order sqrt(T1 - T0).
 """
 import numpy as np
 
@@ -33,30 +35,64 @@ def philox4x32_10(key, c0, c1, c2, c3):
     return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
 
 
-def philox_normal(key, elem, node):
-    """Standard normal for (key, element index array, node index array)."""
+def _radius(w):
+    """sqrt(-2 ln u), u = (w >> 8 + 1) / 2^24 in (0, 1]; float32 with the kernel's op order (log2 * -2 ln 2)."""
+    u = ((w >> np.uint32(8)).astype(np.float32) + np.float32(1)) * np.float32(2.0 ** -24)
+    return np.sqrt(np.float32(-1.3862943611198906) * np.log2(u)).astype(np.float32)
+
+
+def _unit24(w):
+    return (w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+
+
+def _cos_rev(rev):
+    """cos of `rev` revolutions (the device uses v_cos_f32, whose argument is in revolutions)."""
+    return np.cos(np.float64(2.0 * np.pi) * rev.astype(np.float64)).astype(np.float32)
+
+
+def _philox(key, elem, node):
     elem = np.asarray(elem, dtype=np.uint64)
     node = np.broadcast_to(np.asarray(node, dtype=np.uint64), elem.shape)
-    x0, x1, _, _ = philox4x32_10(key, elem & _MASK, elem >> np.uint64(32), node & _MASK, node >> np.uint64(32))
-    u1 = ((x0 >> np.uint32(8)).astype(np.float32) + np.float32(1)) * np.float32(2.0 ** -24)
-    u2 = (x1 >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
-    return (np.sqrt(np.float32(-2.0) * np.log(u1)) * np.cos(np.float32(6.283185307179586) * u2)).astype(np.float32)
+    return philox4x32_10(key, elem & _MASK, elem >> np.uint64(32), node & _MASK, node >> np.uint64(32))
 
 
 def brownian_w(key, n_elem, t, T0, T1, depth=36):
-    """W(t) for elements 0..n_elem-1 of the tree keyed by ``key``."""
+    """W(t) for elements 0..n_elem-1 of the tree keyed by ``key``.
+
+    One Philox block serves two levels: the even-level node (heap index ``node``) takes
+    r(x0)*cos(x1); its left child r(x0)*sin(x1) (= cos(x1 - 1/4 turn)), its right child r(x2)*cos(x3)."""
     elem = np.arange(n_elem, dtype=np.uint64)
     ta, tb = float(T0), float(T1)
+    sd0 = np.sqrt(np.float32(T1 - T0))
+    x0, x1, _, _ = _philox(key, elem, 0)
     wa = np.zeros(n_elem, dtype=np.float32)
-    wb = np.float32(np.sqrt(np.float32(T1 - T0))) * philox_normal(key, elem, 0)
+    wb = (sd0 * _radius(x0) * _cos_rev(_unit24(x1))).astype(np.float32)
+    hs = np.float32(0.5) * sd0
+    r2 = np.float32(0.70710678118654752)
     node = 1
-    for _ in range(depth):
+    for lv in range(0, depth, 2):
+        x0, x1, x2, x3 = _philox(key, elem, node)
         tm = 0.5 * (ta + tb)
-        wm = np.float32(0.5) * (wa + wb) + np.float32(0.5) * np.sqrt(np.float32(tb - ta)) * philox_normal(key, elem, node)
-        if t < tm:
-            tb, wb, node = tm, wm, 2 * node
+        wm = np.float32(0.5) * (wa + wb) + hs * (_radius(x0) * _cos_rev(_unit24(x1)))
+        hs = hs * r2
+        right0 = not (t < tm)
+        if right0:
+            ta, wa = tm, wm
         else:
-            ta, wa, node = tm, wm, 2 * node + 1
+            tb, wb = tm, wm
+        if lv + 1 >= depth:
+            break
+        rad = _radius(x2 if right0 else x0)
+        rev = _unit24(x3) if right0 else _unit24(x1) - np.float32(0.25)
+        tm = 0.5 * (ta + tb)
+        wm = np.float32(0.5) * (wa + wb) + hs * (rad * _cos_rev(rev))
+        hs = hs * r2
+        right1 = not (t < tm)
+        if right1:
+            ta, wa = tm, wm
+        else:
+            tb, wb = tm, wm
+        node = 4 * node + (2 if right0 else 0) + (1 if right1 else 0)
     frac = np.float32((t - ta) / (tb - ta))
     return (wa + frac * (wb - wa)).astype(np.float32)
 

@@ -336,7 +336,12 @@ def test_brownian_vs_oracle(ops):
     out = torch.empty(3, 3, 5, 7, device=DEV)
     ops.brownian(out, g(torch.tensor(seeds, dtype=torch.int64)), 0.01, 80.0, 0.5, 3.25, 1.0 / (3.25 - 0.5) ** 0.5)
     ref = obrown.brownian_increment(seeds, per, 0.01, 80.0, 0.5, 3.25, 1.0 / (3.25 - 0.5) ** 0.5)
-    assert np.abs(out.cpu().numpy().reshape(3, per) - ref).max() < 2e-5
+    assert np.abs(out.cpu().numpy().reshape(3, per) - ref).max() < 1e-4       # hardware log2/sqrt/cos vs numpy
+    # odd depth (the last level uses only the node's own deviate) and a shallow tree
+    for depth in (1, 7, 12):
+        ops.brownian(out, g(torch.tensor(seeds, dtype=torch.int64)), 0.01, 80.0, 0.5, 3.25, 1.0, depth)
+        ref = obrown.brownian_increment(seeds, per, 0.01, 80.0, 0.5, 3.25, 1.0, depth)
+        assert np.abs(out.cpu().numpy().reshape(3, per) - ref).max() < 1e-4, depth
     # path consistency: W(a,c) == W(a,b) + W(b,c)
     ab, bc, ac = (torch.empty(3, 3, 5, 7, device=DEV) for _ in range(3))
     s = g(torch.tensor(seeds, dtype=torch.int64))
@@ -349,6 +354,25 @@ def test_brownian_vs_oracle(ops):
     ops.brownian(big, g(torch.arange(4, dtype=torch.int64) + 99), 0.01, 160.0, 0.02, 0.03, 1.0 / 0.01 ** 0.5)
     assert abs(big.var().item() - 1.0) < 0.02 and abs(big.mean().item()) < 0.01
     assert abs(torch.corrcoef(big[:2])[0, 1].item()) < 0.02
+
+
+def test_brownian_cached_endpoints(ops):
+    """kd_brownian_cached_f32: stored end points reproduce the uncached increments bit for bit."""
+    seeds = g(torch.tensor([7, 8], dtype=torch.int64))
+    shape = (2, 3 * 11 * 13)
+    plain = lambda a, b, m: ops.brownian(torch.empty(shape, device=DEV), seeds, 0.01, 80.0, a, b, m)
+    w = [torch.full(shape, float("nan"), device=DEV) for _ in range(3)]
+    out = torch.empty(shape, device=DEV)
+    ops.brownian_cached(out, w[0], False, w[1], False, seeds, 0.01, 80.0, 1.0, 2.0, 0.7)          # fills W(1), W(2)
+    assert torch.equal(out, plain(1.0, 2.0, 0.7)) and torch.isfinite(w[0]).all() and torch.isfinite(w[1]).all()
+    ops.brownian_cached(out, w[1], True, w[2], False, seeds, 0.01, 80.0, 2.0, 5.5, 1.3)           # reads W(2), fills W(5.5)
+    assert torch.equal(out, plain(2.0, 5.5, 1.3))
+    ops.brownian_cached(out, w[0], True, w[2], True, seeds, 0.01, 80.0, 1.0, 5.5, -2.0)           # both read
+    assert torch.equal(out, plain(1.0, 5.5, -2.0))
+    ops.brownian_cached(out, None, False, w[2], True, seeds, 0.01, 80.0, 0.3, 5.5, 1.0)           # computed, not stored
+    assert torch.equal(out, plain(0.3, 5.5, 1.0))
+    with pytest.raises(RuntimeError):
+        ops.brownian_cached(out, None, True, w[2], True, seeds, 0.01, 80.0, 0.3, 5.5, 1.0)
 
 
 def test_to_uint8(ops):
