@@ -886,6 +886,268 @@ __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseA
   }
 }
 
+// ---- global core for T > 256: key blocks streamed through LDS, online softmax -----------------------------------------
+// One workgroup per (sample, head, block of 256 queries): 8 waves x 32 queries, the query fragments and the O^T accumulators
+// stay in registers while 128-key blocks of K (row-major, swizzled) and V (transposed, pair-packed) pass through LDS in the
+// same split-bf16 operand scheme as above.  The next block's K / V rows are requested from HBM/L2 once the current block's
+// scores are done, so their latency hides behind the softmax update and O^T += V^T P^T.
+// Running max / sum per query (both lanes of a query keep partial sums; alpha is a per-lane scalar because queries are the
+// MFMA column dimension of S^T and O^T).
+constexpr int GL_QW = 8, GL_KB = 128, GL_NTK = GL_KB / 32, GL_THR = GL_QW * 64;
+constexpr int GL_VSTR = GL_KB * 2 + 4;
+constexpr int GL_IMG_K = GL_KB * 128, GL_IMG_V = DH * GL_VSTR;
+constexpr int GL_LDS = 2 * GL_IMG_K + 2 * GL_IMG_V;
+
+template <bool PREP>
+__global__ __launch_bounds__(GL_THR) void attn_global_long_kernel(const DenseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char gl_smem[];
+  char* Khi = gl_smem;
+  char* Klo = gl_smem + GL_IMG_K;
+  char* Vhi = gl_smem + 2 * GL_IMG_K;
+  char* Vlo = Vhi + GL_IMG_V;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h2 = lane >> 5;
+  const int T = a.T, nqb = (T + GL_QW * 32 - 1) / (GL_QW * 32);
+  int r = blockIdx.x;
+  const int qb = r % nqb; r /= nqb;
+  const int head = r % a.nh, b = r / a.nh;
+  const long row_stride = 3L * a.nh * DH;
+  const float* base = a.qkv + (long)b * T * row_stride + head * DH;
+  const float sqrt_scale = PREP ? sqrtf(a.scale_h[head]) : 1.f;
+  const int c16 = tid & 15, rsub = tid >> 4;             // staging: 16 lanes per key row, 32 rows per round
+
+  // ---- this lane's query (32 of its 64 dims: 8-wide chunks 2*step + h2), prepared and split once ---------------------------
+  const int q_slot = qb * (GL_QW * 32) + wid * 32 + l31;
+  const bool q_ok = q_slot < T;
+  const int q_tok = min(q_slot, T - 1);
+  bf16x8 qh[4], ql[4];
+  {
+    f32x4 qf[8];
+    const float* rp = base + (long)q_tok * row_stride;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      qf[2 * st] = *reinterpret_cast<const f32x4*>(rp + 16 * st + 8 * h2);
+      qf[2 * st + 1] = *reinterpret_cast<const f32x4*>(rp + 16 * st + 8 * h2 + 4);
+    }
+    if (PREP) {
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += qf[i][0] * qf[i][0] + qf[i][1] * qf[i][1] + qf[i][2] * qf[i][2] + qf[i][3] * qf[i][3];
+      ss += __shfl_xor(ss, 32, 64);
+      const float f = sqrt_scale * rsqrtf(ss + a.eps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) qf[i] = qf[i] * f;
+      const float* cs = a.cos_t + ((long)q_tok * a.nh + head) * ROT + 8 * h2;
+      const float* sn = a.sin_t + ((long)q_tok * a.nh + head) * ROT + 8 * h2;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f32x4 cc = *reinterpret_cast<const f32x4*>(cs + 4 * u), sc = *reinterpret_cast<const f32x4*>(sn + 4 * u);
+        const f32x4 x1 = qf[u], x2 = qf[2 + u];
+        qf[u] = x1 * cc - x2 * sc;
+        qf[2 + u] = x2 * cc + x1 * sc;
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      u32x2 h0, l0, h1, l1;
+      split4_bf16(qf[2 * st], h0, l0);
+      split4_bf16(qf[2 * st + 1], h1, l1);
+      qh[st] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+      ql[st] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+    }
+  }
+
+  // ---- key-block staging registers: K rows i*32 + rsub (4 rounds), V key pairs 2*(j*32 + rsub) (2 rounds) -------------------
+  f32x4 kreg[4], vreg[4];
+  auto request = [&](int kb) {
+    const int k0 = kb * GL_KB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      kreg[i] = *reinterpret_cast<const f32x4*>(base + (long)min(k0 + i * 32 + rsub, T - 1) * row_stride + a.nh * DH + 4 * c16);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int key = k0 + 2 * (j * 32 + rsub);
+      vreg[2 * j] = *reinterpret_cast<const f32x4*>(base + (long)min(key, T - 1) * row_stride + 2 * a.nh * DH + 4 * c16);
+      vreg[2 * j + 1] = *reinterpret_cast<const f32x4*>(base + (long)min(key + 1, T - 1) * row_stride + 2 * a.nh * DH + 4 * c16);
+    }
+  };
+  request(0);
+
+  f32x16 O[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) O[e][u][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int nkb = (T + GL_KB - 1) / GL_KB;
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int k0 = kb * GL_KB;
+    // ---- publish this block: K rows (prepared, split, swizzled), V^T (split, key pairs packed) ------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int slot = i * 32 + rsub, key = k0 + slot;
+      f32x4 v = kreg[i];
+      if (PREP) {
+        const int tk = min(key, T - 1);
+        v = prep_row16(v, c16, sqrt_scale, a.cos_t + ((long)tk * a.nh + head) * ROT, a.sin_t + ((long)tk * a.nh + head) * ROT, a.eps);
+      }
+      if (key >= T) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x2 hi, lo;
+      split4_bf16(v, hi, lo);
+      const int o = na_kswz(slot, c16 >> 1) + (c16 & 1) * 8;
+      *reinterpret_cast<u32x2*>(Khi + o) = hi;
+      *reinterpret_cast<u32x2*>(Klo + o) = lo;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int slot = 2 * (j * 32 + rsub), key = k0 + slot;
+      f32x4 v0 = vreg[2 * j], v1 = vreg[2 * j + 1];
+      if (key >= T) v0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (key + 1 >= T) v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x2 h0, l0, h1, l1;
+      split4_bf16(v0, h0, l0);
+      split4_bf16(v1, h1, l1);
+      char* ph_ = Vhi + (4 * c16) * GL_VSTR + slot * 2;
+      char* pl_ = Vlo + (4 * c16) * GL_VSTR + slot * 2;
+      *reinterpret_cast<unsigned*>(ph_) = __builtin_amdgcn_perm(h1[0], h0[0], 0x05040100u);
+      *reinterpret_cast<unsigned*>(ph_ + GL_VSTR) = __builtin_amdgcn_perm(h1[0], h0[0], 0x07060302u);
+      *reinterpret_cast<unsigned*>(ph_ + 2 * GL_VSTR) = __builtin_amdgcn_perm(h1[1], h0[1], 0x05040100u);
+      *reinterpret_cast<unsigned*>(ph_ + 3 * GL_VSTR) = __builtin_amdgcn_perm(h1[1], h0[1], 0x07060302u);
+      *reinterpret_cast<unsigned*>(pl_) = __builtin_amdgcn_perm(l1[0], l0[0], 0x05040100u);
+      *reinterpret_cast<unsigned*>(pl_ + GL_VSTR) = __builtin_amdgcn_perm(l1[0], l0[0], 0x07060302u);
+      *reinterpret_cast<unsigned*>(pl_ + 2 * GL_VSTR) = __builtin_amdgcn_perm(l1[1], l0[1], 0x05040100u);
+      *reinterpret_cast<unsigned*>(pl_ + 3 * GL_VSTR) = __builtin_amdgcn_perm(l1[1], l0[1], 0x07060302u);
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T for the block's 4 key tiles ------------------------------------------------------------------------------
+    f32x16 S[GL_NTK];
+#pragma unroll
+    for (int t = 0; t < GL_NTK; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      bf16x8 kh[GL_NTK], kl[GL_NTK];
+#pragma unroll
+      for (int t = 0; t < GL_NTK; ++t) {
+        const int o = na_kswz(t * 32 + l31, 2 * st + h2);
+        kh[t] = *reinterpret_cast<const bf16x8*>(Khi + o);
+        kl[t] = *reinterpret_cast<const bf16x8*>(Klo + o);
+      }
+#pragma unroll
+      for (int t = 0; t < GL_NTK; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[t], qh[st], S[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < GL_NTK; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[t], ql[st], S[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < GL_NTK; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[t], qh[st], S[t], 0, 0, 0);
+    }
+
+    if (kb + 1 < nkb) request(kb + 1);          // in flight during the softmax update and the P V MFMAs (kept out of the
+                                                // S phase, whose q fragments already fill the register budget)
+    // ---- online softmax update (keys >= T carry -inf; every block holds at least one real key) --------------------------------
+    float m_blk = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < GL_NTK; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (k0 + GL_KB > T) S[t][i] += (k0 + t * 32 + mfma32_row(i, lane) < T) ? 0.f : -INFINITY;
+        m_blk = fmaxf(m_blk, S[t][i]);
+      }
+    m_blk = fmaxf(m_blk, __shfl_xor(m_blk, 32, 64));
+    const float m_new = fmaxf(m_run, m_blk);
+    const float alpha = __expf(m_run - m_new);       // first block: exp(-inf) = 0
+    m_run = m_new;
+    float l_blk = 0.f;
+#pragma unroll
+    for (int t = 0; t < GL_NTK; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pv = __expf(S[t][i] - m_new);
+        S[t][i] = pv;
+        l_blk += pv;
+      }
+    l_run = l_run * alpha + l_blk;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[e][u][i] *= alpha;
+
+    // ---- O^T += V^T P^T ----------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < GL_NTK; ++t) {
+      bf16x8 ph[2], pl[2], vh[2][2], vl[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        u32x2 ph0, pl0, ph1, pl1;
+        split4_bf16(f32x4{S[t][8 * u], S[t][8 * u + 1], S[t][8 * u + 2], S[t][8 * u + 3]}, ph0, pl0);
+        split4_bf16(f32x4{S[t][8 * u + 4], S[t][8 * u + 5], S[t][8 * u + 6], S[t][8 * u + 7]}, ph1, pl1);
+        ph[u] = __builtin_bit_cast(bf16x8, u32x4{ph0[0], ph0[1], ph1[0], ph1[1]});
+        pl[u] = __builtin_bit_cast(bf16x8, u32x4{pl0[0], pl0[1], pl1[0], pl1[1]});
+        const int key0 = t * 32 + 16 * u + 4 * h2;          // k-slots: keys key0..+3 and key0+8..+11
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int o = (32 * e + l31) * GL_VSTR + key0 * 2;
+          const unsigned* hp = reinterpret_cast<const unsigned*>(Vhi + o);
+          const unsigned* lp = reinterpret_cast<const unsigned*>(Vlo + o);
+          vh[e][u] = __builtin_bit_cast(bf16x8, u32x4{hp[0], hp[1], hp[4], hp[5]});
+          vl[e][u] = __builtin_bit_cast(bf16x8, u32x4{lp[0], lp[1], lp[4], lp[5]});
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) O[e][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[e][u], ph[u], O[e][u], 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) O[e][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[e][u], pl[u], O[e][u], 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) O[e][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[e][u], ph[u], O[e][u], 0, 0, 0);
+    }
+    __syncthreads();                            // every wave is done with this block's images
+  }
+
+  if (q_ok) {
+    const float l = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l;
+    float* op = a.out + ((long)b * T + q_tok) * (a.nh * DH) + head * DH;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (O[e][0][4 * g + u] + O[e][1][4 * g + u]) * inv;
+        *reinterpret_cast<f32x4*>(op + e * 32 + 8 * g + 4 * h2) = v;
+      }
+  }
+}
+
+static int launch_global_long(const DenseArgs& a, int prep, hipStream_t s) {
+  const long nqb = (a.T + GL_QW * 32 - 1) / (GL_QW * 32);
+  const long nblocks = (long)a.batch * a.nh * nqb;
+  LaunchScope prof("attn_global_bf16x3", 4.0 * (double)a.batch * a.nh * a.T * a.T * DH, 4.0 * (double)a.batch * a.T * a.nh * DH * 4.0, s);
+  if (prep) {
+    auto k = attn_global_long_kernel<true>;
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS); set = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(GL_THR), GL_LDS, s, a);
+  } else {
+    auto k = attn_global_long_kernel<false>;
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS); set = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(GL_THR), GL_LDS, s, a);
+  }
+  return check_launch("kd_attn_global_f32");
+}
+
 template <int MODE, int NT>
 static int launch_global_split(const DenseArgs& a, int prep, long nblocks, hipStream_t s) {
   constexpr int TP = NT * 32, VSTR = TP * 2 + 4;
@@ -952,7 +1214,6 @@ extern "C" int kd_qk_prep_f32(float* qkv, const float* scale_h, const float* cos
 extern "C" int kd_attn_global_f32(const float* qkv, float* out, int batch, int T, int nh, int prep, const float* scale_h,
                                   const float* cos_t, const float* sin_t, float eps, void* stream) {
   if (!qkv || !out || batch <= 0 || nh <= 0 || T <= 0) return fail(KD_EINVAL, "kd_attn_global_f32: bad arguments");
-  if (T > 256) return fail(KD_EINVAL, "kd_attn_global_f32: T=%d > 256 tokens not supported by the LDS-resident core", T);
   if (int e = check_prep(prep, scale_h, cos_t, sin_t, "kd_attn_global_f32")) return e;
   DenseArgs a{qkv, out, scale_h, cos_t, sin_t, batch, T, nh, 0, 0, 0, 0, eps};
   const long nb = (long)batch * nh;
@@ -960,6 +1221,10 @@ extern "C" int kd_attn_global_f32(const float* qkv, float* out, int batch, int T
   // default: split-bf16x3 MFMA core (like the GEMMs); KDIFF_GEMM=exact keeps the exact-fp32 MFMA core
   const char* mode = getenv("KDIFF_GEMM");                    // read per call (tests switch modes inside one process)
   const bool exact = mode && !strcmp(mode, "exact");
+  if (T > 256) {
+    if (exact) return fail(KD_EINVAL, "kd_attn_global_f32: T=%d > 256 tokens is served by the streaming split-bf16x3 core only (unset KDIFF_GEMM=exact)", T);
+    return launch_global_long(a, prep, s);
+  }
   if (!exact) {
     if (T <= 64) return launch_global_split<MODE_GLOBAL, 2>(a, prep, nb, s);
     if (T <= 128) return launch_global_split<MODE_GLOBAL, 4>(a, prep, nb, s);

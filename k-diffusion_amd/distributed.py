@@ -27,6 +27,7 @@ class RankContext:
         self.device = torch.device(device)
         self._owns_group = False
         if self.num_processes > 1 and not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # RCCL over dmabuf IPC (the host driver has no legacy IPC)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             backend = backend or ("nccl" if self.device.type == "cuda" else "gloo")

@@ -251,8 +251,31 @@ def test_attn_global_sizes(ops, gtol, T, nh, B):
     ref = hdit.attn_global(q, k, v, 1.0)
     y = ops.attn_global(g(_pack(q, k, v)).view(B, T, -1), nh).view(B, 1, T, nh, 64)
     assert relerr(y, ref) < gtol
-    with pytest.raises(RuntimeError, match="256"):
-        ops.attn_global(g(rn(1, 300, 192)), 1)
+
+
+@pytest.mark.parametrize("H,W,nh,B", [(20, 15, 2, 2), (32, 32, 2, 1), (17, 16, 1, 3), (24, 40, 1, 1)])
+def test_attn_global_long_sequences(ops, monkeypatch, H, W, nh, B):
+    """T > 256 tokens: the streaming core (128-key blocks, online softmax), with and without fused q/k preparation."""
+    monkeypatch.setenv("KDIFF_GEMM", "split3")
+    T = H * W
+    q, k, v = (rn(B, 1, T, nh, 64, seed=s, scale=sc) for s, sc in ((1, 0.6), (2, 0.6), (3, 1.0)))
+    y = ops.attn_global(g(_pack(q, k, v)).view(B, T, -1), nh).view(B, 1, T, nh, 64)
+    assert relerr(y, hdit.attn_global(q, k, v, 1.0)) < 1e-4
+    scale = torch.linspace(5.0, 12.0, nh)
+    cos, sin = _tables(H, W, nh)
+    theta = hdit.rope_theta(hdit.axial_pos(H, W), hdit.rope_freqs(nh))
+    qs, ks = hdit.cosine_sim_scale(q.view(B, H, W, nh, 64), k.view(B, H, W, nh, 64), scale)
+    ref = hdit.attn_global(hdit.apply_rope(qs, theta).reshape(B, 1, T, nh, 64), hdit.apply_rope(ks, theta).reshape(B, 1, T, nh, 64), v, 1.0)
+    y = ops.attn_global(g(_pack(q, k, v)).view(B, T, -1), nh, prep=(g(scale), g(cos), g(sin))).view(B, 1, T, nh, 64)
+    assert relerr(y, ref) < 1e-4
+    # a peaked row (one dominant key far from the first block) exercises the running-max rescale
+    k2 = k.clone()
+    k2[:, :, T - 3] = q[:, :, 5] * 4.0
+    y = ops.attn_global(g(_pack(q, k2, v)).view(B, T, -1), nh).view(B, 1, T, nh, 64)
+    assert relerr(y, hdit.attn_global(q, k2, v, 1.0)) < 5e-4          # logits of order 100: 3e-5 relative on them
+    monkeypatch.setenv("KDIFF_GEMM", "exact")
+    with pytest.raises(RuntimeError, match="streaming"):
+        ops.attn_global(g(_pack(q, k, v)).view(B, T, -1), nh)
 
 
 @pytest.mark.parametrize("H,W,nh,B", [(7, 7, 1, 2), (8, 8, 2, 1), (9, 12, 1, 2), (16, 16, 2, 2), (20, 13, 1, 1), (32, 32, 4, 1)])
