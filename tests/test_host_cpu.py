@@ -44,7 +44,12 @@ def test_bad_arguments_are_rejected_without_a_gpu(KD):
     assert lib.kd_attn_window_f32(1, 1, 1, 16, 16, 1, 7, 0, 0, None, None, None, 1e-6, None) == -1
     assert b"window_size" in lib.kd_last_error()
     assert lib.kd_attn_na2d_f32(1, 1, 1, 16, 16, 1, 5, 0, None, None, None, 1e-6, None) == -1
-    assert lib.kd_attn_global_f32(1, 1, 1, 1024, 1, 0, None, None, None, 1e-6, None) == -1
+    assert lib.kd_attn_global_f32(1, 1, 1, 0, 1, 0, None, None, None, 1e-6, None) == -1
+    assert lib.kd_attn_global_f32(1, 1, 1, 64, 1, 1, None, None, None, 1e-6, None) == -1          # prep without its tables
+    assert b"prep" in lib.kd_last_error()
+    assert lib.kd_brownian_cached_f32(1, None, None, 1, 0, 1, 1, 8, 0.0, 1.0, 0.2, 0.4, 1.0, 36, None) == -1
+    assert b"cached end point" in lib.kd_last_error()
+    assert lib.kd_brownian_f32(1, 1, 1, 8, 0.0, 1.0, 0.5, 0.4, 1.0, 36, None) == -1            # t0 > t1
 
 
 def test_hot_path_has_no_cpu_fallback(KD):
