@@ -541,7 +541,8 @@ static int launch(const KdGemm& d, hipStream_t s) {
 
 }  // namespace kd
 
-namespace kd { int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc); }   // gemm_astat.hip
+namespace kd { int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc); }    // gemm_astat.hip
+namespace kd { int gemm_skinny_try(const KdGemm& d, hipStream_t s, int* rc); }   // gemm_skinny.hip
 
 using namespace kd;
 
@@ -567,6 +568,11 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
   // all rows of a 128-row tile share their scale vector: stage it in LDS once per tile
   e.scale_tab = e.norm && e.a_mode == KD_A_PLAIN && e.K <= SCALE_TAB_MAX_K && (e.scale_stride == 0 || e.rows_per_sample % BM == 0);
 
+  {
+    static const bool skinny_on = !(getenv("KDIFF_SKINNY") && getenv("KDIFF_SKINNY")[0] == '0');
+    int rc = 0;
+    if (skinny_on && !gemm_skinny_try(e, s, &rc)) return rc;   // <= 128 rows (one per sample): the conditioning chain
+  }
   {
     static const bool astat_on = !(getenv("KDIFF_ASTAT") && getenv("KDIFF_ASTAT")[0] == '0');
     int rc = 0;

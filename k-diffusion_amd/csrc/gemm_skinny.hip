@@ -1,0 +1,115 @@
+// Skinny GEMM for the conditioning chain: C[M, N] = epilogue( norm(A)[M, K] @ W[N, K]^T ) with M <= 128 rows.
+//
+// The mapping network, the time / class / augmentation embeddings and the AdaRMSNorm scale projection
+// (image_transformer_v2.py:569-581, :734-740, :155-166) multiply a [batch, width] activation by a weight: one row per
+// SAMPLE, not per token.  On the 128x128 MFMA tile kernel such a product is one or two workgroups walking K serially
+// (40-55 us of pure latency each on an otherwise idle chip).  Here the work is spread the other way round:
+//   * a workgroup owns 8 output columns (16 W rows for GEGLU) and up to 64 rows of A: lane = row;
+//   * its 4 waves split K; W is wave-uniform (scalar loads, one s_load_dwordx4 per column per 4 k), A comes as one
+//     16-byte load per lane per 4 k, the products are plain fp32 FMAs (flops are negligible: <= 0.1 GFLOP);
+//   * the 4 partial sums meet in LDS, then norm / GEGLU / +const / +residual and the store.
+// N/8 workgroups x 4 waves fill the chip's SIMDs where the tile kernel had 1-6 workgroups.  fp32 throughout (not
+// the bf16 split): both precision modes of kd_gemm_f32 route here.
+#include "kd_common.h"
+
+namespace kd {
+
+namespace skinny {
+
+constexpr int CB = 8;          // output columns per workgroup
+constexpr int ROWS = 64;       // rows per workgroup (lane = row)
+
+template <bool NORM, int EPI>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const KdGemm p) {
+  constexpr bool GEGLU = EPI == KD_EPI_GEGLU;
+  constexpr int NW = GEGLU ? 2 * CB : CB;                 // W rows (= accumulators per lane)
+  __shared__ float part[4][NW + 1][ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: W goes through s_load
+  const int M = p.M, N = p.N, K = p.K;
+  const int n0 = blockIdx.x * CB, m0 = blockIdx.y * ROWS;
+  const int row = min(m0 + lane, M - 1);
+  const float* __restrict__ ap = p.A + (long)row * K;
+  const float* __restrict__ W = p.W;
+  const float* __restrict__ sc = p.scale;                 // NORM: one scale vector for all rows (scale_stride == 0)
+
+  const float* wrow[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int n = min(n0 + (j % CB), N - 1);
+    wrow[j] = W + (long)(GEGLU && j >= CB ? N + n : n) * K;
+  }
+  float acc[NW], ssq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NW; ++j) acc[j] = 0.f;
+
+  const int nch = K >> 2;                                 // 4-wide k chunks; this wave's contiguous share
+  const int c0 = (int)((long)nch * wid / 4), c1 = (int)((long)nch * (wid + 1) / 4);
+#pragma unroll 2
+  for (int c = c0; c < c1; ++c) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(ap + 4 * c);
+    if (NORM) {
+      ssq += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+      a = a * *reinterpret_cast<const f32x4*>(sc + 4 * c);
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wrow[j] + 4 * c);      // wave-uniform address
+      acc[j] = fmaf(a[3], w[3], fmaf(a[2], w[2], fmaf(a[1], w[1], fmaf(a[0], w[0], acc[j]))));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NW; ++j) part[wid][j][lane] = acc[j];
+  part[wid][NW][lane] = ssq;
+  __syncthreads();
+
+  for (int idx = tid; idx < ROWS * CB; idx += 256) {
+    const int m = idx / CB, cc = idx % CB;
+    const int gm = m0 + m, gn = n0 + cc;
+    if (gm >= M || gn >= N) continue;
+    float v = part[0][cc][m] + part[1][cc][m] + part[2][cc][m] + part[3][cc][m];
+    float rs = 1.f;
+    if (NORM) rs = rsqrtf((part[0][NW][m] + part[1][NW][m] + part[2][NW][m] + part[3][NW][m]) / (float)K + p.eps);
+    v *= rs;
+    if (GEGLU) {
+      const float gate = (part[0][CB + cc][m] + part[1][CB + cc][m] + part[2][CB + cc][m] + part[3][CB + cc][m]) * rs;
+      v *= gelu_erf_fast(gate);
+    }
+    const long o = (long)gm * N + gn;
+    if (EPI == KD_EPI_STORE) v += p.out_add;
+    if (EPI == KD_EPI_RESIDUAL) v += p.R[o];
+    p.C[o] = v;
+  }
+}
+
+template <bool NORM, int EPI>
+static int launch(const KdGemm& d, hipStream_t s) {
+  const double n_eff = (EPI == KD_EPI_GEGLU) ? 2.0 * d.N : (double)d.N;
+  char nm[96] = "gemm_skinny";
+  if (prof_on()) snprintf(nm, sizeof(nm), "gemm_skinny<n%d,e%d> M=%d N=%d K=%d", (int)NORM, EPI, d.M, d.N, d.K);
+  LaunchScope prof(nm, 2.0 * d.M * n_eff * d.K,
+                   4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N * (EPI == KD_EPI_RESIDUAL ? 2.0 : 1.0)), s);
+  const dim3 grid((unsigned)((d.N + CB - 1) / CB), (unsigned)((d.M + ROWS - 1) / ROWS));
+  hipLaunchKernelGGL((gemm_skinny_kernel<NORM, EPI>), grid, dim3(256), 0, s, d);
+  return check_launch("kd_gemm_f32");
+}
+
+}  // namespace skinny
+
+// returns 0 when the descriptor was served here (*rc = launch status), 1 when it is not eligible
+int gemm_skinny_try(const KdGemm& d, hipStream_t s, int* rc) {
+  using namespace skinny;
+  if (d.M > 2 * ROWS || d.a_mode != KD_A_PLAIN || !d.W || d.debug) return 1;
+  if (d.norm && d.scale_stride != 0) return 1;            // per-sample scale vectors: not the conditioning chain's case
+  if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_RESIDUAL && d.epi != KD_EPI_GEGLU) return 1;
+#define KD_SK(NO, EP) if ((d.norm != 0) == NO && d.epi == EP) { *rc = launch<NO, EP>(d, s); return 0; }
+  KD_SK(false, KD_EPI_STORE)
+  KD_SK(true, KD_EPI_STORE)
+  KD_SK(false, KD_EPI_RESIDUAL)
+  KD_SK(true, KD_EPI_RESIDUAL)
+  KD_SK(false, KD_EPI_GEGLU)
+  KD_SK(true, KD_EPI_GEGLU)
+#undef KD_SK
+  return 1;
+}
+
+}  // namespace kd

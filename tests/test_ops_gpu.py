@@ -45,6 +45,27 @@ def test_gemm_plain_and_residual(ops, gtol, M, N, K):
     assert relerr(ops.linear(g(x), g(w), out_add=1.0), x @ w.T + 1) < gtol
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 256, 256), (7, 12, 12), (64, 260, 772), (65, 8, 256), (128, 52, 128), (32, 768, 256)])
+def test_skinny_gemm_rows_per_sample(ops, gtol, M, N, K):
+    """<= 128 rows (one per sample: mapping network, embeddings, AdaRMSNorm scale projection) are served by the
+    fp32 skinny kernel in both precision modes: every epilogue / prologue it takes, against torch."""
+    x, w, r = rn(M, K, seed=1), rn(N, K, seed=2) / K ** 0.5, rn(M, N, seed=3)
+    w2, gain = rn(2 * N, K, seed=4) / K ** 0.5, 1 + 0.2 * rn(K, seed=5)
+    assert relerr(ops.linear(g(x), g(w)), x @ w.T) < 2e-5
+    assert relerr(ops.linear(g(x), g(w), residual=g(r)), x @ w.T + r) < 2e-5
+    assert relerr(ops.linear(g(x), g(w), out_add=1.0), x @ w.T + 1) < 2e-5
+    val, gate = (x @ w2.T).chunk(2, dim=-1)
+    assert relerr(ops.linear_geglu(g(x), g(w2)), val * torch.nn.functional.gelu(gate)) < 2e-5
+    xn = x * torch.rsqrt(x.square().mean(-1, keepdim=True) + 1e-6) * gain
+    assert relerr(ops.norm_linear(g(x), g(gain), g(w), rows_per_sample=M), xn @ w.T) < 2e-5
+    val, gate = (xn @ w2.T).chunk(2, dim=-1)
+    assert relerr(ops.norm_linear(g(x), g(gain), g(w2), rows_per_sample=M, epi=__import__("k_diffusion_amd")._native.EPI_GEGLU), val * torch.nn.functional.gelu(gate)) < 2e-5
+    # per-sample scale vectors are not the skinny kernel's case: the tile kernels keep serving them
+    scales = 1 + 0.2 * rn(M, K, seed=6)
+    xs = x * torch.rsqrt(x.square().mean(-1, keepdim=True) + 1e-6) * scales
+    assert relerr(ops.norm_linear(g(x), g(scales), g(w), rows_per_sample=1), xs @ w.T) < gtol
+
+
 def test_split3_error_is_bounded_and_asymmetric_safe(ops, monkeypatch):
     """The split-bf16x3 product against an fp64 reference on wide-dynamic-range data: error stays ~2^-15-class
     relative to sum|a*b| (a transposed / permuted operand would show up as O(1))."""
