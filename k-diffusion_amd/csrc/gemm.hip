@@ -348,13 +348,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KdGemm p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         // ---- accumulators of rows 8g..8g+7 -> strip[8][NW] ----------------------------------------
+        if (EPI == KD_EPI_GEGLU) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = 4 * g + q, row8 = q + 4 * (lane >> 5);
-          if (EPI == KD_EPI_GEGLU) {
-            const float gate = acc[i][1][r] * rsv[r];
-            strip[row8 * NW + col_l] = (acc[i][0][r] * rsv[r]) * ((p.debug & 8) ? gate : gelu_erf_fast(gate));
-          } else {
+          for (int q = 0; q < 4; q += 2) {                // rows r, r+1: adjacent accumulator registers -> packed fp32 math
+            const int r = 4 * g + q, row8 = q + 4 * (lane >> 5);
+            const f32x2 rs2 = {rsv[r], rsv[r + 1]};
+            const f32x2 gate = f32x2{acc[i][1][r], acc[i][1][r + 1]} * rs2;
+            const f32x2 o = (f32x2{acc[i][0][r], acc[i][0][r + 1]} * rs2) * ((p.debug & 8) ? gate : gelu_erf_fast2(gate));
+            strip[row8 * NW + col_l] = o.x;
+            strip[(row8 + 1) * NW + col_l] = o.y;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int r = 4 * g + q, row8 = q + 4 * (lane >> 5);
             strip[row8 * NW + col_l] = acc[i][0][r] * rsv[r];
             strip[row8 * NW + 32 + col_l] = acc[i][1][r] * rsv[r];
           }

@@ -57,7 +57,10 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
 // several workgroups when M alone gives too few panels to fill the chip (each re-normalises the A panel: cheap next to
 // its share of W).  K = 512 keeps 256 VGPRs of A fragments per lane: one workgroup per CU, unified VGPR/AGPR file.
 template <int NC, int EPI>
-__global__ __launch_bounds__(256, NC == 8 ? 2 : 1) void gemm_astat_kernel(const KdGemm p) {
+#ifndef KD_LB2_MAXNC
+#define KD_LB2_MAXNC 8
+#endif
+__global__ __launch_bounds__(256, NC <= KD_LB2_MAXNC ? 2 : 1) void gemm_astat_kernel(const KdGemm p) {
   constexpr int K = NC * 16, NK = NC / 2;                 // NK: W stages per n-tile (multiple of NSTG)
   constexpr bool GEGLU = EPI == KD_EPI_GEGLU;
   constexpr int NCOL = GEGLU ? 64 : 128;                  // output columns per n-tile
@@ -120,6 +123,16 @@ __global__ __launch_bounds__(256, NC == 8 ? 2 : 1) void gemm_astat_kernel(const 
   float rsv[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) rsv[r] = rs_tab[wid * 32 + mfma32_row(r, lane)];
+#ifdef KD_PHASE
+  {   // timing experiment: de-phase the two co-resident workgroups of a CU (main loop of one over the epilogue of the other)
+#if KD_PHASE == 1
+    const unsigned odd = __builtin_amdgcn_s_getreg((11 << 11) | (0 << 6) | 6) != 0;          // LDS_ALLOC.base != 0: second workgroup on the CU
+#else
+    const unsigned odd = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 1;           // HW_ID.TG_ID parity
+#endif
+    if (odd) __builtin_amdgcn_s_sleep(KD_PHASE_SLEEP);
+  }
+#endif
 
   f32x16 acc[4];
 #pragma unroll
@@ -163,13 +176,23 @@ __global__ __launch_bounds__(256, NC == 8 ? 2 : 1) void gemm_astat_kernel(const 
       const int row_base = m0 + wid * 32 + 8 * g;
       if (EPI == KD_EPI_QKV && pass + 1 < NPASS) load_tab(pass + 1, cs_next, sn_next);
       // registers of rows 8g..8g+7 -> strip[8][64]
+      if (GEGLU) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int r = 4 * g + q, row8 = q + 4 * lh;
-        if (GEGLU) {
-          strip[row8 * 64 + l31] = (acc[0][r] * rsv[r]) * gelu_erf_fast(acc[1][r] * rsv[r]);
-          strip[row8 * 64 + 32 + l31] = (acc[2][r] * rsv[r]) * gelu_erf_fast(acc[3][r] * rsv[r]);
-        } else {
+        for (int q = 0; q < 4; q += 2) {                  // accumulator rows r, r+1 are adjacent registers: packed fp32 math
+          const int r = 4 * g + q, row8 = q + 4 * lh;
+          const f32x2 rs2 = {rsv[r], rsv[r + 1]};
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const f32x2 val = f32x2{acc[2 * hh][r], acc[2 * hh][r + 1]} * rs2;
+            const f32x2 o = val * gelu_erf_fast2(f32x2{acc[2 * hh + 1][r], acc[2 * hh + 1][r + 1]} * rs2);
+            strip[row8 * 64 + 32 * hh + l31] = o.x;
+            strip[(row8 + 1) * 64 + 32 * hh + l31] = o.y;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 4 * g + q, row8 = q + 4 * lh;
           strip[row8 * 64 + l31] = acc[2 * half][r] * rsv[r];
           strip[row8 * 64 + 32 + l31] = acc[2 * half + 1][r] * rsv[r];
         }
@@ -200,10 +223,12 @@ __global__ __launch_bounds__(256, NC == 8 ? 2 : 1) void gemm_astat_kernel(const 
     for (int ks = 0; ks < NK; ++ks) {
       const int s = nt * NK + ks;
       // Stage s has landed?  Stages ks = 0, 1 of every tile but the first were confirmed before the previous epilogue.
+#ifndef KD_ABL_NOSYNC
       if (nt == 0 || ks >= 2) {
         if (s + 2 < total) KD_WAIT_VM(8); else if (s + 1 < total) KD_WAIT_VM(4); else KD_WAIT_VM(0);
       }
       KD_BARRIER();                      // every wave's quarter of stage s is in; everyone is done reading slot (s-1) % NSTG
+#endif
       if (s + 3 < total) issue(s + 3);   // refill the slot freed by stage s-1
       const char* st = ring + (ks % NSTG) * STAGE;
 #pragma unroll
@@ -213,21 +238,34 @@ __global__ __launch_bounds__(256, NC == 8 ? 2 : 1) void gemm_astat_kernel(const 
         bf16x8 bh[4], bl[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+#ifdef KD_ABL_NOLDS
+          bh[j] = ah[(c + j) % NC]; bl[j] = al[(c + j) % NC];
+#else
           bh[j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 64 + o);
           bl[j] = *reinterpret_cast<const bf16x8*>(st + IMG + j * 32 * 64 + o);
+#endif
         }
+#ifdef KD_ABL_NOMFMA
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(bh[j]), "v"(bl[j]), "v"(ah[c]), "v"(al[c]));
+#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[c], bh[j], acc[j], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c], bl[j], acc[j], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c], bh[j], acc[j], 0, 0, 0);
+#endif
       }
     }
     // stages (nt+1, ks = 0, 1) were requested >= 2 stages ago: confirm them now, before the stores of this epilogue
     // enter the vector-memory queue (outstanding after the last issue: stages s+1, s+2, s+3 -> leave only s+3)
     if (nt + 1 < n_tiles) KD_WAIT_VM(4);
+#ifdef KD_ABL_NOEPI
+    if (p.eps < 0.f) epilogue(nt);       // never true: keeps the accumulators alive without the epilogue's cost
+#else
     epilogue(nt);
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll

@@ -75,6 +75,33 @@ __device__ __forceinline__ float erf_fast(float a) {
 }
 __device__ __forceinline__ float gelu_erf_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
+// Two GELUs per instruction stream: the same polynomial on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 run two lanes' worth
+// of fp32 per issue), log2(e) folded into the coefficients so the exponential is a bare v_exp_f32.  The GEGLU epilogues are
+// VALU-bound (both co-resident workgroups sit in their epilogues together), so issue slots are what they pay for.
+using f32x2 = float __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
+  constexpr float L2E = 1.4426950408889634f;
+  const f32x2 a = x * 0.70710678118654752440f;
+  const f32x2 t = {fminf(fabsf(a.x), 6.0f), fminf(fabsf(a.y), 6.0f)};
+  f32x2 r = f32x2{-5.2967772e-07f * L2E, -5.2967772e-07f * L2E};
+#define KD_PK_STEP(c) r = __builtin_elementwise_fma(r, t, f32x2{(c) * L2E, (c) * L2E})
+  KD_PK_STEP(1.1485352e-05f);
+  KD_PK_STEP(-1.0681756e-04f);
+  KD_PK_STEP(5.4055965e-04f);
+  KD_PK_STEP(-1.4155075e-03f);
+  KD_PK_STEP(-1.7897904e-04f);
+  KD_PK_STEP(1.9390738e-02f);
+  KD_PK_STEP(-1.0285765e-01f);
+  KD_PK_STEP(-6.3660932e-01f);
+  KD_PK_STEP(-1.1283793e+00f);
+#undef KD_PK_STEP
+  const f32x2 e = r * t;
+  const f32x2 om = f32x2{1.0f, 1.0f} - f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+  const f32x2 er = {copysignf(om.x, a.x), copysignf(om.y, a.y)};
+  const f32x2 h = x * 0.5f;
+  return __builtin_elementwise_fma(h, er, h);
+}
+
 constexpr int KD_ROT = 16;       // rotary angles per head: dims [0,16) pair with [16,32)
 // ---- DPP helpers: cross-lane moves inside a 16-lane row as plain VALU ops (no LDS round trip like ds_bpermute) ----
 template <int CTRL>
