@@ -81,14 +81,21 @@ __device__ __host__ __forceinline__ int w_row_of(int nt, int r, int N, bool gegl
   return (nt * BN + r < N) ? nt * BN + r : -1;
 }
 
-template <int AMODE, bool NORM, int EPI, int PREC>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const KdGemm p) {
+// KS = 2 ("K split inside the workgroup", split3 + plain A + no norm only): 512 threads, two 256-thread groups that each
+// run the whole pipeline below on their own half of K with their own pair of LDS stages; group 1 then hands its
+// accumulators to group 0 through LDS (fixed order: deterministic), which runs the epilogue.  For shapes whose tile count
+// does not even fill the chip once (level-2 out / down projections: 256 tiles, 16-48 K-steps each) this doubles the waves
+// per SIMD and halves the serial K walk, where splitting K over workgroups would need atomics or a second pass.
+template <int AMODE, bool NORM, int EPI, int PREC, int KS = 1>
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_kernel(const KdGemm p) {
   constexpr bool SPLIT = PREC == KD_PREC_SPLIT3;
+  static_assert(KS == 1 || (SPLIT && !NORM && AMODE == KD_A_PLAIN), "K split: split3, plain A, no norm prologue");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int grp = KS == 1 ? 0 : (int)(threadIdx.x >> 8);
   float* As = smem;                       // exact mode
   float* Bs = smem + 2 * BM * S;
-  char* stage0 = reinterpret_cast<char*>(smem);   // split mode
-  float* rs = SPLIT ? reinterpret_cast<float*>(stage0 + 2 * STAGE) : Bs + 2 * BN * S;
+  char* stage0 = reinterpret_cast<char*>(smem) + grp * (2 * STAGE);   // split mode: this group's two stages
+  float* rs = SPLIT ? reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + KS * 2 * STAGE) : Bs + 2 * BN * S;
 
   // 4 wave-private [8][64] epilogue strips: split mode has room for its own region; exact mode reuses the first
   // A stage (every wave is past the K loop's last barrier when the epilogue starts)
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KdGemm p) {
   float* sc_tab = rs + BM + (SPLIT ? 4 * 8 * 64 : 0);      // [K] norm scales of this tile's sample (when p.scale_tab)
   const bool use_tab = NORM && p.scale_tab;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   constexpr int NCOL = (EPI == KD_EPI_GEGLU) ? 64 : BN;   // output columns covered per tile
   const int n_tiles = (p.N + NCOL - 1) / NCOL;
@@ -113,7 +120,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KdGemm p) {
   const int nt = tile % n_tiles, mt = tile / n_tiles;
   const int m0 = mt * BM, n0 = nt * NCOL;
   const int M = p.M, N = p.N, K = p.K;
-  const int nk = (K + BK - 1) / BK;
+  const int nk_all = (K + BK - 1) / BK;
+  const int nk = nk_all / KS, kt0 = grp * nk;             // this group's K-steps: kt0 .. kt0 + nk - 1 (host: nk_all % KS == 0)
 
   // ---- per-thread load coordinates: tile rows r0 + 32*j, j < NLD, k-chunk kc (same every K-step) --------
   // Loads are branch-free (out-of-range rows / k are clamped to a valid address and zeroed when the registers are
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KdGemm p) {
     }
   };
   // W tile: exact mode gathers fp32 rows; split mode copies the packed, pre-swizzled bf16 image verbatim
-  const char* wp_tile = SPLIT ? reinterpret_cast<const char*>(p.Wp) + (size_t)nt * nk * WP_BLOCK : nullptr;
+  const char* wp_tile = SPLIT ? reinterpret_cast<const char*>(p.Wp) + (size_t)nt * nk_all * WP_BLOCK : nullptr;
   auto load_b = [&](int kt, f32x4 (&rb)[NLD]) {
     if (SPLIT) {
       const f32x4* src = reinterpret_cast<const f32x4*>(wp_tile + (size_t)kt * WP_BLOCK) + tid;
@@ -289,22 +297,49 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const KdGemm p) {
   };
 
   // distance-2 pipeline, unrolled by two so that both register sets have static names
-  load_a(0, ra0); load_b(0, rb0);
-  if (nk > 1) { load_a(BK, ra1); load_b(1, rb1); }
-  store_tiles(0, 0, ra0, rb0);
+  load_a(kt0 * BK, ra0); load_b(kt0, rb0);
+  if (nk > 1) { load_a((kt0 + 1) * BK, ra1); load_b(kt0 + 1, rb1); }
+  store_tiles(0, kt0 * BK, ra0, rb0);
   __syncthreads();
   for (int kt = 0; kt < nk; kt += 2) {
     // tile kt is in LDS buffer 0, set 1 holds tile kt+1 (in flight), set 0 is free
-    if (kt + 2 < nk) { load_a((kt + 2) * BK, ra0); load_b(kt + 2, rb0); }
+    if (kt + 2 < nk) { load_a((kt0 + kt + 2) * BK, ra0); load_b(kt0 + kt + 2, rb0); }
     compute(0);
-    if (kt + 1 < nk) store_tiles(1, (kt + 1) * BK, ra1, rb1);
+    if (kt + 1 < nk) store_tiles(1, (kt0 + kt + 1) * BK, ra1, rb1);
     __syncthreads();
     if (kt + 1 >= nk) break;
     // tile kt+1 is in LDS buffer 1, set 0 holds tile kt+2 (in flight), set 1 is free
-    if (kt + 3 < nk) { load_a((kt + 3) * BK, ra1); load_b(kt + 3, rb1); }
+    if (kt + 3 < nk) { load_a((kt0 + kt + 3) * BK, ra1); load_b(kt0 + kt + 3, rb1); }
     compute(1);
-    if (kt + 2 < nk) store_tiles(0, (kt + 2) * BK, ra0, rb0);
+    if (kt + 2 < nk) store_tiles(0, (kt0 + kt + 2) * BK, ra0, rb0);
     __syncthreads();
+  }
+
+  if (KS == 2) {
+    // group 1 -> group 0: 64 accumulator floats per thread through group 1's (now idle) stages, 16 bytes per lane per
+    // access at (j * 256 + tid): conflict-free, and the same tid holds the same fragment positions in both groups
+    f32x4* xch = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + 2 * STAGE);
+    if (grp == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            xch[((i * 2 + j) * 4 + q) * 256 + tid] = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 o = xch[((i * 2 + j) * 4 + q) * 256 + tid];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[i][j][4 * q + u] += o[u];
+        }
   }
 
   if (NORM) {
@@ -524,13 +559,13 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   *reinterpret_cast<uint4*>(dst + IMG) = uint4{l0[0], l0[1], l1[0], l1[1]};
 }
 
-template <int AMODE, bool NORM, int EPI, int PREC>
+template <int AMODE, bool NORM, int EPI, int PREC, int KS = 1>
 static int launch(const KdGemm& d, hipStream_t s) {
-  constexpr size_t LDS_BASE = PREC == KD_PREC_SPLIT3 ? LDS_SPLIT : LDS_EXACT;
+  constexpr size_t LDS_BASE = PREC == KD_PREC_SPLIT3 ? LDS_SPLIT + (KS - 1) * 2 * STAGE : LDS_EXACT;
   constexpr size_t LDS_BYTES = LDS_BASE + (NORM ? SCALE_TAB_MAX_K * sizeof(float) : 0);
   constexpr int NCOL = (EPI == KD_EPI_GEGLU) ? 64 : BN;
   const long tiles = (long)((d.M + BM - 1) / BM) * ((d.N + NCOL - 1) / NCOL);
-  auto kern = gemm_kernel<AMODE, NORM, EPI, PREC>;
+  auto kern = gemm_kernel<AMODE, NORM, EPI, PREC, KS>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
@@ -538,11 +573,11 @@ static int launch(const KdGemm& d, hipStream_t s) {
   }
   const double n_eff = (EPI == KD_EPI_GEGLU) ? 2.0 * d.N : (double)d.N;
   char nm[96] = "gemm";
-  if (prof_on()) snprintf(nm, sizeof(nm), "gemm_%s<a%d,n%d,e%d> M=%d N=%d K=%d", PREC == KD_PREC_SPLIT3 ? "bf16x3" : "f32", AMODE, (int)NORM, EPI, d.M, d.N, d.K);
+  if (prof_on()) snprintf(nm, sizeof(nm), "gemm_%s<a%d,n%d,e%d%s> M=%d N=%d K=%d", PREC == KD_PREC_SPLIT3 ? "bf16x3" : "f32", AMODE, (int)NORM, EPI, KS == 2 ? ",ks2" : "", d.M, d.N, d.K);
   // algorithmic bytes: A once, W once, C once (+ the residual / skip / x_in operand of the epilogues that read one)
   const double r_bytes = (EPI == KD_EPI_RESIDUAL || EPI == KD_EPI_SPLIT_LERP || (EPI == KD_EPI_UNPATCH_NCHW && d.sigma)) ? 4.0 * d.M * d.N : 0.0;
   LaunchScope prof(nm, 2.0 * d.M * n_eff * d.K, 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N) + r_bytes, s);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), LDS_BYTES, s, d);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256 * KS), LDS_BYTES, s, d);
   return check_launch("kd_gemm_f32");
 }
 
@@ -587,6 +622,17 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
   }
   if (e.precision != KD_PREC_EXACT && e.precision != KD_PREC_SPLIT3) return fail(KD_EINVAL, "kd_gemm_f32: unknown precision %d", e.precision);
   if (e.precision == KD_PREC_SPLIT3 && !e.Wp) return fail(KD_EINVAL, "kd_gemm_f32: split3 needs the packed weight image Wp (kd_pack_weight_bf16x3)");
+  {
+    // residual / plain projections whose tiles do not even fill the chip once and that walk a long K: split K inside the
+    // workgroup (two wave groups, deterministic in-LDS reduction)
+    static const bool ks_on = !(getenv("KDIFF_KSPLIT") && getenv("KDIFF_KSPLIT")[0] == '0');
+    const long tiles = (long)((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);
+    const int nk = (e.K + BK - 1) / BK;
+    if (ks_on && e.precision == KD_PREC_SPLIT3 && e.Wp && e.a_mode == KD_A_PLAIN && !e.norm && !e.debug && tiles <= 256 && nk >= 8 && nk % 4 == 0) {
+      if (e.epi == KD_EPI_RESIDUAL) return launch<KD_A_PLAIN, false, KD_EPI_RESIDUAL, KD_PREC_SPLIT3, 2>(e, s);
+      if (e.epi == KD_EPI_STORE) return launch<KD_A_PLAIN, false, KD_EPI_STORE, KD_PREC_SPLIT3, 2>(e, s);
+    }
+  }
 #define KD_CASE(AM, NO, EP)                                             \
   if (e.a_mode == AM && (e.norm != 0) == NO && e.epi == EP)             \
     return e.precision == KD_PREC_SPLIT3 ? launch<AM, NO, EP, KD_PREC_SPLIT3>(e, s) : launch<AM, NO, EP, KD_PREC_EXACT>(e, s);

@@ -29,13 +29,13 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-constexpr int BM = 128;                 // rows per workgroup (4 waves x 32)
+constexpr int BM = 128;                 // rows per workgroup of the 4-wave form (4 waves x 32); the 8-wave form owns 2 * BM
 constexpr int BK = 32;                  // K per W stage
 constexpr int IMG = 128 * BK * 2;       // one bf16 image of a stage: [128 W rows][32 k] = 8 KiB
 constexpr int STAGE = 2 * IMG;          // hi + lo = 16 KiB  (== WP_BLOCK of gemm.hip)
 constexpr int NSTG = 4;                 // ring depth
 constexpr int LDS_RING = NSTG * STAGE;  // 64 KiB
-constexpr int LDS_BYTES = LDS_RING + 4 * 8 * 64 * 4 + BM * 4 + 64;   // + epilogue strips + row rsqrt table + sqrt(qk scale) per head (<= 16)
+constexpr int lds_bytes(int nwv) { return LDS_RING + nwv * 8 * 64 * 4 + nwv * 32 * 4 + 64; }   // + epilogue strips + row rsqrt table + sqrt(qk scale) per head (<= 16)
 
 __device__ __forceinline__ int swz(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -56,11 +56,13 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
 // NC = K / 16 (8, 16 or 32); EPI: KD_EPI_STORE / KD_EPI_QKV / KD_EPI_GEGLU.  gridDim.y splits the n-tiles of a panel over
 // several workgroups when M alone gives too few panels to fill the chip (each re-normalises the A panel: cheap next to
 // its share of W).  K = 512 keeps 256 VGPRs of A fragments per lane: one workgroup per CU, unified VGPR/AGPR file.
-template <int NC, int EPI>
-#ifndef KD_LB2_MAXNC
-#define KD_LB2_MAXNC 8
-#endif
-__global__ __launch_bounds__(256, NC <= KD_LB2_MAXNC ? 2 : 1) void gemm_astat_kernel(const KdGemm p) {
+// NWV = waves per workgroup (4 or 8): an 8-wave workgroup owns a 256-row panel fed by ONE W ring -- half the L2 -> CU
+// bytes per flop of two co-resident 4-wave workgroups.  The vector-memory path delivers ~10-13 B/clk/CU even on L2 hits
+// (every tiled / streamed kernel here tops out there), so bytes per flop into the CU is what the main loop pays for.
+template <int NC, int EPI, int NWV>
+__global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_astat_kernel(const KdGemm p) {
+  constexpr int BMW = NWV * 32;                           // rows of this workgroup's panel
+  constexpr int PCS = 4 * 4 / NWV;                        // 1 KiB pieces of a W stage moved by each wave (4 or 2)
   constexpr int K = NC * 16, NK = NC / 2;                 // NK: W stages per n-tile (multiple of NSTG)
   constexpr bool GEGLU = EPI == KD_EPI_GEGLU;
   constexpr int NCOL = GEGLU ? 64 : 128;                  // output columns per n-tile
@@ -68,8 +70,8 @@ __global__ __launch_bounds__(256, NC <= KD_LB2_MAXNC ? 2 : 1) void gemm_astat_ke
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;
   float* strips = reinterpret_cast<float*>(smem + LDS_RING);
-  float* rs_tab = strips + 4 * 8 * 64;
-  float* sq_tab = rs_tab + BM;
+  float* rs_tab = strips + NWV * 8 * 64;
+  float* sq_tab = rs_tab + BMW;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int M = p.M, N = p.N;
@@ -77,15 +79,15 @@ __global__ __launch_bounds__(256, NC <= KD_LB2_MAXNC ? 2 : 1) void gemm_astat_ke
   const int nt_begin = (int)((long)n_tiles_all * blockIdx.y / gridDim.y), nt_end = (int)((long)n_tiles_all * (blockIdx.y + 1) / gridDim.y);
   const int n_tiles = nt_end - nt_begin;                  // n-tiles of this workgroup
   const int total = n_tiles * NK;                         // its W stages
-  const int m0 = blockIdx.x * BM;
+  const int m0 = blockIdx.x * BMW;
 
   // ---- W stage s -> ring slot s % NSTG (this wave's quarter: 4 x 1 KiB, lands at slot + wid*4 KiB + lane*16) ----------
   const char* wp = reinterpret_cast<const char*>(p.Wp) + (size_t)nt_begin * NK * STAGE;
   auto issue = [&](int s) {
-    const char* src = wp + (size_t)s * STAGE + wid * 4096 + lane * 16;
-    char* dst = ring + (s % NSTG) * STAGE + wid * 4096;
+    const char* src = wp + (size_t)s * STAGE + wid * (PCS * 1024) + lane * 16;
+    char* dst = ring + (s % NSTG) * STAGE + wid * (PCS * 1024);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < PCS; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 1024),
                                        (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
   };
@@ -124,13 +126,19 @@ __global__ __launch_bounds__(256, NC <= KD_LB2_MAXNC ? 2 : 1) void gemm_astat_ke
 #pragma unroll
   for (int r = 0; r < 16; ++r) rsv[r] = rs_tab[wid * 32 + mfma32_row(r, lane)];
 #ifdef KD_PHASE
+#ifndef KD_PHASE_REPEAT
+#define KD_PHASE_REPEAT 1
+#endif
   {   // timing experiment: de-phase the two co-resident workgroups of a CU (main loop of one over the epilogue of the other)
 #if KD_PHASE == 1
     const unsigned odd = __builtin_amdgcn_s_getreg((11 << 11) | (0 << 6) | 6) != 0;          // LDS_ALLOC.base != 0: second workgroup on the CU
 #else
     const unsigned odd = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 1;           // HW_ID.TG_ID parity
 #endif
-    if (odd) __builtin_amdgcn_s_sleep(KD_PHASE_SLEEP);
+    if (odd) {
+#pragma unroll
+      for (int i = 0; i < KD_PHASE_REPEAT; ++i) __builtin_amdgcn_s_sleep(KD_PHASE_SLEEP);
+    }
   }
 #endif
 
@@ -225,7 +233,8 @@ __global__ __launch_bounds__(256, NC <= KD_LB2_MAXNC ? 2 : 1) void gemm_astat_ke
       // Stage s has landed?  Stages ks = 0, 1 of every tile but the first were confirmed before the previous epilogue.
 #ifndef KD_ABL_NOSYNC
       if (nt == 0 || ks >= 2) {
-        if (s + 2 < total) KD_WAIT_VM(8); else if (s + 1 < total) KD_WAIT_VM(4); else KD_WAIT_VM(0);
+        if (NWV == 4) { if (s + 2 < total) KD_WAIT_VM(8); else if (s + 1 < total) KD_WAIT_VM(4); else KD_WAIT_VM(0); }
+        else { if (s + 2 < total) KD_WAIT_VM(4); else if (s + 1 < total) KD_WAIT_VM(2); else KD_WAIT_VM(0); }
       }
       KD_BARRIER();                      // every wave's quarter of stage s is in; everyone is done reading slot (s-1) % NSTG
 #endif
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(256, NC <= KD_LB2_MAXNC ? 2 : 1) void gemm_astat_ke
     }
     // stages (nt+1, ks = 0, 1) were requested >= 2 stages ago: confirm them now, before the stores of this epilogue
     // enter the vector-memory queue (outstanding after the last issue: stages s+1, s+2, s+3 -> leave only s+3)
-    if (nt + 1 < n_tiles) KD_WAIT_VM(4);
+    if (nt + 1 < n_tiles) { if (NWV == 4) KD_WAIT_VM(4); else KD_WAIT_VM(2); }
 #ifdef KD_ABL_NOEPI
     if (p.eps < 0.f) epilogue(nt);       // never true: keeps the accumulators alive without the epilogue's cost
 #else
@@ -273,9 +282,10 @@ __global__ __launch_bounds__(256, NC <= KD_LB2_MAXNC ? 2 : 1) void gemm_astat_ke
   }
 }
 
-template <int NC, int EPI>
+template <int NC, int EPI, int NWV>
 static int launch(const KdGemm& d, hipStream_t s) {
-  auto kern = gemm_astat_kernel<NC, EPI>;
+  auto kern = gemm_astat_kernel<NC, EPI, NWV>;
+  constexpr int LDS_BYTES = lds_bytes(NWV), BMW = NWV * 32;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -286,10 +296,10 @@ static int launch(const KdGemm& d, hipStream_t s) {
   if (prof_on()) snprintf(nm, sizeof(nm), "gemm_astat<e%d> M=%d N=%d K=%d", EPI, d.M, d.N, d.K);
   LaunchScope prof(nm, 2.0 * d.M * n_eff * d.K, 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N), s);
   // panels x n-splits: aim at >= 256 workgroups (one per CU) while every split keeps >= 2 n-tiles
-  const int panels = (d.M + BM - 1) / BM, n_tiles = d.N / (EPI == KD_EPI_GEGLU ? 64 : 128);
+  const int panels = (d.M + BMW - 1) / BMW, n_tiles = d.N / (EPI == KD_EPI_GEGLU ? 64 : 128);
   int splits = 1;
   while (panels * splits < 256 && n_tiles / (splits * 2) >= 2) splits *= 2;
-  hipLaunchKernelGGL(kern, dim3((unsigned)panels, (unsigned)splits), dim3(256), LDS_BYTES, s, d);
+  hipLaunchKernelGGL(kern, dim3((unsigned)panels, (unsigned)splits), dim3(64 * NWV), LDS_BYTES, s, d);
   return check_launch("kd_gemm_f32(astat)");
 }
 
@@ -307,7 +317,20 @@ int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
   if (!(d.scale_stride == 0 || d.rows_per_sample % BM == 0)) return 1;          // one scale vector per panel
   if (d.epi == KD_EPI_QKV && (d.rows_per_sample % BM || d.n_heads > 16)) return 1;
   if (d.M < 4 * BM) return 1;
-#define KD_AS(NCV, EP) if (d.K == NCV * 16 && d.epi == EP) { *rc = launch<NCV, EP>(d, s); return 0; }
+  // 256-row panels (8 waves, one W ring; KDIFF_ASTAT_WAVES=8) where the A fragments leave room for two waves per SIMD
+  // (K = 128) and the panel grid still fills the chip.  Measured neutral against two co-resident 4-wave workgroups
+  // (level-0 qkv 59 -> 65 us, GEGLU 117 -> 114 us, end to end -0.4 %: profiles/r01_astat_ablation.md), so the 4-wave
+  // form stays the default: halving the W bytes into the CU is not what the main loop waits for.
+  const char* mw = getenv("KDIFF_ASTAT_WAVES");             // read per call (tests switch it inside one process)
+  const int max_waves = mw ? atoi(mw) : 4;
+  const bool wide = max_waves >= 8 && d.K == 128 && d.M >= 256 * 2 * BM && (d.scale_stride == 0 || d.rows_per_sample % (2 * BM) == 0) &&
+                    (d.epi != KD_EPI_QKV || d.rows_per_sample % (2 * BM) == 0);
+#define KD_AS(NCV, EP) if (d.K == NCV * 16 && d.epi == EP) { *rc = launch<NCV, EP, 4>(d, s); return 0; }
+  if (wide) {
+    if (d.epi == KD_EPI_STORE) { *rc = launch<8, KD_EPI_STORE, 8>(d, s); return 0; }
+    if (d.epi == KD_EPI_QKV) { *rc = launch<8, KD_EPI_QKV, 8>(d, s); return 0; }
+    if (d.epi == KD_EPI_GEGLU) { *rc = launch<8, KD_EPI_GEGLU, 8>(d, s); return 0; }
+  }
   KD_AS(8, KD_EPI_STORE) KD_AS(8, KD_EPI_QKV) KD_AS(8, KD_EPI_GEGLU)
   KD_AS(16, KD_EPI_STORE) KD_AS(16, KD_EPI_QKV) KD_AS(16, KD_EPI_GEGLU)
   KD_AS(32, KD_EPI_STORE) KD_AS(32, KD_EPI_QKV) KD_AS(32, KD_EPI_GEGLU)

@@ -37,7 +37,7 @@ def g(t):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (131, 200, 96), (32, 768, 256), (1000, 48, 128), (5, 7 * 4, 12), (384, 512, 1536),
-                                   (257, 129, 48), (64, 3072, 512)])
+                                   (257, 129, 48), (64, 3072, 512), (300, 130, 256), (2048, 512, 512), (1000, 256, 1536)])
 def test_gemm_plain_and_residual(ops, gtol, M, N, K):
     x, w, r = rn(M, K, seed=1), rn(N, K, seed=2) / K ** 0.5, rn(M, N, seed=3)
     assert relerr(ops.linear(g(x), g(w)), x @ w.T) < gtol
@@ -129,12 +129,16 @@ def test_qkv_epilogue_prepares_q_and_k(ops, gtol):
 
 
 @pytest.mark.parametrize("M,K,N,kind", [(1024, 128, 384, "qkv"), (1000, 128, 768, "geglu"), (4096, 256, 768, "qkv"), (640, 256, 1536, "geglu"),
-                                        (8192, 512, 1536, "qkv"), (2048, 512, 3072, "geglu"), (768, 512, 512, "store"), (520, 128, 256, "store")])
+                                        (8192, 512, 1536, "qkv"), (2048, 512, 3072, "geglu"), (768, 512, 512, "store"), (520, 128, 256, "store"),
+                                        # >= 65536 rows at K = 128: the 8-wave / 256-row-panel form (ragged last panel included)
+                                        (65536, 128, 384, "qkv"), (65736, 128, 768, "geglu"), (65736, 128, 256, "store"), (131072, 128, 384, "geglu")])
 def test_wide_projections_a_stationary(ops, monkeypatch, M, K, N, kind):
     """The A-stationary kernel (gemm_astat.hip: K in {128, 256, 512}, >= 2 n-tiles, M >= 512) against the oracle at
     shapes that exercise its n-split grids (few panels), a ragged last panel, per-sample and shared norm scales, and all
     three epilogues (store, GEGLU, qkv with q/k preparation)."""
     monkeypatch.setenv("KDIFF_GEMM", "split3")
+    if M >= 65536:
+        monkeypatch.setenv("KDIFF_ASTAT_WAVES", "8")       # the optional 8-wave / 256-row-panel form
     B = 4 if M % 4 == 0 and (M // 4) % 128 == 0 else 1
     T = M // B
     x = rn(M, K, seed=1)
