@@ -34,8 +34,13 @@ def family_of(symbol):
                          ("attn_dense_kernel<1", "attn_window_f32"), ("sampler_step_kernel", "sampler_step_f32")):
         if needle in symbol:
             return name
-    if "gemm_kernel<" in symbol:
-        return "gemm_bf16x3" if symbol.rstrip(">(KdGemm) ").endswith("1") else "gemm_f32"
+    if "gemm_skinny_kernel" in symbol:
+        return "gemm_skinny"
+    if "attn_global_long_kernel" in symbol:
+        return "attn_global_bf16x3"
+    if "gemm_kernel<" in symbol:        # gemm_kernel<AMODE, NORM, EPI, PREC[, KS]>: PREC 1 = split-bf16x3
+        args = [a.strip() for a in symbol.split("gemm_kernel<", 1)[1].split(">", 1)[0].split(",")]
+        return "gemm_bf16x3" if len(args) >= 4 and args[3] == "1" else "gemm_f32"
     return None
 
 
