@@ -120,6 +120,7 @@ __global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_
     if (lh == 0) rs_tab[wid * 32 + l31] = rsqrtf(ssq / (float)K + p.eps);
     if (EPI == KD_EPI_QKV && tid < p.n_heads) sq_tab[tid] = sqrtf(p.qk_scale[tid]);
   }
+  const bool full_panel = m0 + BMW <= M && !(p.debug & 32);   // (debug bit 32: keep the conservative wait, for A/B runs)    // every row of the panel exists: every epilogue store is issued
   const int tok0 = EPI == KD_EPI_QKV ? (m0 + wid * 32) % p.rows_per_sample : 0;   // token of this wave's first row (panels never straddle samples)
   __syncthreads();       // rs_tab visible (also drains this wave's first W stages: they are needed next anyway)
   float rsv[16];
@@ -192,7 +193,11 @@ __global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
             const f32x2 val = f32x2{acc[2 * hh][r], acc[2 * hh][r + 1]} * rs2;
+#ifdef KD_ABL_NOGELU
+            const f32x2 o = val * (f32x2{acc[2 * hh + 1][r], acc[2 * hh + 1][r + 1]} * rs2);
+#else
             const f32x2 o = val * gelu_erf_fast2(f32x2{acc[2 * hh + 1][r], acc[2 * hh + 1][r + 1]} * rs2);
+#endif
             strip[row8 * 64 + 32 * hh + l31] = o.x;
             strip[(row8 + 1) * 64 + 32 * hh + l31] = o.y;
           }
@@ -215,7 +220,12 @@ __global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_
         f32x4 v = *reinterpret_cast<const f32x4*>(strip + row8 * 64 + c4);
         if (EPI == KD_EPI_QKV && which < 2) v = prep_row16_regs(v, lane & 15, sq_tab[head], cs[t], sn[t], p.eps);
         if (EPI == KD_EPI_STORE) v = v + p.out_add;
+#ifdef KD_ABL_NOSTORE
+        if (p.eps < 0.f) *reinterpret_cast<f32x4*>(p.C + (long)gm * N + gn) = v;     // never true
+        else asm volatile("" ::"v"(v));
+#else
         if (gm < M) *reinterpret_cast<f32x4*>(p.C + (long)gm * N + gn) = v;
+#endif
       }
     };
 #pragma unroll
@@ -232,7 +242,17 @@ __global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_
       const int s = nt * NK + ks;
       // Stage s has landed?  Stages ks = 0, 1 of every tile but the first were confirmed before the previous epilogue.
 #ifndef KD_ABL_NOSYNC
-      if (nt == 0 || ks >= 2) {
+      if (nt > 0 && ks == 2 && full_panel && NWV == 4) {
+        // First counted wait after an epilogue.  vmcnt retires in issue order on gfx9-class hardware, loads and stores
+        // alike, and this wave's queue now reads [stage s][NST epilogue stores][stage s+1][stage s+2]: allowing the
+        // stores to stay outstanding (+NST) waits for stage s only.  Counting loads alone here made every n-tile wait for
+        // the acknowledgement of the previous tile's stores -- microseconds under HBM write pressure.  (Only when no row
+        // of the panel is masked: a masked row's store may not be issued at all.)
+        constexpr int NST = GEGLU ? 8 : 16;
+        if (s + 2 < total) { if (NST == 8) KD_WAIT_VM(16); else KD_WAIT_VM(24); }
+        else if (s + 1 < total) { if (NST == 8) KD_WAIT_VM(12); else KD_WAIT_VM(20); }
+        else { if (NST == 8) KD_WAIT_VM(8); else KD_WAIT_VM(16); }
+      } else if (nt == 0 || ks >= 2) {
         if (NWV == 4) { if (s + 2 < total) KD_WAIT_VM(8); else if (s + 1 < total) KD_WAIT_VM(4); else KD_WAIT_VM(0); }
         else { if (s + 2 < total) KD_WAIT_VM(4); else if (s + 1 < total) KD_WAIT_VM(2); else KD_WAIT_VM(0); }
       }
@@ -299,7 +319,10 @@ static int launch(const KdGemm& d, hipStream_t s) {
   const int panels = (d.M + BMW - 1) / BMW, n_tiles = d.N / (EPI == KD_EPI_GEGLU ? 64 : 128);
   int splits = 1;
   while (panels * splits < 256 && n_tiles / (splits * 2) >= 2) splits *= 2;
-  hipLaunchKernelGGL(kern, dim3((unsigned)panels, (unsigned)splits), dim3(64 * NWV), LDS_BYTES, s, d);
+  KdGemm e = d;
+  static const bool conservative = getenv("KDIFF_ASTAT_STOREWAIT") && getenv("KDIFF_ASTAT_STOREWAIT")[0] == '1';
+  if (conservative) e.debug |= 32;
+  hipLaunchKernelGGL(kern, dim3((unsigned)panels, (unsigned)splits), dim3(64 * NWV), LDS_BYTES, s, e);
   return check_launch("kd_gemm_f32(astat)");
 }
 
@@ -308,7 +331,7 @@ static int launch(const KdGemm& d, hipStream_t s) {
 // Eligibility + dispatch (called by kd_gemm_f32).  Returns 1 if the descriptor was not taken.
 int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
   using namespace astat;
-  if (d.precision != KD_PREC_SPLIT3 || d.a_mode != KD_A_PLAIN || !d.norm || !d.Wp || d.debug) return 1;
+  if (d.precision != KD_PREC_SPLIT3 || d.a_mode != KD_A_PLAIN || !d.norm || !d.Wp || (d.debug & ~32)) return 1;
   if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_QKV && d.epi != KD_EPI_GEGLU) return 1;
   static const int max_k = getenv("KDIFF_ASTAT_MAXK") ? atoi(getenv("KDIFF_ASTAT_MAXK")) : 512;    // A/B switch for benchmarks/
   if ((d.K != 128 && d.K != 256 && d.K != 512) || d.K > max_k) return 1;
