@@ -389,7 +389,8 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_kernel(const K
             const int r = 4 * g + q, row8 = q + 4 * (lane >> 5);
             const f32x2 rs2 = {rsv[r], rsv[r + 1]};
             const f32x2 gate = f32x2{acc[i][1][r], acc[i][1][r + 1]} * rs2;
-            const f32x2 o = (f32x2{acc[i][0][r], acc[i][0][r + 1]} * rs2) * ((p.debug & 8) ? gate : gelu_erf_fast2(gate));
+            const f32x2 val = f32x2{acc[i][0][r], acc[i][0][r + 1]} * rs2;
+            const f32x2 o = (p.debug & 8) ? val * gate : geglu_pair(val * 0.5f, gate);
             strip[row8 * NW + col_l] = o.x;
             strip[(row8 + 1) * NW + col_l] = o.y;
           }

@@ -190,13 +190,13 @@ __global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_
         for (int q = 0; q < 4; q += 2) {                  // accumulator rows r, r+1 are adjacent registers: packed fp32 math
           const int r = 4 * g + q, row8 = q + 4 * lh;
           const f32x2 rs2 = {rsv[r], rsv[r + 1]};
+          const f32x2 rsh = rs2 * 0.5f;
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
-            const f32x2 val = f32x2{acc[2 * hh][r], acc[2 * hh][r + 1]} * rs2;
 #ifdef KD_ABL_NOGELU
-            const f32x2 o = val * (f32x2{acc[2 * hh + 1][r], acc[2 * hh + 1][r + 1]} * rs2);
+            const f32x2 o = (f32x2{acc[2 * hh][r], acc[2 * hh][r + 1]} * rs2) * (f32x2{acc[2 * hh + 1][r], acc[2 * hh + 1][r + 1]} * rs2);
 #else
-            const f32x2 o = val * gelu_erf_fast2(f32x2{acc[2 * hh + 1][r], acc[2 * hh + 1][r + 1]} * rs2);
+            const f32x2 o = geglu_pair(f32x2{acc[2 * hh][r], acc[2 * hh][r + 1]} * rsh, f32x2{acc[2 * hh + 1][r], acc[2 * hh + 1][r + 1]} * rs2);
 #endif
             strip[row8 * 64 + 32 * hh + l31] = o.x;
             strip[(row8 + 1) * 64 + 32 * hh + l31] = o.y;

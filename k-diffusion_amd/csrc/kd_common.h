@@ -75,31 +75,28 @@ __device__ __forceinline__ float erf_fast(float a) {
 }
 __device__ __forceinline__ float gelu_erf_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
-// Two GELUs per instruction stream: the same polynomial on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 run two lanes' worth
-// of fp32 per issue), log2(e) folded into the coefficients so the exponential is a bare v_exp_f32.  The GEGLU epilogues are
-// VALU-bound (both co-resident workgroups sit in their epilogues together), so issue slots are what they pay for.
+// GEGLU on two outputs at once:  (value/2) * gate * (1 + erf(gate / sqrt 2)).
+// erf(t / sqrt 2) = 1 - 2^(t * Q(t)) with Q = log2(erfc(t / sqrt 2)) / t fitted by a degree-5 polynomial in the gate magnitude
+// t itself (the 1/sqrt 2 and log2 e live in the coefficients, the exponential is a bare v_exp_f32): |erf error| <= 3.1e-7 and
+// |gelu error| <= 4.8e-7 in fp32 over the whole range (clamp at 8.5, beyond which 2^(tQ) underflows to erf = 1).  The GEGLU
+// epilogues are bound by their VALU issue slots (profiles/r01_astat_ablation.md): this form needs ~17 per output where the
+// degree-9 erf_fast + separate scaling took ~23.  `vh` = value * 0.5 (the caller folds the 1/2 into its row scale).
 using f32x2 = float __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
-  constexpr float L2E = 1.4426950408889634f;
-  const f32x2 a = x * 0.70710678118654752440f;
-  const f32x2 t = {fminf(fabsf(a.x), 6.0f), fminf(fabsf(a.y), 6.0f)};
-  f32x2 r = f32x2{-5.2967772e-07f * L2E, -5.2967772e-07f * L2E};
-#define KD_PK_STEP(c) r = __builtin_elementwise_fma(r, t, f32x2{(c) * L2E, (c) * L2E})
-  KD_PK_STEP(1.1485352e-05f);
-  KD_PK_STEP(-1.0681756e-04f);
-  KD_PK_STEP(5.4055965e-04f);
-  KD_PK_STEP(-1.4155075e-03f);
-  KD_PK_STEP(-1.7897904e-04f);
-  KD_PK_STEP(1.9390738e-02f);
-  KD_PK_STEP(-1.0285765e-01f);
-  KD_PK_STEP(-6.3660932e-01f);
-  KD_PK_STEP(-1.1283793e+00f);
+__device__ __forceinline__ f32x2 geglu_pair(f32x2 vh, f32x2 g) {
+  const f32x2 t = {fminf(fabsf(g.x), 8.5f), fminf(fabsf(g.y), 8.5f)};
+  f32x2 r = f32x2{1.775372766132932e-05f, 1.775372766132932e-05f};
+#define KD_PK_STEP(c) r = __builtin_elementwise_fma(r, t, f32x2{(c), (c)})
+  KD_PK_STEP(-6.4774916972965e-04f);
+  KD_PK_STEP(7.724025286734104e-03f);
+  KD_PK_STEP(-5.2926722913980484e-02f);
+  KD_PK_STEP(-4.590827524662018e-01f);
+  KD_PK_STEP(-1.1511168479919434f);
 #undef KD_PK_STEP
   const f32x2 e = r * t;
   const f32x2 om = f32x2{1.0f, 1.0f} - f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-  const f32x2 er = {copysignf(om.x, a.x), copysignf(om.y, a.y)};
-  const f32x2 h = x * 0.5f;
-  return __builtin_elementwise_fma(h, er, h);
+  const f32x2 er = {copysignf(om.x, g.x), copysignf(om.y, g.y)};
+  const f32x2 vg = vh * g;
+  return __builtin_elementwise_fma(vg, er, vg);
 }
 
 constexpr int KD_ROT = 16;       // rotary angles per head: dims [0,16) pair with [16,32)
