@@ -161,6 +161,17 @@ int kd_precond_in_f32(const float* x, const float* sigma, float* y, float sigma_
 int kd_precond_out_f32(const float* f, const float* x, const float* sigma, float* y, float sigma_data, int batch,
                        long long per_sample, void* stream);
 
+/* DPM-Solver (k_diffusion/sampling.py:333-480) in the reference's operation order:
+ *   kd_dpm_eps_f32:     out = (x - denoised) / sigma                                  (DPMSolver.eps :354)
+ *   kd_dpm_combine_f32: out = x - a * eps [- b * (eps_r - eps) when eps_r != NULL]      (x_1 :363, u1 :371, x_2 :373, u2 :384, x_3 :387)
+ *   kd_dpm_error_f32:   the adaptive solver's local error (:464-465) as kd_dpm_error_partials() per-block partial sums of
+ *                       ((x_low - x_high) / max(atol, rtol * max(|x_low|, |x_prev|)))^2 on a fixed grid (reproducible total). */
+int kd_dpm_eps_f32(float* out, const float* x, const float* denoised, float sigma, long long n, void* stream);
+int kd_dpm_combine_f32(float* out, const float* x, const float* eps, const float* eps_r, float a, float b, long long n, void* stream);
+int kd_dpm_error_partials(void);
+int kd_dpm_error_f32(const float* x_low, const float* x_high, const float* x_prev, float atol, float rtol, long long n, float* partial,
+                     void* stream);
+
 /* Foreign-model wrappers (k_diffusion/external.py): the image-sized arithmetic of their forward()s,
  *   y[b, :] = f[b, :] * a[b] (+ x[b, :] * c[b] when x != NULL)          (:38, :113, :162)
  * and the discrete schedule's sigma <-> t maps over an ascending table log_sigmas[n] (:66-84). */

@@ -62,6 +62,10 @@ SIGNATURES = {
     "kd_rows_affine_f32": [_vp, _vp, _vp, _vp, _vp, _i, _ll, _vp],
     "kd_sigma_to_t_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "kd_t_to_sigma_f32": [_vp, _vp, _vp, _i, _i, _vp],
+    "kd_dpm_eps_f32": [_vp, _vp, _vp, _f, _ll, _vp],
+    "kd_dpm_combine_f32": [_vp, _vp, _vp, _vp, _f, _f, _ll, _vp],
+    "kd_dpm_error_partials": [],
+    "kd_dpm_error_f32": [_vp, _vp, _vp, _f, _f, _ll, _vp, _vp],
     "kd_brownian_f32": [_vp, _vp, _i, _ll, _d, _d, _d, _d, _f, _i, _vp],
     "kd_brownian_cached_f32": [_vp, _vp, _vp, _i, _i, _vp, _i, _ll, _d, _d, _d, _d, _f, _i, _vp],
     "kd_to_uint8": [_vp, _vp, _ll, _vp],

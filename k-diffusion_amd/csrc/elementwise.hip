@@ -100,6 +100,43 @@ __global__ __launch_bounds__(EW_BLOCK) void rows_affine_kernel(const float* __re
   }
 }
 
+// DPM-Solver tensors in the reference's own operation order (k_diffusion/sampling.py:350-388), so that results track the
+// reference to the last bits (the adaptive solver's accept / reject decisions hang on them):
+//   eps     = (x - denoised) / sigma                                   (:354)
+//   combine = x - a * eps [- b * (eps_r - eps)]                        (x_1, u1: b-term absent; x_2, u2, x_3: :372,:384,:387)
+// a, b are the reference's 0-dim fp32 products, evaluated on the host.
+__global__ __launch_bounds__(EW_BLOCK) void dpm_eps_kernel(float* out, const float* __restrict__ x, const float* __restrict__ den, float sigma, long n) {
+  for (long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * EW_BLOCK) out[i] = dvd(sub(x[i], den[i]), sigma);
+}
+__global__ __launch_bounds__(EW_BLOCK) void dpm_combine_kernel(float* out, const float* __restrict__ x, const float* __restrict__ eps,
+                                                               const float* __restrict__ eps_r, float a, float b, long n) {
+  for (long i = (long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * EW_BLOCK) {
+    const float e = eps[i];
+    float v = sub(x[i], mul(a, e));
+    if (eps_r) v = sub(v, mul(b, sub(eps_r[i], e)));
+    out[i] = v;
+  }
+}
+
+// Local error of the adaptive DPM-Solver (sampling.py:464-465): partial[b] = sum over block b's elements of
+// ((x_low - x_high) / max(atol, rtol * max(|x_low|, |x_prev|)))^2 on a FIXED grid, so that the host's sum of the partials
+// (and with it every accept / reject decision) is reproducible run to run
+constexpr int ERR_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void dpm_error_kernel(const float* __restrict__ lo, const float* __restrict__ hi, const float* __restrict__ prev,
+                                                        float atol, float rtol, long n, float* partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)ERR_BLOCKS * 256) {
+    const float l = lo[i];
+    const float d = dvd(sub(l, hi[i]), fmaxf(atol, mul(rtol, fmaxf(fabsf(l), fabsf(prev[i])))));
+    s = add(s, mul(d, d));
+  }
+  s = wave_sum_xor(s, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = add(add(red[0], red[1]), add(red[2], red[3]));
+}
+
 // DiscreteSchedule.sigma_to_t (external.py:66-78): position of log(sigma) in the ascending table log_sigmas[n], linearly
 // interpolated (clamped to the table) or, quantized, the index of the nearest entry
 __global__ __launch_bounds__(256) void sigma_to_t_kernel(const float* __restrict__ sigma, const float* __restrict__ log_sigmas, float* t, int count, int n, int quantize) {
@@ -234,6 +271,33 @@ extern "C" int kd_rows_affine_f32(const float* f, const float* x, const float* a
   LaunchScope prof("rows_affine_f32", 0, (x ? 12.0 : 8.0) * batch * per_sample, s);
   hipLaunchKernelGGL(rows_affine_kernel, dim3(ew_grid((long)batch * per_sample)), dim3(EW_BLOCK), 0, s, f, x, a, c, y, batch, (long)per_sample);
   return check_launch("kd_rows_affine_f32");
+}
+
+extern "C" int kd_dpm_eps_f32(float* out, const float* x, const float* denoised, float sigma, long long n, void* stream) {
+  if (!out || !x || !denoised || n <= 0 || !(sigma > 0.f)) return fail(KD_EINVAL, "kd_dpm_eps_f32: bad arguments (sigma must be > 0)");
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope prof("dpm_eps_f32", 0, 12.0 * n, s);
+  hipLaunchKernelGGL(dpm_eps_kernel, dim3(ew_grid((long)n)), dim3(EW_BLOCK), 0, s, out, x, denoised, sigma, (long)n);
+  return check_launch("kd_dpm_eps_f32");
+}
+
+extern "C" int kd_dpm_combine_f32(float* out, const float* x, const float* eps, const float* eps_r, float a, float b, long long n, void* stream) {
+  if (!out || !x || !eps || n <= 0) return fail(KD_EINVAL, "kd_dpm_combine_f32: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope prof("dpm_combine_f32", 0, 4.0 * n * (eps_r ? 4 : 3), s);
+  hipLaunchKernelGGL(dpm_combine_kernel, dim3(ew_grid((long)n)), dim3(EW_BLOCK), 0, s, out, x, eps, eps_r, a, b, (long)n);
+  return check_launch("kd_dpm_combine_f32");
+}
+
+extern "C" int kd_dpm_error_partials(void) { return ERR_BLOCKS; }
+
+extern "C" int kd_dpm_error_f32(const float* x_low, const float* x_high, const float* x_prev, float atol, float rtol, long long n, float* partial,
+                                void* stream) {
+  if (!x_low || !x_high || !x_prev || !partial || n <= 0 || !(atol >= 0.f) || !(rtol >= 0.f)) return fail(KD_EINVAL, "kd_dpm_error_f32: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope prof("dpm_error_f32", 0, 12.0 * n, s);
+  hipLaunchKernelGGL(dpm_error_kernel, dim3(ERR_BLOCKS), dim3(256), 0, s, x_low, x_high, x_prev, atol, rtol, (long)n, partial);
+  return check_launch("kd_dpm_error_f32");
 }
 
 extern "C" int kd_sigma_to_t_f32(const float* sigma, const float* log_sigmas, float* t, int count, int n, int quantize, void* stream) {

@@ -14,6 +14,8 @@ import ctypes as C
 import os
 import weakref
 
+import math
+
 import torch
 
 from . import _native as nat
@@ -313,6 +315,31 @@ def t_to_sigma(t, log_sigmas):
     nat.check(nat.lib().kd_t_to_sigma_f32(_p(_chk(t.contiguous(), "t")), _p(_chk(log_sigmas, "log_sigmas")), _p(out), t.numel(), log_sigmas.numel(),
                                       _stream()), "kd_t_to_sigma_f32")
     return out
+
+
+def dpm_eps(x, denoised, sigma, out=None):
+    """(x - denoised) / sigma -- DPMSolver.eps (sampling.py:354), the reference's rounding order."""
+    out = torch.empty_like(x) if out is None else out
+    nat.check(nat.lib().kd_dpm_eps_f32(_p(_chk(out, "out")), _p(_chk(x, "x")), _p(_chk(denoised, "denoised")), float(sigma), x.numel(), _stream()),
+              "kd_dpm_eps_f32")
+    return out
+
+
+def dpm_combine(x, eps, a, eps_r=None, b=0.0, out=None):
+    """x - a * eps [- b * (eps_r - eps)]: every DPM-Solver state (sampling.py:363-387), the reference's rounding order."""
+    out = torch.empty_like(x) if out is None else out
+    nat.check(nat.lib().kd_dpm_combine_f32(_p(_chk(out, "out")), _p(_chk(x, "x")), _p(_chk(eps, "eps")), None if eps_r is None else _p(_chk(eps_r, "eps_r")),
+                                           float(a), float(b), x.numel(), _stream()), "kd_dpm_combine_f32")
+    return out
+
+
+def dpm_error(x_low, x_high, x_prev, atol, rtol):
+    """Adaptive DPM-Solver local error (sampling.py:464-465) as a python float: sqrt(sum(((lo - hi) / delta)^2) / numel).
+    One launch writes fixed-grid partial sums; their total is taken on the host (the controller needs the value there)."""
+    part = torch.empty(nat.lib().kd_dpm_error_partials(), device=x_low.device, dtype=torch.float32)
+    nat.check(nat.lib().kd_dpm_error_f32(_p(_chk(x_low, "x_low")), _p(_chk(x_high, "x_high")), _p(_chk(x_prev, "x_prev")), float(atol), float(rtol),
+                                         x_low.numel(), _p(part), _stream()), "kd_dpm_error_f32")
+    return math.sqrt(float(part.double().sum().item()) / x_low.numel())
 
 
 def brownian(out, seeds, T0, T1, t0, t1, mult, depth=36):

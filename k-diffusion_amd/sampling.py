@@ -18,7 +18,7 @@ import math
 import os
 
 import torch
-from tqdm.auto import trange
+from tqdm.auto import tqdm, trange
 
 from . import _native as nat
 from . import ops, utils
@@ -371,6 +371,214 @@ def sample_lms(model, x, sigmas, extra_args=None, callback=None, disable=None, o
                 ops.sampler_step(nat.STEP_AXPY, acc, dj, out=acc, c0=c)
             lp.update(nat.STEP_AXPY, acc, c0=1.0)
     return lp.x
+
+
+# ---- DPM-Solver (fixed-step "fast" and adaptive), sampling.py:304-507 -----------------------------------------------
+
+class PIDStepSizeController:
+    """PID controller for the adaptive solver's step size (sampling.py:304-330): host scalars only."""
+
+    def __init__(self, h, pcoeff, icoeff, dcoeff, order=1, accept_safety=0.81, eps=1e-8):
+        self.h = h
+        self.b1 = (pcoeff + icoeff + dcoeff) / order
+        self.b2 = -(pcoeff + 2 * dcoeff) / order
+        self.b3 = dcoeff / order
+        self.accept_safety, self.eps = accept_safety, eps
+        self.errs = []
+
+    def limiter(self, x):
+        return 1 + math.atan(x - 1)
+
+    def propose_step(self, error):
+        inv_error = 1 / (float(error) + self.eps)
+        if not self.errs:
+            self.errs = [inv_error] * 3
+        self.errs[0] = inv_error
+        factor = self.limiter(self.errs[0] ** self.b1 * self.errs[1] ** self.b2 * self.errs[2] ** self.b3)
+        accept = factor >= self.accept_safety
+        if accept:
+            self.errs[2], self.errs[1] = self.errs[1], self.errs[0]
+        self.h *= factor
+        return accept
+
+
+class DPMSolver:
+    """DPM-Solver-1/2/3 (https://arxiv.org/abs/2206.00927) behind the reference's class surface (sampling.py:333-480).
+
+    Same formulation as the reference (eps = (x - D) / sigma, states x - a eps - b (eps_r - eps)) and the same rounding
+    order, but each tensor expression is ONE fused HIP launch (``kd_dpm_eps_f32`` / ``kd_dpm_combine_f32``) fed with the
+    reference's own 0-dim fp32 scalar products computed on the host; the adaptive solver's error norm is one more launch
+    (``kd_dpm_error_f32``) and the step's only device -> host value.  Given the same denoised tensors the states are
+    bit-identical to the reference's, which matters for the adaptive solver: its accept / reject decisions amplify
+    rounding differences."""
+
+    def __init__(self, model, extra_args=None, eps_callback=None, info_callback=None):
+        self.model = model
+        self.extra_args = {} if extra_args is None else extra_args
+        self.eps_callback, self.info_callback = eps_callback, info_callback
+
+    def t(self, sigma):
+        return -torch.as_tensor(sigma, dtype=torch.float32).log()
+
+    def sigma(self, t):
+        return torch.as_tensor(t, dtype=torch.float32).neg().exp()
+
+    def eps(self, eps_cache, key, x, t, *args, **kwargs):
+        """eps(x, t) memoised per step under ``key`` (:350-357).  Returns (eps, cache)."""
+        if key in eps_cache:
+            return eps_cache[key], eps_cache
+        if not x.is_cuda:
+            raise RuntimeError('the samplers run on the HIP path only: x must live on a ROCm device (no CPU fallback)')
+        x = x.contiguous()
+        sig = torch.full((x.shape[0],), _f(self.sigma(t)), device=x.device, dtype=torch.float32)
+        den = self.model(x, sig, *args, **self.extra_args, **kwargs).contiguous()
+        eps = ops.dpm_eps(x, den, _f(self.sigma(t)))
+        if self.eps_callback is not None:
+            self.eps_callback()
+        return eps, {key: eps, **eps_cache}
+
+    def dpm_solver_1_step(self, x, t, t_next, eps_cache=None):
+        eps_cache = {} if eps_cache is None else eps_cache
+        h = t_next - t
+        eps, eps_cache = self.eps(eps_cache, 'eps', x, t)
+        return ops.dpm_combine(x.contiguous(), eps, _f(self.sigma(t_next) * h.expm1())), eps_cache
+
+    def dpm_solver_2_step(self, x, t, t_next, r1=1 / 2, eps_cache=None):
+        eps_cache = {} if eps_cache is None else eps_cache
+        x = x.contiguous()
+        h = t_next - t
+        eps, eps_cache = self.eps(eps_cache, 'eps', x, t)
+        s1 = t + r1 * h
+        u1 = ops.dpm_combine(x, eps, _f(self.sigma(s1) * (r1 * h).expm1()))
+        eps_r1, eps_cache = self.eps(eps_cache, 'eps_r1', u1, s1)
+        x_2 = ops.dpm_combine(x, eps, _f(self.sigma(t_next) * h.expm1()), eps_r1, _f(self.sigma(t_next) / (2 * r1) * h.expm1()))
+        return x_2, eps_cache
+
+    def dpm_solver_3_step(self, x, t, t_next, r1=1 / 3, r2=2 / 3, eps_cache=None):
+        eps_cache = {} if eps_cache is None else eps_cache
+        x = x.contiguous()
+        h = t_next - t
+        eps, eps_cache = self.eps(eps_cache, 'eps', x, t)
+        s1, s2 = t + r1 * h, t + r2 * h
+        u1 = ops.dpm_combine(x, eps, _f(self.sigma(s1) * (r1 * h).expm1()))
+        eps_r1, eps_cache = self.eps(eps_cache, 'eps_r1', u1, s1)
+        u2 = ops.dpm_combine(x, eps, _f(self.sigma(s2) * (r2 * h).expm1()), eps_r1,
+                             _f(self.sigma(s2) * (r2 / r1) * ((r2 * h).expm1() / (r2 * h) - 1)))
+        eps_r2, eps_cache = self.eps(eps_cache, 'eps_r2', u2, s2)
+        x_3 = ops.dpm_combine(x, eps, _f(self.sigma(t_next) * h.expm1()), eps_r2, _f(self.sigma(t_next) / r2 * (h.expm1() / h - 1)))
+        return x_3, eps_cache
+
+    # -- drivers -----------------------------------------------------------------------------------------------------------
+    def _ancestral(self, t, t_next, t_end, eta):
+        """Deterministic target time and the noise scale added back (:411-416, :448-453)."""
+        if not eta:
+            return t_next, 0.
+        sd, su = get_ancestral_step(self.sigma(t), self.sigma(t_next), eta)
+        t_next_ = torch.minimum(t_end, self.t(sd))
+        return t_next_, (self.sigma(t_next) ** 2 - self.sigma(t_next_) ** 2) ** 0.5
+
+    def _noised(self, x, su, s_noise, noise):
+        out = torch.empty_like(x)
+        ops.sampler_step(nat.STEP_ADD_NOISE, x, noise.contiguous(), out=out, c0=_f(su), c1=_f(s_noise), c2=1.0)
+        return out
+
+    @torch.no_grad()
+    def dpm_solver_fast(self, x, t_start, t_end, nfe, eta=0., s_noise=1., noise_sampler=None):
+        noise_sampler = default_noise_sampler(x) if noise_sampler is None else noise_sampler
+        t_start, t_end = torch.as_tensor(t_start, dtype=torch.float32), torch.as_tensor(t_end, dtype=torch.float32)
+        if not t_end > t_start and eta:
+            raise ValueError('eta must be 0 for reverse sampling')
+        m = math.floor(nfe / 3) + 1
+        ts = torch.linspace(t_start, t_end, m + 1)
+        orders = [3] * (m - 2) + [2, 1] if nfe % 3 == 0 else [3] * (m - 1) + [nfe % 3]
+        x = x.contiguous()
+        for i, order in enumerate(orders):
+            t, t_next = ts[i], ts[i + 1]
+            t_next_, su = self._ancestral(t, t_next, t_end, eta)
+            eps, eps_cache = self.eps({}, 'eps', x, t)
+            if self.info_callback is not None:
+                self.info_callback({'x': x, 'i': i, 't': ts[i], 't_up': t, 'denoised': ops.dpm_combine(x, eps, _f(self.sigma(t)))})
+            if order == 1:
+                x, eps_cache = self.dpm_solver_1_step(x, t, t_next_, eps_cache=eps_cache)
+            elif order == 2:
+                x, eps_cache = self.dpm_solver_2_step(x, t, t_next_, eps_cache=eps_cache)
+            else:
+                x, eps_cache = self.dpm_solver_3_step(x, t, t_next_, eps_cache=eps_cache)
+            if eta:
+                x = self._noised(x, su, s_noise, noise_sampler(self.sigma(t), self.sigma(t_next)))
+        return x
+
+    @torch.no_grad()
+    def dpm_solver_adaptive(self, x, t_start, t_end, order=3, rtol=0.05, atol=0.0078, h_init=0.05, pcoeff=0., icoeff=1., dcoeff=0.,
+                            accept_safety=0.81, eta=0., s_noise=1., noise_sampler=None):
+        noise_sampler = default_noise_sampler(x) if noise_sampler is None else noise_sampler
+        if order not in {2, 3}:
+            raise ValueError('order should be 2 or 3')
+        t_start, t_end = torch.as_tensor(t_start, dtype=torch.float32), torch.as_tensor(t_end, dtype=torch.float32)
+        forward = bool(t_end > t_start)
+        if not forward and eta:
+            raise ValueError('eta must be 0 for reverse sampling')
+        h_init = abs(h_init) * (1 if forward else -1)
+        s, x = t_start, x.contiguous()
+        x_prev = x
+        pid = PIDStepSizeController(h_init, pcoeff, icoeff, dcoeff, 1.5 if eta else order, accept_safety)
+        info = {'steps': 0, 'nfe': 0, 'n_accept': 0, 'n_reject': 0}
+        while (s < t_end - 1e-5) if forward else (s > t_end + 1e-5):
+            t = torch.minimum(t_end, s + pid.h) if forward else torch.maximum(t_end, s + pid.h)
+            t_, su = self._ancestral(s, t, t_end, eta)
+            eps, eps_cache = self.eps({}, 'eps', x, s)
+            denoised = ops.dpm_combine(x, eps, _f(self.sigma(s))) if self.info_callback is not None else None
+            if order == 2:
+                x_low, eps_cache = self.dpm_solver_1_step(x, s, t_, eps_cache=eps_cache)
+                x_high, eps_cache = self.dpm_solver_2_step(x, s, t_, eps_cache=eps_cache)
+            else:
+                x_low, eps_cache = self.dpm_solver_2_step(x, s, t_, r1=1 / 3, eps_cache=eps_cache)
+                x_high, eps_cache = self.dpm_solver_3_step(x, s, t_, eps_cache=eps_cache)
+            error = ops.dpm_error(x_low, x_high, x_prev, atol, rtol)        # the step's one device -> host value
+            accept = pid.propose_step(error)
+            if accept:
+                x_prev = x_low
+                x = self._noised(x_high, su, s_noise, noise_sampler(self.sigma(s), self.sigma(t))) if eta else x_high
+                s = t
+                info['n_accept'] += 1
+            else:
+                info['n_reject'] += 1
+            info['nfe'] += order
+            info['steps'] += 1
+            if self.info_callback is not None:
+                self.info_callback({'x': x, 'i': info['steps'] - 1, 't': s, 't_up': s, 'denoised': denoised, 'error': error, 'h': pid.h, **info})
+        return x, info
+
+
+def _dpm_solver_for(model, extra_args, callback, pbar):
+    solver = DPMSolver(model, extra_args, eps_callback=pbar.update)
+    if callback is not None:
+        solver.info_callback = lambda info: callback({'sigma': solver.sigma(info['t']), 'sigma_hat': solver.sigma(info['t_up']), **info})
+    return solver
+
+
+@torch.no_grad()
+def sample_dpm_fast(model, x, sigma_min, sigma_max, n, extra_args=None, callback=None, disable=None, eta=0., s_noise=1., noise_sampler=None):
+    """DPM-Solver-Fast (fixed step size)."""
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError('sigma_min and sigma_max must not be 0')
+    with tqdm(total=n, disable=disable) as pbar:
+        solver = _dpm_solver_for(model, extra_args, callback, pbar)
+        return solver.dpm_solver_fast(x, solver.t(torch.tensor(sigma_max)), solver.t(torch.tensor(sigma_min)), n, eta, s_noise, noise_sampler)
+
+
+@torch.no_grad()
+def sample_dpm_adaptive(model, x, sigma_min, sigma_max, extra_args=None, callback=None, disable=None, order=3, rtol=0.05, atol=0.0078,
+                        h_init=0.05, pcoeff=0., icoeff=1., dcoeff=0., accept_safety=0.81, eta=0., s_noise=1., noise_sampler=None,
+                        return_info=False):
+    """DPM-Solver-12 and 23 (adaptive step size)."""
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError('sigma_min and sigma_max must not be 0')
+    with tqdm(disable=disable) as pbar:
+        solver = _dpm_solver_for(model, extra_args, callback, pbar)
+        x, info = solver.dpm_solver_adaptive(x, solver.t(torch.tensor(sigma_max)), solver.t(torch.tensor(sigma_min)), order, rtol, atol,
+                                             h_init, pcoeff, icoeff, dcoeff, accept_safety, eta, s_noise, noise_sampler)
+    return (x, info) if return_info else x
 
 
 @torch.no_grad()

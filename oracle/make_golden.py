@@ -82,6 +82,18 @@ def scalar_kats():
     kat["solver_toy_3m_sde_recorded"] = hexf(S.sample_dpmpp_3m_sde(toy, xt, sig20, disable=True, noise_sampler=lambda a, b: next(it)))
     it = iter(noise)
     kat["solver_toy_2m_sde_recorded"] = hexf(S.sample_dpmpp_2m_sde(toy, xt, sig20, disable=True, noise_sampler=lambda a, b: next(it)))
+    # DPM-Solver family (sampling.py:304-507): fixed-step "fast" at the three order patterns, with ancestral noise, and the
+    # adaptive solver at both orders (its accept / reject bookkeeping recorded beside the result)
+    kat["solver_toy_dpm_fast"] = {str(n): hexf(S.sample_dpm_fast(toy, xt, 1e-2, 80., n, disable=True)) for n in (12, 13, 14, 4)}
+    it = iter(noise)
+    kat["solver_toy_dpm_fast_eta_recorded"] = hexf(S.sample_dpm_fast(toy, xt, 1e-2, 80., 12, disable=True, eta=0.7, noise_sampler=lambda a, b: next(it)))
+    kat["solver_toy_dpm_adaptive"] = {}
+    for order in (3, 2):
+        xa, info = S.sample_dpm_adaptive(toy, xt, 1e-2, 80., disable=True, order=order, return_info=True)
+        kat["solver_toy_dpm_adaptive"][str(order)] = {"x": hexf(xa), "info": info}
+    it = iter(noise * 4)
+    xa, info = S.sample_dpm_adaptive(toy, xt, 1e-2, 80., disable=True, eta=0.5, noise_sampler=lambda a, b: next(it), return_info=True)
+    kat["solver_toy_dpm_adaptive_eta_recorded"] = {"x": hexf(xa), "info": info}
     # foreign-model wrappers (external.py) on a linear-beta DDPM schedule with analytic inner models
     E = K.external
     acp = torch.cumprod(1 - torch.linspace(1e-4, 2e-2, 1000), dim=0)

@@ -204,3 +204,155 @@ def sample_lms(model, x, sigmas, extra_args=None, callback=None, order=4):
         cs = [lms_coeff(cur, t, i, j) for j in range(cur)]
         x = x + sum(c * d for c, d in zip(cs, reversed(hist)))
     return x
+
+
+# ---- DPM-Solver (fixed-step "fast" and adaptive), sampling.py:304-507 -------------------------------
+# Restated in the reference's eps formulation and operation order (t = -log sigma as 0-dim fp32 tensors).
+# `noise_sampler(sigma, sigma_next)` is required whenever eta > 0 (the tests inject recorded noise).
+
+def _dpm_sigma(t):
+    return t.neg().exp()
+
+
+def _dpm_eps(model, x, t, extra, cache, key, count):
+    """:350-357: eps = (x - D(x, sigma(t))) / sigma(t), memoised per step under `key`."""
+    if key not in cache:
+        sigma = _dpm_sigma(t) * x.new_ones([x.shape[0]])
+        cache[key] = (x - model(x, sigma, **extra)) / _dpm_sigma(t)
+        count[0] += 1
+    return cache[key]
+
+
+def _dpm_step1(model, x, t, t_next, extra, cache, count):
+    """:359-364."""
+    h = t_next - t
+    eps = _dpm_eps(model, x, t, extra, cache, "eps", count)
+    return x - _dpm_sigma(t_next) * h.expm1() * eps
+
+
+def _dpm_step2(model, x, t, t_next, extra, cache, count, r1=1 / 2):
+    """:366-374."""
+    h = t_next - t
+    eps = _dpm_eps(model, x, t, extra, cache, "eps", count)
+    s1 = t + r1 * h
+    u1 = x - _dpm_sigma(s1) * (r1 * h).expm1() * eps
+    eps_r1 = _dpm_eps(model, u1, s1, extra, cache, "eps_r1", count)
+    return x - _dpm_sigma(t_next) * h.expm1() * eps - _dpm_sigma(t_next) / (2 * r1) * h.expm1() * (eps_r1 - eps)
+
+
+def _dpm_step3(model, x, t, t_next, extra, cache, count, r1=1 / 3, r2=2 / 3):
+    """:376-388."""
+    h = t_next - t
+    eps = _dpm_eps(model, x, t, extra, cache, "eps", count)
+    s1, s2 = t + r1 * h, t + r2 * h
+    u1 = x - _dpm_sigma(s1) * (r1 * h).expm1() * eps
+    eps_r1 = _dpm_eps(model, u1, s1, extra, cache, "eps_r1", count)
+    u2 = x - _dpm_sigma(s2) * (r2 * h).expm1() * eps - _dpm_sigma(s2) * (r2 / r1) * ((r2 * h).expm1() / (r2 * h) - 1) * (eps_r1 - eps)
+    eps_r2 = _dpm_eps(model, u2, s2, extra, cache, "eps_r2", count)
+    return x - _dpm_sigma(t_next) * h.expm1() * eps - _dpm_sigma(t_next) / r2 * (h.expm1() / h - 1) * (eps_r2 - eps)
+
+
+def _dpm_ancestral(t, t_next, t_end, eta):
+    """:411-416 / :448-453: the deterministic part stops at t(sigma_down); su is the noise added back."""
+    if not eta:
+        return t_next, 0.0
+    sd, su = ancestral_step(_dpm_sigma(t), _dpm_sigma(t_next), eta)
+    t_next_ = torch.minimum(t_end, -sd.log())
+    su = (_dpm_sigma(t_next) ** 2 - _dpm_sigma(t_next_) ** 2) ** 0.5
+    return t_next_, su
+
+
+def sample_dpm_fast(model, x, sigma_min, sigma_max, n, extra_args=None, callback=None, eta=0.0, s_noise=1.0, noise_sampler=None):
+    """:390-430, :482-491."""
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError("sigma_min and sigma_max must not be 0")
+    extra = {} if extra_args is None else extra_args
+    t_start, t_end = -torch.tensor(sigma_max).log(), -torch.tensor(sigma_min).log()
+    if not t_end > t_start and eta:
+        raise ValueError("eta must be 0 for reverse sampling")
+    m = math.floor(n / 3) + 1
+    ts = torch.linspace(t_start, t_end, m + 1)
+    orders = [3] * (m - 2) + [2, 1] if n % 3 == 0 else [3] * (m - 1) + [n % 3]
+    count = [0]
+    for i, order in enumerate(orders):
+        cache = {}
+        t, t_next = ts[i], ts[i + 1]
+        t_next_, su = _dpm_ancestral(t, t_next, t_end, eta)
+        eps = _dpm_eps(model, x, t, extra, cache, "eps", count)
+        if callback is not None:
+            callback({"x": x, "i": i, "t": ts[i], "t_up": t, "denoised": x - _dpm_sigma(t) * eps, "sigma": _dpm_sigma(t), "sigma_hat": _dpm_sigma(t)})
+        step = (_dpm_step1, _dpm_step2, _dpm_step3)[order - 1]
+        x = step(model, x, t, t_next_, extra, cache, count)
+        if eta:
+            x = x + su * s_noise * noise_sampler(_dpm_sigma(t), _dpm_sigma(t_next))
+    return x
+
+
+class PIDStepSizeController:
+    """:304-330."""
+
+    def __init__(self, h, pcoeff, icoeff, dcoeff, order=1, accept_safety=0.81, eps=1e-8):
+        self.h = h
+        self.b1, self.b2, self.b3 = (pcoeff + icoeff + dcoeff) / order, -(pcoeff + 2 * dcoeff) / order, dcoeff / order
+        self.accept_safety, self.eps, self.errs = accept_safety, eps, []
+
+    def propose_step(self, error):
+        inv_error = 1 / (float(error) + self.eps)
+        if not self.errs:
+            self.errs = [inv_error, inv_error, inv_error]
+        self.errs[0] = inv_error
+        factor = self.errs[0] ** self.b1 * self.errs[1] ** self.b2 * self.errs[2] ** self.b3
+        factor = 1 + math.atan(factor - 1)
+        accept = factor >= self.accept_safety
+        if accept:
+            self.errs[2], self.errs[1] = self.errs[1], self.errs[0]
+        self.h *= factor
+        return accept
+
+
+def sample_dpm_adaptive(model, x, sigma_min, sigma_max, extra_args=None, callback=None, order=3, rtol=0.05, atol=0.0078, h_init=0.05,
+                        pcoeff=0.0, icoeff=1.0, dcoeff=0.0, accept_safety=0.81, eta=0.0, s_noise=1.0, noise_sampler=None, return_info=False):
+    """:432-480, :494-507."""
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError("sigma_min and sigma_max must not be 0")
+    if order not in {2, 3}:
+        raise ValueError("order should be 2 or 3")
+    extra = {} if extra_args is None else extra_args
+    t_start, t_end = -torch.tensor(sigma_max).log(), -torch.tensor(sigma_min).log()
+    forward = bool(t_end > t_start)
+    if not forward and eta:
+        raise ValueError("eta must be 0 for reverse sampling")
+    h_init = abs(h_init) * (1 if forward else -1)
+    atol_t, rtol_t = torch.tensor(atol), torch.tensor(rtol)
+    s, x_prev = t_start, x
+    pid = PIDStepSizeController(h_init, pcoeff, icoeff, dcoeff, 1.5 if eta else order, accept_safety)
+    info = {"steps": 0, "nfe": 0, "n_accept": 0, "n_reject": 0}
+    count = [0]
+    while (s < t_end - 1e-5) if forward else (s > t_end + 1e-5):
+        cache = {}
+        t = torch.minimum(t_end, s + pid.h) if forward else torch.maximum(t_end, s + pid.h)
+        t_, su = _dpm_ancestral(s, t, t_end, eta)
+        eps = _dpm_eps(model, x, s, extra, cache, "eps", count)
+        denoised = x - _dpm_sigma(s) * eps
+        if order == 2:
+            x_low = _dpm_step1(model, x, s, t_, extra, cache, count)
+            x_high = _dpm_step2(model, x, s, t_, extra, cache, count)
+        else:
+            x_low = _dpm_step2(model, x, s, t_, extra, cache, count, r1=1 / 3)
+            x_high = _dpm_step3(model, x, s, t_, extra, cache, count)
+        delta = torch.maximum(atol_t, rtol_t * torch.maximum(x_low.abs(), x_prev.abs()))
+        error = torch.linalg.norm((x_low - x_high) / delta) / x.numel() ** 0.5
+        accept = pid.propose_step(error)
+        if accept:
+            x_prev = x_low
+            x = x_high + su * s_noise * noise_sampler(_dpm_sigma(s), _dpm_sigma(t)) if eta else x_high
+            s = t
+            info["n_accept"] += 1
+        else:
+            info["n_reject"] += 1
+        info["nfe"] += order
+        info["steps"] += 1
+        if callback is not None:
+            callback({"x": x, "i": info["steps"] - 1, "t": s, "t_up": s, "denoised": denoised, "error": error, "h": pid.h,
+                      "sigma": _dpm_sigma(s), "sigma_hat": _dpm_sigma(s), **info})
+    return (x, info) if return_info else x

@@ -116,7 +116,12 @@ def main(argv=None):
             cc = class_ids(args, num_classes, lo, n, device)
             if cc is not None:
                 extra['class_cond'] = cc
-            return sampler(model, x, sigmas, extra_args=extra, disable=not accelerator.is_local_main_process)
+            quiet = not accelerator.is_local_main_process
+            if sampler is K.sampling.sample_dpm_fast:           # these two take the sigma range, not a schedule
+                return sampler(model, x, sigma_min, sigma_max, args.steps, extra_args=extra, disable=quiet)
+            if sampler is K.sampling.sample_dpm_adaptive:
+                return sampler(model, x, sigma_min, sigma_max, extra_args=extra, disable=quiet)
+            return sampler(model, x, sigmas, extra_args=extra, disable=quiet)
 
         t0 = time.perf_counter()
         x_0 = K.evaluation.compute_features(accelerator, sample_fn, lambda x: x, args.n, args.batch_size)

@@ -357,6 +357,26 @@ def test_sampler_steps_bit_exact(ops):
     assert torch.equal(bits(Xc), bits(cases[N.STEP_DPMPP_2M1]))
 
 
+def test_dpm_solver_kernels(ops):
+    n = 2 * 3 * 17 * 5 + 3
+    x, d, e2 = (rn(n, seed=s, scale=sc) for s, sc in ((1, 30.0), (2, 1.0), (3, 5.0)))
+    k = [torch.tensor(v, dtype=torch.float32) for v in (0.731, 1.37, 1.618)]
+    f = [float(v) for v in k]
+    eps = (x - d) / k[0]
+    assert torch.equal(bits(ops.dpm_eps(g(x), g(d), f[0])), bits(eps))
+    assert torch.equal(bits(ops.dpm_combine(g(x), g(eps), f[1])), bits(x - k[1] * eps))
+    assert torch.equal(bits(ops.dpm_combine(g(x), g(eps), f[1], g(e2), f[2])), bits(x - k[1] * eps - k[2] * (e2 - eps)))
+    with pytest.raises(RuntimeError, match="sigma"):
+        ops.dpm_eps(g(x), g(d), 0.0)
+    # adaptive-solver error norm (sampling.py:464-465), reproducible to the bit run to run
+    lo, hi, prev = rn(3, 5, 7, 11, seed=5, scale=4.0), rn(3, 5, 7, 11, seed=6, scale=4.0), rn(3, 5, 7, 11, seed=7, scale=9.0)
+    delta = torch.maximum(torch.tensor(0.0078), torch.tensor(0.05) * torch.maximum(lo.abs(), prev.abs()))
+    ref = (torch.linalg.norm(((lo - hi) / delta).double()) / lo.numel() ** 0.5).item()
+    got = ops.dpm_error(g(lo), g(hi), g(prev), 0.0078, 0.05)
+    assert abs(got - ref) < 1e-6 * ref
+    assert got == ops.dpm_error(g(lo), g(hi), g(prev), 0.0078, 0.05)
+
+
 def test_preconditioner_generic(ops):
     x, fx = rn(3, 3, 8, 8, seed=1, scale=20.0), rn(3, 3, 8, 8, seed=2)
     sigma = torch.tensor([0.01, 2.0, 160.0])

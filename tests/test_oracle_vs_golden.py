@@ -98,6 +98,34 @@ def test_solver_known_answers_bit_exact(golden):
     assert torch.equal(bits(got.reshape(-1)), bits(unhex(kat["solver_toy_sde_recorded"])))
 
 
+def test_dpm_solver_family_bit_exact(golden):
+    """sample_dpm_fast (order patterns 3..3,2,1 / 3..3,1 / 3..3,2 / single step, and ancestral noise) and
+    sample_dpm_adaptive (orders 3 and 2, ancestral) -- the oracle against runs recorded from the real reference,
+    including the adaptive solver's accept / reject bookkeeping."""
+    kat = golden["kat"]
+    toy = lambda x, sigma, **kw: torch.tanh(x) / (1 + sigma.view(-1, 1, 1, 1))
+    xt = torch.randn(2, 3, 4, 4, generator=torch.Generator().manual_seed(3)) * 80
+    noise = cases.recorded_noise(tuple(xt.shape), 64, seed=77)
+    for n, hx in kat["solver_toy_dpm_fast"].items():
+        got = solvers.sample_dpm_fast(toy, xt, 1e-2, 80., int(n))
+        assert torch.equal(bits(got.reshape(-1)), bits(unhex(hx))), n
+    it = iter(noise)
+    got = solvers.sample_dpm_fast(toy, xt, 1e-2, 80., 12, eta=0.7, noise_sampler=lambda a, b: next(it))
+    assert torch.equal(bits(got.reshape(-1)), bits(unhex(kat["solver_toy_dpm_fast_eta_recorded"])))
+    for order, rec in kat["solver_toy_dpm_adaptive"].items():
+        got, info = solvers.sample_dpm_adaptive(toy, xt, 1e-2, 80., order=int(order), return_info=True)
+        assert info == rec["info"], order
+        assert torch.equal(bits(got.reshape(-1)), bits(unhex(rec["x"]))), order
+    it = iter(noise * 4)
+    got, info = solvers.sample_dpm_adaptive(toy, xt, 1e-2, 80., eta=0.5, noise_sampler=lambda a, b: next(it), return_info=True)
+    rec = kat["solver_toy_dpm_adaptive_eta_recorded"]
+    assert info == rec["info"] and torch.equal(bits(got.reshape(-1)), bits(unhex(rec["x"])))
+    with pytest.raises(ValueError, match="order"):
+        solvers.sample_dpm_adaptive(toy, xt, 1e-2, 80., order=4)
+    with pytest.raises(ValueError, match="must not be 0"):
+        solvers.sample_dpm_fast(toy, xt, 0.0, 80., 6)
+
+
 def test_ops_vs_reference(golden):
     o = golden["ops"]
     x = o["rms_norm.x"]
