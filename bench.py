@@ -238,8 +238,7 @@ def main():
             with open(args.kernel_table, "w") as f:
                 json.dump({"families": fam, "kernels": groups, "timed_seconds": dt}, f, indent=1)
         n_img = args.gpus * B * args.steps
-        from oracle import hdit
-        mac = hdit.forward_cost_mac(mc)["total"]
+        mac = K.models.flops.forward_cost_mac(mc)["total"]
         nfe = args.sampler_steps if args.sampler == "sample_dpmpp_2m" else None
         result = {
             "metric": "images/sec, 256x256 image_transformer_v2, 50-step DPM++2M (whole job)",

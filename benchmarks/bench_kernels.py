@@ -32,6 +32,13 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters * 1e3        # us
 
 
+def _rope(h, nh):
+    """cos / sin tables [h*h, nh, 16] of the axial RoPE, on the device (the package's own table builder)."""
+    rope = K.models.axial_rope
+    cos_t, sin_t = rope.rope_tables(rope.make_axial_pos(h, h).view(h, h, 2), rope.rope_freqs(32, nh))
+    return cos_t.to(DEV), sin_t.to(DEV)
+
+
 def gemm_cases(B):
     T = [B * 4096, B * 1024, B * 256]
     d = [128, 256, 512]
@@ -54,11 +61,10 @@ def run_gemm(args, res):
             fn = lambda: ops.norm_linear(x, scale, w, rows_per_sample=M // B, epi=nat.EPI_GEGLU, out=out)
             n_eff = 2 * N
         elif kind == "qkv":
-            from oracle import hdit
             nh, T = Kd // 64, M // B
             h = int(T ** 0.5)
-            theta = hdit.rope_theta(hdit.axial_pos(h, h), hdit.rope_freqs(nh)).reshape(T, nh, 16)
-            qk = (10.0 * torch.ones(nh, device=DEV), torch.cos(theta).to(DEV).contiguous(), torch.sin(theta).to(DEV).contiguous(), nh)
+            cos_t, sin_t = _rope(h, nh)
+            qk = (10.0 * torch.ones(nh, device=DEV), cos_t, sin_t, nh)
             w = torch.randn(N, Kd, device=DEV) / Kd ** 0.5
             scale = 1 + 0.1 * torch.randn(B, Kd, device=DEV)
             out = torch.empty(M, N, device=DEV)
@@ -85,11 +91,9 @@ def run_gemm(args, res):
 
 def run_attn(args, res, what):
     B = args.batch
-    from oracle import hdit
     for lv, (h, nh) in enumerate([(64, 2), (32, 4), (16, 8)]):
         qkv = torch.randn(B, h, h, 3 * nh * 64, device=DEV)
-        theta = hdit.rope_theta(hdit.axial_pos(h, h), hdit.rope_freqs(nh)).reshape(h * h, nh, 16)
-        prep = (10.0 * torch.ones(nh, device=DEV), torch.cos(theta).to(DEV).contiguous(), torch.sin(theta).to(DEV).contiguous())
+        prep = (10.0 * torch.ones(nh, device=DEV), *_rope(h, nh))
         out = torch.empty(B, h, h, nh * 64, device=DEV)
         byts = 4.0 * B * h * h * nh * 64 * 4
         if what == "na" and lv < 2:
