@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(float* qkv, const float* s
 }
 
 // ---- dense cores ------------------------------------------------------------------------------------
-enum { MODE_GLOBAL = 0, MODE_WINDOW = 1 };
+// window modes carry log2(window_size) in the template value: 8x8 (the shipped config), 4x4, 16x16 windows
+enum { MODE_GLOBAL = 0, MODE_WINDOW = 1, MODE_WINDOW4 = 2, MODE_WINDOW16 = 3 };
+template <int MODE> struct WinLog2 { static constexpr int v = MODE == MODE_WINDOW ? 3 : (MODE == MODE_WINDOW4 ? 2 : 4); };
 
 struct DenseArgs {
   const float* qkv; float* out;
@@ -66,14 +68,17 @@ struct DenseArgs {
 template <int MODE>
 __device__ __forceinline__ int slot_token(const DenseArgs& a, int slot, int wi, int wj) {
   if (MODE == MODE_GLOBAL) return slot < a.T ? slot : -1;
-  const int ai = slot >> 3, bj = slot & 7;                 // ws == 8
-  int i = wi * 8 + ai - a.shift; if (i < 0) i += a.H;      // rolled[i] = orig[(i - shift) mod H]  (:274)
-  int j = wj * 8 + bj - a.shift; if (j < 0) j += a.W;
+  constexpr int L = WinLog2<MODE>::v, WS = 1 << L;
+  const int ai = slot >> L, bj = slot & (WS - 1);
+  int i = wi * WS + ai - a.shift; if (i < 0) i += a.H;     // rolled[i] = orig[(i - shift) mod H]  (:274)
+  int j = wj * WS + bj - a.shift; if (j < 0) j += a.W;
   return i * a.W + j;
 }
 // wrapped-region id of a window slot (make_shifted_window_masks, :285-316)
+template <int MODE>
 __device__ __forceinline__ int slot_region(int slot, int wi, int wj, int shift) {
-  return ((wi == 0 && (slot >> 3) < shift) ? 2 : 0) + ((wj == 0 && (slot & 7) < shift) ? 1 : 0);
+  constexpr int L = WinLog2<MODE>::v, WS = 1 << L;
+  return ((wi == 0 && (slot >> L) < shift) ? 2 : 0) + ((wj == 0 && (slot & (WS - 1)) < shift) ? 1 : 0);
 }
 
 template <int MODE, int MAXT, bool PREP>
@@ -88,11 +93,11 @@ __global__ __launch_bounds__(MAXT * 64) void attn_dense_kernel(const DenseArgs a
   if (MODE == MODE_GLOBAL) {
     head = blockIdx.x % a.nh; b = blockIdx.x / a.nh;
   } else {
-    const int nww = a.W >> 3, nwh = a.H >> 3;
+    const int nww = a.W >> WinLog2<MODE>::v, nwh = a.H >> WinLog2<MODE>::v;
     int r = blockIdx.x;
     wj = r % nww; r /= nww; wi = r % nwh; r /= nwh; head = r % a.nh; b = r / a.nh;
   }
-  const int n_slots = (MODE == MODE_GLOBAL) ? a.T : 64;
+  const int n_slots = (MODE == MODE_GLOBAL) ? a.T : (1 << (2 * WinLog2<MODE>::v));
   const int ntiles = (n_slots + 31) >> 5;
   const long row_stride = 3L * a.nh * DH;                       // floats between consecutive tokens
   const float* base = a.qkv + (long)b * a.T * row_stride + head * DH;
@@ -179,11 +184,11 @@ __global__ __launch_bounds__(MAXT * 64) void attn_dense_kernel(const DenseArgs a
   // The mask enters as an additive bias (0 / -inf) that is recomputed in both passes instead of a
   // select written back into S: hipcc (ROCm 7.2) miscompiles `S[t][r] = ok ? S[t][r] : -inf` on an
   // MFMA accumulator (it overwrites element 0's AGPR with -inf before the conditional copy).
-  const int q_region = (MODE == MODE_WINDOW) ? slot_region(q_slot, wi, wj, a.shift) : 0;
+  const int q_region = (MODE != MODE_GLOBAL) ? slot_region<MODE>(q_slot, wi, wj, a.shift) : 0;
   auto key_bias = [&](int t, int r) -> float {
     const int ks = t * 32 + mfma32_row(r, lane);
     bool ok = ks < n_slots;
-    if (MODE == MODE_WINDOW && a.shift) ok = ok && (slot_region(ks, wi, wj, a.shift) == q_region);
+    if (MODE != MODE_GLOBAL && a.shift) ok = ok && (slot_region<MODE>(ks, wi, wj, a.shift) == q_region);
     return ok ? 0.f : -INFINITY;
   };
   float m = -INFINITY;
@@ -656,12 +661,12 @@ __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseA
   int b, head, wi = 0, wj = 0;
   if (MODE == MODE_GLOBAL) {
     head = blockIdx.x % a.nh; b = blockIdx.x / a.nh;
-  } else {                                               // one workgroup per (sample, head, 8x8 window): 64 slots, NT == 2
-    const int nww = a.W >> 3, nwh = a.H >> 3;
+  } else {                                               // one workgroup per (sample, head, window): ws^2 slots
+    const int nww = a.W >> WinLog2<MODE>::v, nwh = a.H >> WinLog2<MODE>::v;
     int r = blockIdx.x;
     wj = r % nww; r /= nww; wi = r % nwh; r /= nwh; head = r % a.nh; b = r / a.nh;
   }
-  const int T = MODE == MODE_GLOBAL ? a.T : 64;          // slots of this problem
+  const int T = MODE == MODE_GLOBAL ? a.T : (1 << (2 * WinLog2<MODE>::v));          // slots of this problem
   const long row_stride = 3L * a.nh * DH;
   const float* base = a.qkv + (long)b * a.T * row_stride + head * DH;
   const float sqrt_scale = PREP ? sqrtf(a.scale_h[head]) : 1.f;
@@ -777,7 +782,7 @@ __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseA
     }
   }
 
-  const int q_region = (MODE == MODE_WINDOW) ? slot_region(min(q_slot, 63), wi, wj, a.shift) : 0;
+  const int q_region = (MODE != MODE_GLOBAL) ? slot_region<MODE>(min(q_slot, T - 1), wi, wj, a.shift) : 0;
   // ---- softmax over keys (keys >= T masked by an additive -inf) ----------------------------------------------------------------------
   float m = -INFINITY;
 #pragma unroll
@@ -786,8 +791,10 @@ __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseA
     for (int i = 0; i < 16; ++i) {
       if (MODE == MODE_GLOBAL) {
         if (t * 32 + 32 > T) S[t][i] += (t * 32 + mfma32_row(i, lane) < T) ? 0.f : -INFINITY;
-      } else if (a.shift) {      // shifted windows: a key counts only if it lies in the query's wrapped region (:285-316)
-        S[t][i] += (slot_region(t * 32 + mfma32_row(i, lane), wi, wj, a.shift) == q_region) ? 0.f : -INFINITY;
+      } else {
+        if ((1 << (2 * WinLog2<MODE>::v)) < TP) S[t][i] += (t * 32 + mfma32_row(i, lane) < T) ? 0.f : -INFINITY;      // 4x4 windows: 16 of 32 slots
+        // shifted windows: a key counts only if it lies in the query's wrapped region (:285-316)
+        if (a.shift) S[t][i] += (slot_region<MODE>(min(t * 32 + mfma32_row(i, lane), T - 1), wi, wj, a.shift) == q_region) ? 0.f : -INFINITY;
       }
       m = fmaxf(m, S[t][i]);
     }
@@ -1152,7 +1159,7 @@ template <int MODE, int NT>
 static int launch_global_split(const DenseArgs& a, int prep, long nblocks, hipStream_t s) {
   constexpr int TP = NT * 32, VSTR = TP * 2 + 4;
   constexpr int lds = 2 * (TP * 128 > DH * VSTR ? TP * 128 : DH * VSTR);
-  const int n_slots = MODE == MODE_GLOBAL ? a.T : 64;
+  const int n_slots = MODE == MODE_GLOBAL ? a.T : (1 << (2 * WinLog2<MODE>::v));
   LaunchScope prof(MODE == MODE_GLOBAL ? "attn_global_bf16x3" : "attn_window_bf16x3", 4.0 * (double)nblocks * n_slots * n_slots * DH,
                    4.0 * (double)a.batch * a.T * a.nh * DH * 4.0, s);
   if (prep) {
@@ -1172,7 +1179,7 @@ static int launch_global_split(const DenseArgs& a, int prep, long nblocks, hipSt
 template <int MODE, int MAXT>
 static int launch_dense(const DenseArgs& a, int prep, long nblocks, const char* name, hipStream_t s) {
   const size_t lds = (size_t)2 * MAXT * 32 * LDS_ROW * sizeof(float);
-  const int n_slots = MODE == MODE_GLOBAL ? a.T : 64;
+  const int n_slots = MODE == MODE_GLOBAL ? a.T : (1 << (2 * WinLog2<MODE>::v));
   const double flops = 4.0 * (double)nblocks * n_slots * n_slots * DH;
   const double bytes = 4.0 * (double)a.batch * a.T * a.nh * DH * 4.0;
   LaunchScope prof(name, flops, bytes, s);
@@ -1238,15 +1245,22 @@ extern "C" int kd_attn_global_f32(const float* qkv, float* out, int batch, int T
 extern "C" int kd_attn_window_f32(const float* qkv, float* out, int batch, int H, int W, int nh, int ws, int shift, int prep,
                                   const float* scale_h, const float* cos_t, const float* sin_t, float eps, void* stream) {
   if (!qkv || !out || batch <= 0 || nh <= 0 || H <= 0 || W <= 0) return fail(KD_EINVAL, "kd_attn_window_f32: bad arguments");
-  if (ws != 8) return fail(KD_EINVAL, "kd_attn_window_f32: window_size %d unsupported (only 8)", ws);
+  if (ws != 4 && ws != 8 && ws != 16) return fail(KD_EINVAL, "kd_attn_window_f32: window_size %d unsupported (4, 8 or 16)", ws);
   if ((H % ws) || (W % ws)) return fail(KD_EINVAL, "kd_attn_window_f32: grid %dx%d not divisible by the window", H, W);
   if (shift < 0 || shift >= ws) return fail(KD_EINVAL, "kd_attn_window_f32: bad shift %d", shift);
   if (int e = check_prep(prep, scale_h, cos_t, sin_t, "kd_attn_window_f32")) return e;
   DenseArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H * W, nh, H, W, ws, shift, eps};
   const long nb = (long)batch * nh * (H / ws) * (W / ws);
   const char* mode = getenv("KDIFF_GEMM");
-  if (!(mode && !strcmp(mode, "exact"))) return launch_global_split<MODE_WINDOW, 2>(a, prep, nb, (hipStream_t)stream);
-  return launch_dense<MODE_WINDOW, 2>(a, prep, nb, "attn_window_f32", (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (!(mode && !strcmp(mode, "exact"))) {
+    if (ws == 8) return launch_global_split<MODE_WINDOW, 2>(a, prep, nb, s);
+    if (ws == 4) return launch_global_split<MODE_WINDOW4, 1>(a, prep, nb, s);
+    return launch_global_split<MODE_WINDOW16, 8>(a, prep, nb, s);
+  }
+  if (ws == 8) return launch_dense<MODE_WINDOW, 2>(a, prep, nb, "attn_window_f32", s);
+  if (ws == 4) return launch_dense<MODE_WINDOW4, 1>(a, prep, nb, "attn_window_f32", s);
+  return launch_dense<MODE_WINDOW16, 8>(a, prep, nb, "attn_window_f32", s);
 }
 
 extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, int W, int nh, int ks, int prep,

@@ -162,6 +162,14 @@ def op_fixtures():
     ts.fac.data = torch.tensor([0.37])
     skip = rn(2, 16, 16, 64)
     out["split.w"], out["split.skip"], out["split.y"] = ts.proj.weight.data.clone(), skip, ts(x, skip)
+    # other window sizes (own generator: the entries above keep their values): 4x4 windows on an 8x12 grid, 16x16 on 16x32
+    g2 = torch.Generator().manual_seed(2025)
+    rn2 = lambda *s: torch.randn(*s, generator=g2)
+    for tag, ws, shift, (n, h, w, nh) in (("w4s0", 4, 0, (2, 8, 12, 2)), ("w4s2", 4, 2, (2, 8, 12, 2)), ("w16s8", 16, 8, (1, 16, 32, 1)),
+                                          ("w16s0", 16, 0, (1, 16, 32, 1))):
+        qw, kw_, vw = rn2(n, h, w, nh, 64) * 0.6, rn2(n, h, w, nh, 64) * 0.6, rn2(n, h, w, nh, 64)
+        ow = v2.apply_window_attention(ws, shift, hf2(qw), hf2(kw_), hf2(vw), scale=1.0)
+        out.update({f"attn_{tag}.q": qw, f"attn_{tag}.k": kw_, f"attn_{tag}.v": vw, f"attn_{tag}.o": ow.permute(0, 2, 3, 1, 4).contiguous()})
     # fourier features + mapping network are covered by the "cond" tap of the forward cases
     return {k: v.detach().contiguous() for k, v in out.items()}
 
@@ -212,6 +220,8 @@ def main():
     if "--kat-only" in sys.argv:
         return
     save_file(op_fixtures(), os.path.join(gd, "ops.safetensors"), metadata=meta)
+    if "--ops-only" in sys.argv:
+        return
     save_file(forward_fixtures(), os.path.join(gd, "forward.safetensors"), metadata=meta)
     save_file(sample_fixtures(), os.path.join(gd, "samples.safetensors"), metadata=meta)
     for f in sorted(os.listdir(gd)):

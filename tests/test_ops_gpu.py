@@ -270,6 +270,17 @@ def test_window_attention_rect(ops, gtol, golden):
     assert relerr(y, o["attn_window_rect.o"]) < gtol
 
 
+@pytest.mark.parametrize("tag,ws,shift", [("w4s0", 4, 0), ("w4s2", 4, 2), ("w16s8", 16, 8), ("w16s0", 16, 0)])
+def test_window_attention_other_sizes(ops, gtol, golden, tag, ws, shift):
+    """4x4 and 16x16 windows (one and eight waves per window) against the reference's apply_window_attention."""
+    o = golden["ops"]
+    q = o[f"attn_{tag}.q"]
+    y = ops.attn_window(g(_pack(q, o[f"attn_{tag}.k"], o[f"attn_{tag}.v"])), q.shape[3], ws, shift).view(*q.shape)
+    assert relerr(y, o[f"attn_{tag}.o"]) < gtol
+    with pytest.raises(RuntimeError, match="window_size"):
+        ops.attn_window(g(rn(1, 12, 12, 192)), 1, 6, 0)
+
+
 @pytest.mark.parametrize("T,nh,B", [(49, 4, 3), (64, 8, 2), (100, 1, 2), (256, 2, 2), (7, 1, 1)])
 def test_attn_global_sizes(ops, gtol, T, nh, B):
     q, k, v = (rn(B, 1, T, nh, 64, seed=s, scale=sc) for s, sc in ((1, 0.6), (2, 0.6), (3, 1.0)))

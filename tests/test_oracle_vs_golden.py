@@ -143,6 +143,9 @@ def test_ops_vs_reference(golden):
         assert relerr(hdit.attn_shifted_window(q, k, o["qk.v"], 8, shift), o[f"attn_window{shift}.o"]) < 1e-5, shift
     got = hdit.attn_shifted_window(o["attn_window_rect.q"], o["attn_window_rect.k"], o["attn_window_rect.v"], 8, 4)
     assert relerr(got, o["attn_window_rect.o"]) < 1e-5
+    for tag, ws, shift in (("w4s0", 4, 0), ("w4s2", 4, 2), ("w16s8", 16, 8), ("w16s0", 16, 0)):      # other window sizes
+        got = hdit.attn_shifted_window(o[f"attn_{tag}.q"], o[f"attn_{tag}.k"], o[f"attn_{tag}.v"], ws, shift)
+        assert relerr(got, o[f"attn_{tag}.o"]) < 1e-5, tag
     assert relerr(hdit.token_merge(x, o["merge.w"], 2, 2), o["merge.y"]) < 2e-6
     up = hdit.token_split(x, o["split.w"], 2, 2)
     assert relerr(torch.lerp(o["split.skip"], up, torch.tensor([0.37])), o["split.y"]) < 2e-6
