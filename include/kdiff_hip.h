@@ -76,6 +76,9 @@ typedef struct {
   const float* qk_scale;  /* KD_EPI_QKV: [n_heads] cosine-sim scale (self_attn.scale)                 */
   const float* rope_cos;  /* KD_EPI_QKV: [rows_per_sample, n_heads, 16] cos / sin of AxialRoPE theta  */
   const float* rope_sin;
+  int qkv_packed;       /* KD_EPI_QKV + KD_PREC_SPLIT3: store every 4-column chunk of q, k, v as [hi: 4 x bf16][lo: 4 x bf16]
+                           (hi = bf16(x), lo = bf16(x - hi)) in the 16 bytes of its 4 floats -- the operand format of the
+                           split-bf16x3 attention cores, which then take it as stored (their prep = 2)        */
 } KdGemm;
 
 int kd_gemm_f32(const KdGemm* desc, void* stream);
@@ -105,19 +108,23 @@ int kd_cond_sum_f32(float* out, const float* a, const float* b, int b_rows, cons
  * Replaces scale_for_cosine_sim (image_transformer_v2.py:106-114) + apply_rotary_emb_
  * (:187-231, in place on a view).  cos/sin: [tokens_per_sample, nh, 16] tables of
  * AxialRoPE.forward's theta (:245-248), computed once on the host.
- * The attention kernels below can also apply it on the fly (prep != 0) so that this pass and
- * its HBM round trip disappear from the hot path. */
+ * The attention kernels below take `prep`:
+ *   0  q, k already prepared (by this call or by the KD_EPI_QKV epilogue), fp32
+ *   1  raw fp32 q, k: prepared on the fly (needs scale_h, cos_t, sin_t)
+ *   2  prepared AND stored split (KdGemm.qkv_packed: [hi: 4 x bf16][lo: 4 x bf16] per 4-column chunk): the split-bf16x3
+ *      cores use the operands as stored; not available with KDIFF_GEMM=exact */
 int kd_qk_prep_f32(float* qkv, const float* scale_h, const float* cos_t, const float* sin_t,
                    int batch, int tokens_per_sample, int nh, float eps, void* stream);
 
-/* Dense softmax attention per (sample, head) over all T tokens (T <= 256), softmax scale 1.0.
+/* Dense softmax attention per (sample, head) over all T tokens (any T; T > 256 streams key blocks with an online
+ * softmax and is served by the split-bf16x3 core only), softmax scale 1.0.
  * Replaces F.scaled_dot_product_attention / flash_attn_qkvpacked_func at
  * image_transformer_v2.py:383,392.  out: [batch*T, nh*64]. */
 int kd_attn_global_f32(const float* qkv, float* out, int batch, int T, int nh,
                        int prep, const float* scale_h, const float* cos_t, const float* sin_t, float eps,
                        void* stream);
 
-/* Shifted-window attention (window ws x ws = 64 tokens, ws == 8), roll/window/mask/unwindow
+/* Shifted-window attention (window ws x ws tokens, ws in {4, 8, 16}), roll/window/mask/unwindow
  * folded into addressing.  Replaces apply_window_attention image_transformer_v2.py:319-337
  * (+ :253-316).  shift is 0 or ws/2. */
 int kd_attn_window_f32(const float* qkv, float* out, int batch, int H, int W, int nh, int ws, int shift,

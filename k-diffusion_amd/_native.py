@@ -36,6 +36,7 @@ class KdGemm(C.Structure):
         ("scale", C.c_void_p), ("sigma", C.c_void_p), ("fac", C.c_void_p),
         ("precision", C.c_int), ("Wp", C.c_void_p), ("debug", C.c_int), ("scale_tab", C.c_int),
         ("n_heads", C.c_int), ("qk_scale", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+        ("qkv_packed", C.c_int),
     ]
 
 

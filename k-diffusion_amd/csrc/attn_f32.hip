@@ -305,13 +305,25 @@ __device__ __forceinline__ void split4_bf16(const f32x4 v, u32x2& hi, u32x2& lo)
   lo[0] = pack2_bf16(r01[0], r01[1]);
   lo[1] = pack2_bf16(r23[0], r23[1]);
 }
+// q / k / v chunks as the consumers want them: either split here (fp32 input) or taken as stored (PK: the qkv GEMM already
+// wrote every 4-dim chunk as [hi: 4 x bf16][lo: 4 x bf16] in the 16 bytes of its 4 floats -- kd_gemm_f32 qkv_packed)
+template <bool PK>
+__device__ __forceinline__ void split_in(const f32x4 v, u32x2& hi, u32x2& lo) {
+  if (PK) {
+    hi = u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])};
+    lo = u32x2{__float_as_uint(v[2]), __float_as_uint(v[3])};
+  } else {
+    split4_bf16(v, hi, lo);
+  }
+}
 // byte offset of (row, 16-byte chunk c of 8) in a [rows][64] bf16 image with 128-byte rows
 __device__ __forceinline__ int na_kswz(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 
 // FULL: the image is at least as large as the halo (H >= 14, W >= 22), so every halo key lies inside the image and only
 // the pad rows past key 307 need zeroing: no per-key bounds tests / selects in the staging loops.
-template <bool PREP, bool FULL>
+template <int PMODE, bool FULL>      // PMODE 0: q, k prepared (fp32)  1: raw fp32, prepared here  2: prepared and stored split (packed)
 __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
+  constexpr bool PREP = PMODE == 1, PK = PMODE == 2;
   extern __shared__ __attribute__((aligned(16))) char na_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h2 = lane >> 5;
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
       }
       if (hr < NA_KROWS) {
         u32x2 hi, lo;
-        split4_bf16(v, hi, lo);
+        split_in<PK>(v, hi, lo);
         const int o = na_kswz(hr, c16 >> 1) + (c16 & 1) * 8;
         *reinterpret_cast<u32x2*>(Khi + o) = hi;
         *reinterpret_cast<u32x2*>(Klo + o) = lo;
@@ -432,8 +444,8 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
     u32x2 h0, l0, h1, l1;
-    split4_bf16(qf[2 * st], h0, l0);
-    split4_bf16(qf[2 * st + 1], h1, l1);
+    split_in<PK>(qf[2 * st], h0, l0);
+    split_in<PK>(qf[2 * st + 1], h1, l1);
     qh[st] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
     ql[st] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
   }
@@ -551,8 +563,8 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
       if (tok < 0) v0 = f32x4{0.f, 0.f, 0.f, 0.f};
       if (tok < 0 || !pair_odd_ok(hv_use)) v1 = f32x4{0.f, 0.f, 0.f, 0.f};
       u32x2 h0, l0, h1, l1;
-      split4_bf16(v0, h0, l0);
-      split4_bf16(v1, h1, l1);
+      split_in<PK>(v0, h0, l0);
+      split_in<PK>(v1, h1, l1);
       char* ph_ = Vhi + (4 * c16) * NA_VT_STRIDE + hv_use.key * 2;
       char* pl_ = Vlo + (4 * c16) * NA_VT_STRIDE + hv_use.key * 2;
       // e = 4c16+0: low halves, +1: high halves of word 0; +2, +3: word 1   (v_perm_b32 selects)
@@ -651,8 +663,9 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
 // as the neighbourhood core (S^T = K Q^T with K rows from swizzled LDS, O^T = V^T P^T with P from registers and V staged
 // transposed), without halo or window mask: NT = ceil(T/32) waves, wave w owns queries 32w..32w+31 and all NT key tiles
 // (the whole score row lives in registers: no online softmax).  K and then V^T occupy the same LDS buffer.
-template <int MODE, int NT, bool PREP>
+template <int MODE, int NT, int PMODE>
 __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseArgs a) {
+  constexpr bool PREP = PMODE == 1, PK = PMODE == 2;
   extern __shared__ __attribute__((aligned(16))) char gs_smem[];
   constexpr int TP = NT * 32, NTHR = NT * 64;
   constexpr int VSTR = TP * 2 + 4;                       // bytes per e-row of V^T: odd dword count -> conflict-free dword-pair reads
@@ -709,7 +722,7 @@ __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseA
       }
       if (slot >= T) v = f32x4{0.f, 0.f, 0.f, 0.f};
       u32x2 hi, lo;
-      split4_bf16(v, hi, lo);
+      split_in<PK>(v, hi, lo);
       const int o = na_kswz(slot, c16 >> 1) + (c16 & 1) * 8;
       *reinterpret_cast<u32x2*>(Khi + o) = hi;
       *reinterpret_cast<u32x2*>(Klo + o) = lo;
@@ -749,8 +762,8 @@ __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseA
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
     u32x2 h0, l0, h1, l1;
-    split4_bf16(qf[2 * st], h0, l0);
-    split4_bf16(qf[2 * st + 1], h1, l1);
+    split_in<PK>(qf[2 * st], h0, l0);
+    split_in<PK>(qf[2 * st + 1], h1, l1);
     qh[st] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
     ql[st] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
   }
@@ -821,8 +834,8 @@ __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseA
     if (key >= T) v0 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (key + 1 >= T) v1 = f32x4{0.f, 0.f, 0.f, 0.f};
     u32x2 h0, l0, h1, l1;
-    split4_bf16(v0, h0, l0);
-    split4_bf16(v1, h1, l1);
+    split_in<PK>(v0, h0, l0);
+    split_in<PK>(v1, h1, l1);
     char* ph_ = Vhi + (4 * c16) * VSTR + key * 2;
     char* pl_ = Vlo + (4 * c16) * VSTR + key * 2;
     *reinterpret_cast<unsigned*>(ph_) = __builtin_amdgcn_perm(h1[0], h0[0], 0x05040100u);
@@ -905,8 +918,9 @@ constexpr int GL_VSTR = GL_KB * 2 + 4;
 constexpr int GL_IMG_K = GL_KB * 128, GL_IMG_V = DH * GL_VSTR;
 constexpr int GL_LDS = 2 * GL_IMG_K + 2 * GL_IMG_V;
 
-template <bool PREP>
+template <int PMODE>
 __global__ __launch_bounds__(GL_THR) void attn_global_long_kernel(const DenseArgs a) {
+  constexpr bool PREP = PMODE == 1, PK = PMODE == 2;
   extern __shared__ __attribute__((aligned(16))) char gl_smem[];
   char* Khi = gl_smem;
   char* Klo = gl_smem + GL_IMG_K;
@@ -956,8 +970,8 @@ __global__ __launch_bounds__(GL_THR) void attn_global_long_kernel(const DenseArg
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       u32x2 h0, l0, h1, l1;
-      split4_bf16(qf[2 * st], h0, l0);
-      split4_bf16(qf[2 * st + 1], h1, l1);
+      split_in<PK>(qf[2 * st], h0, l0);
+      split_in<PK>(qf[2 * st + 1], h1, l1);
       qh[st] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
       ql[st] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
     }
@@ -1002,7 +1016,7 @@ __global__ __launch_bounds__(GL_THR) void attn_global_long_kernel(const DenseArg
       }
       if (key >= T) v = f32x4{0.f, 0.f, 0.f, 0.f};
       u32x2 hi, lo;
-      split4_bf16(v, hi, lo);
+      split_in<PK>(v, hi, lo);
       const int o = na_kswz(slot, c16 >> 1) + (c16 & 1) * 8;
       *reinterpret_cast<u32x2*>(Khi + o) = hi;
       *reinterpret_cast<u32x2*>(Klo + o) = lo;
@@ -1014,8 +1028,8 @@ __global__ __launch_bounds__(GL_THR) void attn_global_long_kernel(const DenseArg
       if (key >= T) v0 = f32x4{0.f, 0.f, 0.f, 0.f};
       if (key + 1 >= T) v1 = f32x4{0.f, 0.f, 0.f, 0.f};
       u32x2 h0, l0, h1, l1;
-      split4_bf16(v0, h0, l0);
-      split4_bf16(v1, h1, l1);
+      split_in<PK>(v0, h0, l0);
+      split_in<PK>(v1, h1, l1);
       char* ph_ = Vhi + (4 * c16) * GL_VSTR + slot * 2;
       char* pl_ = Vlo + (4 * c16) * GL_VSTR + slot * 2;
       *reinterpret_cast<unsigned*>(ph_) = __builtin_amdgcn_perm(h1[0], h0[0], 0x05040100u);
@@ -1141,17 +1155,15 @@ static int launch_global_long(const DenseArgs& a, int prep, hipStream_t s) {
   const long nqb = (a.T + GL_QW * 32 - 1) / (GL_QW * 32);
   const long nblocks = (long)a.batch * a.nh * nqb;
   LaunchScope prof("attn_global_bf16x3", 4.0 * (double)a.batch * a.nh * a.T * a.T * DH, 4.0 * (double)a.batch * a.T * a.nh * DH * 4.0, s);
-  if (prep) {
-    auto k = attn_global_long_kernel<true>;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS); set = true; }
-    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(GL_THR), GL_LDS, s, a);
-  } else {
-    auto k = attn_global_long_kernel<false>;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS); set = true; }
-    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(GL_THR), GL_LDS, s, a);
+#define KD_GL(PM)                                                                                                                                   \
+  {                                                                                                                                                \
+    auto k = attn_global_long_kernel<PM>;                                                                                                          \
+    static bool set = false;                                                                                                                       \
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS); set = true; }   \
+    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(GL_THR), GL_LDS, s, a);                                                                    \
   }
+  if (prep == 1) KD_GL(1) else if (prep == 2) KD_GL(2) else KD_GL(0)
+#undef KD_GL
   return check_launch("kd_attn_global_f32");
 }
 
@@ -1162,17 +1174,15 @@ static int launch_global_split(const DenseArgs& a, int prep, long nblocks, hipSt
   const int n_slots = MODE == MODE_GLOBAL ? a.T : (1 << (2 * WinLog2<MODE>::v));
   LaunchScope prof(MODE == MODE_GLOBAL ? "attn_global_bf16x3" : "attn_window_bf16x3", 4.0 * (double)nblocks * n_slots * n_slots * DH,
                    4.0 * (double)a.batch * a.T * a.nh * DH * 4.0, s);
-  if (prep) {
-    auto k = attn_global_split_kernel<MODE, NT, true>;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(NT * 64), lds, s, a);
-  } else {
-    auto k = attn_global_split_kernel<MODE, NT, false>;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(NT * 64), lds, s, a);
+#define KD_GS(PM)                                                                                                                                \
+  {                                                                                                                                             \
+    auto k = attn_global_split_kernel<MODE, NT, PM>;                                                                                            \
+    static bool set = false;                                                                                                                    \
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }   \
+    hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(NT * 64), lds, s, a);                                                                   \
   }
+  if (prep == 1) KD_GS(1) else if (prep == 2) KD_GS(2) else KD_GS(0)
+#undef KD_GS
   return check_launch("kd_attn_global_f32");
 }
 
@@ -1202,7 +1212,8 @@ static int launch_dense(const DenseArgs& a, int prep, long nblocks, const char* 
 using namespace kd;
 
 static int check_prep(int prep, const float* scale_h, const float* cos_t, const float* sin_t, const char* who) {
-  if (prep && (!scale_h || !cos_t || !sin_t)) return fail(KD_EINVAL, "%s: prep needs scale_h, cos_t, sin_t", who);
+  if (prep < 0 || prep > 2) return fail(KD_EINVAL, "%s: prep must be 0 (prepared fp32), 1 (prepare here) or 2 (prepared, stored split)", who);
+  if (prep == 1 && (!scale_h || !cos_t || !sin_t)) return fail(KD_EINVAL, "%s: prep needs scale_h, cos_t, sin_t", who);
   return KD_OK;
 }
 
@@ -1228,6 +1239,7 @@ extern "C" int kd_attn_global_f32(const float* qkv, float* out, int batch, int T
   // default: split-bf16x3 MFMA core (like the GEMMs); KDIFF_GEMM=exact keeps the exact-fp32 MFMA core
   const char* mode = getenv("KDIFF_GEMM");                    // read per call (tests switch modes inside one process)
   const bool exact = mode && !strcmp(mode, "exact");
+  if (exact && prep == 2) return fail(KD_EINVAL, "kd_attn_global_f32: split-stored qkv (prep = 2) is for the split-bf16x3 cores, not KDIFF_GEMM=exact");
   if (T > 256) {
     if (exact) return fail(KD_EINVAL, "kd_attn_global_f32: T=%d > 256 tokens is served by the streaming split-bf16x3 core only (unset KDIFF_GEMM=exact)", T);
     return launch_global_long(a, prep, s);
@@ -1258,6 +1270,7 @@ extern "C" int kd_attn_window_f32(const float* qkv, float* out, int batch, int H
     if (ws == 4) return launch_global_split<MODE_WINDOW4, 1>(a, prep, nb, s);
     return launch_global_split<MODE_WINDOW16, 8>(a, prep, nb, s);
   }
+  if (prep == 2) return fail(KD_EINVAL, "kd_attn_window_f32: split-stored qkv (prep = 2) is for the split-bf16x3 cores, not KDIFF_GEMM=exact");
   if (ws == 8) return launch_dense<MODE_WINDOW, 2>(a, prep, nb, "attn_window_f32", s);
   if (ws == 4) return launch_dense<MODE_WINDOW4, 1>(a, prep, nb, "attn_window_f32", s);
   return launch_dense<MODE_WINDOW16, 8>(a, prep, nb, "attn_window_f32", s);
@@ -1277,16 +1290,18 @@ extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, 
   LaunchScope prof(nm, 4.0 * batch * (double)H * W * nh * DH * ks * ks, 16.0 * batch * (double)H * W * nh * DH, s);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
+#define KD_NA_ATTR(PM, FU) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<PM, FU>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
+    KD_NA_ATTR(0, true) KD_NA_ATTR(0, false) KD_NA_ATTR(1, true) KD_NA_ATTR(1, false) KD_NA_ATTR(2, true) KD_NA_ATTR(2, false)
+#undef KD_NA_ATTR
     attr_set = true;
   }
   const bool full = H >= NA_HR && W >= NA_HC;      // every halo key is inside the image
-  if (prep && full) hipLaunchKernelGGL((attn_na2d_kernel<true, true>), dim3((unsigned)nb), dim3(256), NA_LDS, s, a);
-  else if (prep) hipLaunchKernelGGL((attn_na2d_kernel<true, false>), dim3((unsigned)nb), dim3(256), NA_LDS, s, a);
-  else if (full) hipLaunchKernelGGL((attn_na2d_kernel<false, true>), dim3((unsigned)nb), dim3(256), NA_LDS, s, a);
-  else hipLaunchKernelGGL((attn_na2d_kernel<false, false>), dim3((unsigned)nb), dim3(256), NA_LDS, s, a);
+#define KD_NA(PM)                                                                                              \
+  {                                                                                                           \
+    if (full) hipLaunchKernelGGL((attn_na2d_kernel<PM, true>), dim3((unsigned)nb), dim3(256), NA_LDS, s, a); \
+    else hipLaunchKernelGGL((attn_na2d_kernel<PM, false>), dim3((unsigned)nb), dim3(256), NA_LDS, s, a);      \
+  }
+  if (prep == 1) KD_NA(1) else if (prep == 2) KD_NA(2) else KD_NA(0)
+#undef KD_NA
   return check_launch("kd_attn_na2d_f32");
 }

@@ -476,6 +476,11 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_kernel(const K
               o[u] = (fabsf(fac) < 0.5f) ? skip + fac * diff : o[u] - diff * (1.0f - fac);
             }
           }
+          if (EPI == KD_EPI_QKV && SPLIT && p.qkv_packed) {      // operand format of the split attention cores (kdiff_hip.h)
+            u32x2 hi, lo;
+            split4(o, hi, lo);
+            o = f32x4{__uint_as_float(hi[0]), __uint_as_float(hi[1]), __uint_as_float(lo[0]), __uint_as_float(lo[1])};
+          }
           if (ok[t]) *reinterpret_cast<f32x4*>(p.C + off[t]) = o;
         }
       }
@@ -606,6 +611,8 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
   if (d.norm && d.rows_per_sample <= 0) return fail(KD_EINVAL, "kd_gemm_f32: rows_per_sample");
   if (d.epi == KD_EPI_QKV && (d.n_heads <= 0 || d.N != 3 * d.n_heads * 64 || d.rows_per_sample <= 0 || !d.qk_scale || !d.rope_cos || !d.rope_sin))
     return fail(KD_EINVAL, "kd_gemm_f32: qkv epilogue needs N == 3*n_heads*64, rows_per_sample, qk_scale, rope_cos, rope_sin");
+  if (d.qkv_packed && (d.epi != KD_EPI_QKV || d.precision != KD_PREC_SPLIT3))
+    return fail(KD_EINVAL, "kd_gemm_f32: qkv_packed needs the qkv epilogue and split3 precision");
   KdGemm e = d;
   if (e.rows_per_sample <= 0) e.rows_per_sample = e.M;
   // all rows of a 128-row tile share their scale vector: stage it in LDS once per tile

@@ -220,6 +220,11 @@ __global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_
         f32x4 v = *reinterpret_cast<const f32x4*>(strip + row8 * 64 + c4);
         if (EPI == KD_EPI_QKV && which < 2) v = prep_row16_regs(v, lane & 15, sq_tab[head], cs[t], sn[t], p.eps);
         if (EPI == KD_EPI_STORE) v = v + p.out_add;
+        if (EPI == KD_EPI_QKV && p.qkv_packed) {                  // operand format of the split attention cores (kdiff_hip.h)
+          u32x2 hi, lo;
+          split4(v, hi, lo);
+          v = f32x4{__uint_as_float(hi[0]), __uint_as_float(hi[1]), __uint_as_float(lo[0]), __uint_as_float(lo[1])};
+        }
 #ifdef KD_ABL_NOSTORE
         if (p.eps < 0.f) *reinterpret_cast<f32x4*>(p.C + (long)gm * N + gn) = v;     // never true
         else asm volatile("" ::"v"(v));

@@ -23,6 +23,7 @@ The plan (workspace + prebuilt launch descriptors) is cached per input shape.  T
 CPU path: calling ``forward`` without a ROCm device or without the built library raises.
 """
 import ctypes as C
+import os
 import math
 from dataclasses import dataclass
 from typing import Union
@@ -265,6 +266,8 @@ class _Plan:
         def scale_ptr(name):
             return ("table", 4 * offsets[name])
 
+        packed_qkv = precision == nat.PREC_SPLIT3 and os.environ.get("KDIFF_QKV_PACKED", "1") != "0"
+
         def add_layer(li, prefix, mod, index):
             lv, (gh, gw), T = levels[li], grids[li], toks[li]
             d, x = lv.width, xs[li]
@@ -276,10 +279,13 @@ class _Plan:
                 self.keep += [cos_t, sin_t]
                 # q, k leave the qkv GEMM already prepared (cosine-sim scale + RoPE in its epilogue): every halo /
                 # window / key tile of the attention cores would otherwise redo that work per use
-                gemm(prefix + "qkv_proj", x, sa.qkv_proj.weight, qkv, T, 3 * d, d, epi=nat.EPI_QKV,
-                     scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps,
-                     qk=(sa.scale, cos_t, sin_t, nh))
-                prep = (0, None, None, None, C.c_float(1e-6))
+                # ... and, for the split-bf16x3 cores, already SPLIT (hi / lo bf16 chunks in the fp32 slots): the cores take
+                # their operands as stored instead of converting every halo / window / key-block element again
+                dq = gemm(prefix + "qkv_proj", x, sa.qkv_proj.weight, qkv, T, 3 * d, d, epi=nat.EPI_QKV,
+                          scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps,
+                          qk=(sa.scale, cos_t, sin_t, nh))
+                dq.qkv_packed = 1 if packed_qkv else 0
+                prep = (2 if packed_qkv else 0, None, None, None, C.c_float(1e-6))
                 if isinstance(spec, GlobalAttentionSpec):
                     call(prefix + "attn_global", lib.kd_attn_global_f32, _ptr(qkv), _ptr(att), B, gh * gw, nh, *prep)
                 elif isinstance(spec, NeighborhoodAttentionSpec):
@@ -455,7 +461,8 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         if fp != self._fingerprint:
             self._plans, self._fingerprint, self._packed = {}, fp, {}
         has_class = self.class_emb is not None
-        key = (B, H, W, aug_cond is not None, has_class, self.mapping_cond_in_proj is not None, x.device, nat.default_precision())
+        key = (B, H, W, aug_cond is not None, has_class, self.mapping_cond_in_proj is not None, x.device, nat.default_precision(),
+               os.environ.get("KDIFF_QKV_PACKED", "1"))
         plan = self._plans.get(key)
         if plan is None:
             if self.patch_in.proj.weight.device != x.device:
@@ -503,7 +510,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
             return
         B, _, H, W = x_like.shape
         key = (B, H, W, aug_cond is not None, self.class_emb is not None, self.mapping_cond_in_proj is not None, x_like.device,
-               nat.default_precision())
+               nat.default_precision(), os.environ.get("KDIFF_QKV_PACKED", "1"))
         plan = self._plans.get(key)
         if plan is None or plan.prefetched is not None or self._weights_fingerprint() != self._fingerprint:
             return

@@ -71,7 +71,7 @@ def pack_weight(W, N, K, geglu, cache=True):
 
 def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scale=None, scale_stride=0,
          rows_per_sample=0, residual=None, grid=(0, 0), patch=(0, 0, 0), eps=1e-6, out_add=0.0,
-         sigma=None, sigma_data=1.0, fac=None, scale_ptr=None, precision=None, qk=None):
+         sigma=None, sigma_data=1.0, fac=None, scale_ptr=None, precision=None, qk=None, qkv_packed=False):
     """Fused GEMM (see KdGemm in include/kdiff_hip.h).  ``norm_scale`` may be a tensor or, with
     ``scale_ptr``, a raw device address inside a larger scale table.  ``precision``: nat.PREC_EXACT /
     nat.PREC_SPLIT3 (default: KDIFF_GEMM env, split3)."""
@@ -95,6 +95,7 @@ def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scal
     if qk is not None:          # EPI_QKV: (scale_h [nh], cos [T, nh, 16], sin [T, nh, 16], nh)
         d.qk_scale, d.rope_cos, d.rope_sin = (_chk(t, n).data_ptr() for t, n in zip(qk[:3], ("qk_scale", "cos", "sin")))
         d.n_heads = qk[3]
+        d.qkv_packed = 1 if qkv_packed else 0      # q, k, v stored as split-bf16 chunks for the attention cores (prep="packed")
     nat.check(nat.lib().kd_gemm_f32(C.byref(d), _stream()), "kd_gemm_f32")
     return out
 
@@ -127,7 +128,7 @@ def rms_norm(x, scale, eps=1e-6, out=None):
     return out
 
 
-def norm_linear(x, scale, weight, *, rows_per_sample, epi=nat.EPI_STORE, out=None, eps=1e-6, qk=None):
+def norm_linear(x, scale, weight, *, rows_per_sample, epi=nat.EPI_STORE, out=None, eps=1e-6, qk=None, qkv_packed=False):
     """AdaRMSNorm/RMSNorm (:155-166) fused into the following Linear / LinearGEGLU.
     ``scale``: [B, K] per-sample scales (AdaRMSNorm: Linear(cond) + 1) or [K] shared gain.
     ``epi=EPI_QKV`` with ``qk=(scale_h, cos, sin, nh)``: qkv projection whose q, k come out prepared
@@ -137,7 +138,7 @@ def norm_linear(x, scale, weight, *, rows_per_sample, epi=nat.EPI_STORE, out=Non
     Nn = weight.shape[0] // (2 if epi == nat.EPI_GEGLU else 1)
     out = torch.empty(*x.shape[:-1], Nn, device=x.device, dtype=x.dtype) if out is None else out
     return gemm(x, weight, out, M=M, N=Nn, K=K, epi=epi, norm_scale=scale, scale_stride=K if scale.dim() == 2 else 0,
-                rows_per_sample=rows_per_sample, eps=eps, qk=qk)
+                rows_per_sample=rows_per_sample, eps=eps, qk=qk, qkv_packed=qkv_packed)
 
 
 def token_merge(x, weight, out=None):
@@ -226,6 +227,10 @@ def qk_prep_(qkv, scale_h, cos_t, sin_t, nh, eps=1e-6):
 def _prep_args(prep):
     if prep is None:
         return 0, None, None, None, 1e-6
+    if isinstance(prep, str):
+        if prep != "packed":
+            raise ValueError("prep: None (q, k prepared), (scale_h, cos, sin[, eps]) or 'packed' (prepared and stored split by the qkv GEMM)")
+        return 2, None, None, None, 1e-6
     scale_h, cos_t, sin_t = prep[:3]
     eps = prep[3] if len(prep) > 3 else 1e-6
     return 1, _p(_chk(scale_h, "scale")), _p(_chk(cos_t, "cos")), _p(_chk(sin_t, "sin")), eps

@@ -128,6 +128,41 @@ def test_qkv_epilogue_prepares_q_and_k(ops, gtol):
         ops.norm_linear(g(x), g(scale), g(w[: 2 * d]), rows_per_sample=H * W, epi=5, qk=(g(sh), g(cos), g(sin), nh))
 
 
+@pytest.mark.parametrize("H,W,nh,B,K", [(16, 16, 2, 2, 128), (32, 32, 2, 1, 128), (20, 24, 4, 1, 256), (8, 8, 8, 3, 512)])
+def test_split_stored_qkv_feeds_the_attention_cores(ops, monkeypatch, H, W, nh, B, K):
+    """qkv_packed: the qkv GEMM stores q, k, v as split-bf16 chunks and the split cores (prep='packed') take them as stored.
+    Same split of the same values, so every core must return BIT-identical results to the fp32-qkv path."""
+    monkeypatch.setenv("KDIFF_GEMM", "split3")
+    T, N = H * W, 3 * nh * 64
+    x, w = rn(B * T, K, seed=1), rn(N, K, seed=3) / K ** 0.5
+    scale = 1 + 0.1 * rn(B, K, seed=2)
+    sh = torch.linspace(6.0, 12.0, nh)
+    cos, sin = _tables(H, W, nh)
+    qk = (g(sh), g(cos), g(sin), nh)
+    plain = ops.norm_linear(g(x), g(scale), g(w), rows_per_sample=T, epi=5, qk=qk).view(B, H, W, N)
+    packed = ops.norm_linear(g(x), g(scale), g(w), rows_per_sample=T, epi=5, qk=qk, qkv_packed=True).view(B, H, W, N)
+    assert not torch.equal(plain, packed)
+    # the packed words are (hi, hi, lo, lo) bf16 pairs of the fp32 values
+    pw = packed.view(torch.int32).view(-1, 4)
+    hi = torch.stack([(pw[:, 0] << 16), (pw[:, 0] & -65536), (pw[:, 1] << 16), (pw[:, 1] & -65536)], dim=1).view(torch.float32)
+    lo = torch.stack([(pw[:, 2] << 16), (pw[:, 2] & -65536), (pw[:, 3] << 16), (pw[:, 3] & -65536)], dim=1).view(torch.float32)
+    assert relerr((hi + lo).view_as(plain), plain) < 2.0 ** -15
+    assert torch.equal(hi.view_as(plain), plain.to(torch.bfloat16).to(torch.float32))
+    if H >= 7 and W >= 7:
+        assert torch.equal(ops.attn_na2d(packed, nh, 7, prep="packed"), ops.attn_na2d(plain, nh, 7))
+    assert torch.equal(ops.attn_global(packed.view(B, T, N), nh, prep="packed"), ops.attn_global(plain.view(B, T, N), nh))   # T <= 256 and streaming
+    if H % 8 == 0 and W % 8 == 0:
+        for shift in (0, 4):
+            assert torch.equal(ops.attn_window(packed, nh, 8, shift, prep="packed"), ops.attn_window(plain, nh, 8, shift))
+    if H % 4 == 0 and W % 4 == 0:
+        assert torch.equal(ops.attn_window(packed, nh, 4, 2, prep="packed"), ops.attn_window(plain, nh, 4, 2))
+    monkeypatch.setenv("KDIFF_GEMM", "exact")
+    with pytest.raises(RuntimeError, match="split"):
+        ops.attn_global(packed.view(B, T, N), nh, prep="packed")
+    with pytest.raises(RuntimeError, match="qkv_packed"):
+        ops.norm_linear(g(x), g(scale), g(w), rows_per_sample=T, epi=5, qk=qk, qkv_packed=True)
+
+
 @pytest.mark.parametrize("M,K,N,kind", [(1024, 128, 384, "qkv"), (1000, 128, 768, "geglu"), (4096, 256, 768, "qkv"), (640, 256, 1536, "geglu"),
                                         (8192, 512, 1536, "qkv"), (2048, 512, 3072, "geglu"), (768, 512, 512, "store"), (520, 128, 256, "store"),
                                         # >= 65536 rows at K = 128: the 8-wave / 256-row-panel form (ragged last panel included)
