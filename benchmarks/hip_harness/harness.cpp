@@ -1,0 +1,315 @@
+// Stand-alone check + timing driver for the bf16-mode kernels of libkdiff_hip.so (through the C ABI, no Python / torch:
+// a fresh GPU box runs it seconds after the snapshot lands).  Every case compares the HIP result with an fp64 CPU
+// restatement of the same op on the same bf16-rounded inputs, on a sample of rows, and times the launch with HIP events.
+//   build: make -C benchmarks/hip_harness        run: benchmarks/hip_harness/harness [case-filter]
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/kdiff_hip.h"
+
+#define HIPCHK(x)                                                                                  \
+  do {                                                                                             \
+    hipError_t e_ = (x);                                                                           \
+    if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } \
+  } while (0)
+
+static uint16_t f2bf(float f) {   // round to nearest even
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float bf2f(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr; size_t n = 0;
+  explicit DevBuf(size_t n_) : n(n_) { HIPCHK(hipMalloc(&p, n * sizeof(T))); }
+  ~DevBuf() { (void)hipFree(p); }
+  void up(const std::vector<T>& h) { HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
+  std::vector<T> down() const { std::vector<T> h(n); HIPCHK(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost)); return h; }
+};
+
+static std::mt19937 rng(1234);
+static std::vector<float> randn(size_t n, float s = 1.f) {
+  std::normal_distribution<float> d(0.f, s);
+  std::vector<float> v(n);
+  for (auto& x : v) x = d(rng);
+  return v;
+}
+static std::vector<uint16_t> to_bf(const std::vector<float>& v) {
+  std::vector<uint16_t> o(v.size());
+  for (size_t i = 0; i < v.size(); ++i) o[i] = f2bf(v[i]);
+  return o;
+}
+
+static int g_fail = 0;
+static const char* g_filter = nullptr;
+static bool want(const char* name) { return !g_filter || strstr(name, g_filter); }
+
+template <class F>
+static float time_us(F&& launch, int iters = 20) {
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) launch();
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) launch();
+  HIPCHK(hipEventRecord(e1, 0));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1000.f / iters;
+}
+
+static double gelu(double x) { return 0.5 * x * (1.0 + erf(x * 0.70710678118654752440)); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct GemmCase {
+  const char* name; int M, N, K, epi, norm, rps, nh;
+};
+
+static void run_gemm_case(const GemmCase& c) {
+  if (!want(c.name)) return;
+  const int M = c.M, N = c.N, K = c.K;
+  const bool geglu = c.epi == KD_EPI_GEGLU;
+  const int NW = geglu ? 2 * N : N;      // weight rows
+  const int B = (M + c.rps - 1) / c.rps;
+  auto A_f = randn((size_t)M * K);
+  auto W_f = randn((size_t)NW * K, 1.0f / sqrtf((float)K));
+  auto A_h = to_bf(A_f);
+  std::vector<float> scale_h((size_t)B * K), pos_h((size_t)c.rps * 2), freq_h((size_t)std::max(c.nh, 1) * 8), qks_h(std::max(c.nh, 1));
+  for (auto& x : scale_h) x = 1.0f + 0.3f * std::normal_distribution<float>(0, 1)(rng);
+  for (auto& x : pos_h) x = std::uniform_real_distribution<float>(-1, 1)(rng);
+  for (int h = 0; h < std::max(c.nh, 1); ++h) {
+    qks_h[h] = 8.0f + h;
+    for (int j = 0; j < 8; ++j) freq_h[h * 8 + j] = (float)(exp(log(M_PI) + (log(10 * M_PI) - log(M_PI)) * (j * std::max(c.nh, 1) + h) / (8.0 * std::max(c.nh, 1))) / (2 * M_PI));
+  }
+  auto R_h = to_bf(randn((size_t)M * N));
+
+  DevBuf<uint16_t> dA(A_h.size()), dC((size_t)M * N), dR(R_h.size());
+  DevBuf<float> dW(W_f.size()), dS(scale_h.size()), dP(pos_h.size()), dF(freq_h.size()), dQ(qks_h.size());
+  dA.up(A_h); dR.up(R_h); dW.up(W_f); dS.up(scale_h); dP.up(pos_h); dF.up(freq_h); dQ.up(qks_h);
+  const long long wb = kd_packed_weight_bytes_bf16(N, K, geglu);
+  DevBuf<char> dWp((size_t)wb);
+  if (kd_pack_weight_bf16(dW.p, dWp.p, N, K, geglu, nullptr)) { printf("%s: pack failed: %s\n", c.name, kd_last_error()); ++g_fail; return; }
+  HIPCHK(hipMemset(dC.p, 0xFF, (size_t)M * N * 2));
+
+  KdGemm d;
+  memset(&d, 0, sizeof(d));
+  d.M = M; d.N = N; d.K = K; d.a_mode = KD_A_PLAIN; d.epi = c.epi; d.norm = c.norm;
+  d.rows_per_sample = c.rps; d.scale_stride = K; d.eps = 1e-6f;
+  d.A = reinterpret_cast<const float*>(dA.p); d.C = reinterpret_cast<float*>(dC.p); d.R = reinterpret_cast<const float*>(dR.p);
+  d.W = dW.p; d.Wp = dWp.p; d.scale = c.norm ? dS.p : nullptr; d.precision = KD_PREC_BF16;
+  d.n_heads = c.nh; d.qk_scale = dQ.p; d.rope_pos = dP.p; d.rope_freq = dF.p;
+  if (int rc = kd_gemm_bf16(&d, nullptr)) { printf("%-28s REJECTED (%d): %s\n", c.name, rc, kd_last_error()); ++g_fail; return; }
+  HIPCHK(hipDeviceSynchronize());
+  auto C_h = dC.down();
+
+  // ---- fp64 restatement on sampled rows -------------------------------------------------------------------------------
+  std::vector<int> rows;
+  for (int i = 0; i < 40; ++i) rows.push_back(i);
+  for (int i = 0; i < 40; ++i) rows.push_back(M - 1 - i);
+  std::uniform_int_distribution<int> rd(0, M - 1);
+  for (int i = 0; i < 240; ++i) rows.push_back(rd(rng));
+  double max_err = 0, max_ref = 0;
+  long bad = 0;
+  std::vector<double> acc(NW), out(N);
+  for (int m : rows) {
+    const int b = m / c.rps;
+    std::vector<double> a(K);
+    double ssq = 0;
+    for (int k = 0; k < K; ++k) { a[k] = bf2f(A_h[(size_t)m * K + k]); ssq += a[k] * a[k]; }
+    double rs = 1.0;
+    if (c.norm) {
+      rs = 1.0 / sqrt(ssq / K + 1e-6);
+      for (int k = 0; k < K; ++k) a[k] = bf2f(f2bf((float)(a[k] * scale_h[(size_t)b * K + k])));   // the kernel rounds x * scale to bf16
+    }
+    for (int n = 0; n < NW; ++n) {
+      double s = 0;
+      for (int k = 0; k < K; ++k) s += a[k] * (double)bf2f(f2bf(W_f[(size_t)n * K + k]));
+      acc[n] = s * rs;
+    }
+    if (geglu) {
+      for (int n = 0; n < N; ++n) out[n] = acc[n] * gelu(acc[N + n]);
+    } else if (c.epi == KD_EPI_QKV) {
+      const int tok = m % c.rps;
+      const double py = pos_h[2 * tok], px = pos_h[2 * tok + 1];
+      for (int vec = 0; vec < N / 64; ++vec) {
+        const int which = vec / c.nh, head = vec % c.nh;
+        double* v = &acc[vec * 64];
+        if (which < 2) {
+          double ss = 0;
+          for (int e = 0; e < 64; ++e) ss += v[e] * v[e];
+          const double f = sqrt((double)qks_h[head]) / sqrt(ss + 1e-6);
+          for (int e = 0; e < 64; ++e) v[e] *= f;
+          for (int e = 0; e < 16; ++e) {
+            const double th = (e < 8 ? py : px) * freq_h[head * 8 + (e & 7)] * 2 * M_PI;
+            const double x1 = v[e], x2 = v[e + 16];
+            v[e] = x1 * cos(th) - x2 * sin(th);
+            v[e + 16] = x2 * cos(th) + x1 * sin(th);
+          }
+        }
+        for (int e = 0; e < 64; ++e) out[vec * 64 + e] = v[e];
+      }
+    } else {
+      for (int n = 0; n < N; ++n) out[n] = acc[n] + (c.epi == KD_EPI_RESIDUAL ? (double)bf2f(R_h[(size_t)m * N + n]) : 0.0);
+    }
+    for (int n = 0; n < N; ++n) {
+      const double got = bf2f(C_h[(size_t)m * N + n]);
+      const double err = fabs(got - out[n]);
+      max_ref = std::max(max_ref, fabs(out[n]));
+      if (!(err <= 0.01 * fabs(out[n]) + 0.02)) ++bad;          // bf16 output rounding (2^-9 rel) + accumulation slack
+      if (err == err) max_err = std::max(max_err, err); else max_err = 1e30;
+    }
+  }
+  const float us = time_us([&] { kd_gemm_bf16(&d, nullptr); });
+  const double flops = 2.0 * M * (double)NW * K;
+  const double bytes = 2.0 * ((double)M * K + (double)M * N + (c.epi == KD_EPI_RESIDUAL ? (double)M * N : 0.0));
+  printf("%-28s M=%6d N=%4d K=%4d  max|err|=%.4g (max|ref|=%.3g) bad=%ld  %8.1f us  %7.1f TF/s  %6.0f GB/s  %s\n", c.name, M, N, K, max_err, max_ref, bad,
+         us, flops / us * 1e-6, bytes / us * 1e-3, bad ? "FAIL" : "ok");
+  if (bad) ++g_fail;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// memory-path probes (what does a CU take in per clock, and what does a row-per-lane store pattern cost)
+__global__ __launch_bounds__(1024) void probe_glds(const char* src, int bytes_per_block, int iters, int* sink) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const char* base = src + (size_t)(blockIdx.x & 7) * bytes_per_block;        // 8 distinct L2-resident regions
+  for (int it = 0; it < iters; ++it) {
+    for (int off = wid * 1024; off < bytes_per_block; off += nw * 1024)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(lds + off), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) sink[blockIdx.x] = lds[iters & 15];
+}
+__global__ __launch_bounds__(1024) void probe_vload(const uint4* src, int vec_per_block, int iters, int* sink) {
+  const uint4* base = src + (size_t)(blockIdx.x & 7) * vec_per_block;
+  unsigned acc = 0;
+  for (int it = 0; it < iters; ++it) {
+    for (int i = threadIdx.x; i < vec_per_block; i += blockDim.x * 4) {
+      uint4 a = base[i], b = base[min(i + (int)blockDim.x, vec_per_block - 1)], c = base[min(i + 2 * (int)blockDim.x, vec_per_block - 1)],
+            d = base[min(i + 3 * (int)blockDim.x, vec_per_block - 1)];
+      acc += a.x ^ b.y ^ c.z ^ d.w;
+    }
+    asm volatile("" ::: "memory");
+  }
+  if (acc == 0x12345u) sink[blockIdx.x] = (int)acc;
+}
+// HBM streaming read, every block its own region
+__global__ __launch_bounds__(256) void probe_stream(const uint4* src, size_t vec_total, int* sink) {
+  unsigned acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < vec_total; i += (size_t)gridDim.x * 256 * 4) {
+    const size_t s = (size_t)gridDim.x * 256;
+    uint4 a = src[i], b = src[std::min(i + s, vec_total - 1)], c = src[std::min(i + 2 * s, vec_total - 1)], d = src[std::min(i + 3 * s, vec_total - 1)];
+    acc += a.x ^ b.y ^ c.z ^ d.w;
+  }
+  if (acc == 0x12345u) sink[blockIdx.x] = (int)acc;
+}
+// stores: MODE 0 = fully coalesced 16 B per lane; MODE 1 = "row per lane": lane l31 owns a row of `row_bytes`, the two half-waves
+// write adjacent 16-byte pieces (32 contiguous bytes per row per instruction), successive instructions walk along the row
+template <int MODE>
+__global__ __launch_bounds__(256) void probe_store(uint4* dst, size_t rows, int row_bytes) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+  const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * 256) >> 6;
+  const uint4 v = {1u, 2u, 3u, (unsigned)lane};
+  const int vec_per_row = row_bytes / 16;
+  for (size_t chunk = wave; chunk * 32 < rows; chunk += nwaves) {
+    uint4* base = dst + chunk * 32 * vec_per_row;
+    if (MODE == 0) {
+      for (int i = lane; i < 32 * vec_per_row; i += 64) base[i] = v;
+    } else {
+      for (int i = 0; i < vec_per_row; i += 2) base[(size_t)l31 * vec_per_row + i + lh] = v;
+    }
+  }
+}
+
+static void run_probes() {
+  if (!want("probe")) return;
+  int dev = 0, cus = 256, khz = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, dev);
+  printf("device: %d CUs, %d MHz\n", cus, khz / 1000);
+  DevBuf<int> sink(4096);
+  {
+    const int region = 96 * 1024;
+    DevBuf<char> src((size_t)8 * region);
+    HIPCHK(hipMemset(src.p, 1, (size_t)8 * region));
+    for (int nw : {4, 8, 12, 16}) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(probe_glds), hipFuncAttributeMaxDynamicSharedMemorySize, region);
+      const int iters = 200;
+      const float us = time_us([&] { hipLaunchKernelGGL(probe_glds, dim3(cus), dim3(nw * 64), region, 0, src.p, region, iters, sink.p); }, 5);
+      const double bytes = (double)cus * region * iters;
+      printf("probe glds   L2-resident, %2d waves/CU: %8.1f us  %7.2f TB/s  = %5.1f B/clk/CU @2.4GHz\n", nw, us, bytes / us * 1e-6, bytes / us * 1e-3 / cus / 2.4);
+    }
+    for (int nw : {4, 8, 16}) {
+      const int iters = 200;
+      const float us = time_us([&] { hipLaunchKernelGGL(probe_vload, dim3(cus), dim3(nw * 64), 0, 0, reinterpret_cast<const uint4*>(src.p), region / 16, iters, sink.p); }, 5);
+      const double bytes = (double)cus * region * iters;
+      printf("probe vload  L2-resident, %2d waves/CU: %8.1f us  %7.2f TB/s  = %5.1f B/clk/CU @2.4GHz\n", nw, us, bytes / us * 1e-6, bytes / us * 1e-3 / cus / 2.4);
+    }
+  }
+  {
+    const size_t bytes = (size_t)1 << 30;
+    DevBuf<char> big(bytes);
+    HIPCHK(hipMemset(big.p, 1, bytes));
+    for (int blocks : {1024, 2048, 8192}) {
+      const float us = time_us([&] { hipLaunchKernelGGL(probe_stream, dim3(blocks), dim3(256), 0, 0, reinterpret_cast<const uint4*>(big.p), bytes / 16, sink.p); }, 5);
+      printf("probe stream HBM read 1 GiB, %5d blocks: %8.1f us  %7.2f TB/s\n", blocks, us, (double)bytes / us * 1e-6);
+    }
+    for (int row_bytes : {256, 768}) {
+      const size_t rows = bytes / 2 / row_bytes;
+      const float us0 = time_us([&] { hipLaunchKernelGGL(probe_store<0>, dim3(2048), dim3(256), 0, 0, reinterpret_cast<uint4*>(big.p), rows, row_bytes); }, 5);
+      const float us1 = time_us([&] { hipLaunchKernelGGL(probe_store<1>, dim3(2048), dim3(256), 0, 0, reinterpret_cast<uint4*>(big.p), rows, row_bytes); }, 5);
+      printf("probe store  512 MiB, rows of %4d B: coalesced %8.1f us %6.2f TB/s | row-per-lane %8.1f us %6.2f TB/s\n", row_bytes, us0,
+             (double)rows * row_bytes / us0 * 1e-6, us1, (double)rows * row_bytes / us1 * 1e-6);
+    }
+  }
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1) g_filter = argv[1];
+  printf("libkdiff_hip version %d\n", kd_version());
+  run_probes();
+  const GemmCase cases[] = {
+      {"wstat L0 qkv", 131072, 384, 128, KD_EPI_QKV, 1, 4096, 2},
+      {"wstat L0 geglu", 131072, 384, 128, KD_EPI_GEGLU, 1, 4096, 0},
+      {"wstat L0 out+res", 131072, 128, 128, KD_EPI_RESIDUAL, 0, 4096, 0},
+      {"wstat L0 down+res", 131072, 128, 384, KD_EPI_RESIDUAL, 0, 4096, 0},
+      {"wstat L0 store norm", 131072, 128, 128, KD_EPI_STORE, 1, 4096, 0},
+      {"wstat L1 out+res", 32768, 256, 256, KD_EPI_RESIDUAL, 0, 1024, 0},
+      {"wstat ragged qkv", 4128, 384, 128, KD_EPI_QKV, 1, 96, 2},
+      {"wstat ragged geglu", 4128, 96, 128, KD_EPI_GEGLU, 1, 96, 0},
+  };
+  for (const auto& c : cases) run_gemm_case(c);
+  if (want("waves8")) {
+    kd_set_option("wstat_waves", 8);
+    const GemmCase c8[] = {
+        {"waves8 L0 qkv", 131072, 384, 128, KD_EPI_QKV, 1, 4096, 2},
+        {"waves8 L0 geglu", 131072, 384, 128, KD_EPI_GEGLU, 1, 4096, 0},
+        {"waves8 L0 out+res", 131072, 128, 128, KD_EPI_RESIDUAL, 0, 4096, 0},
+    };
+    for (const auto& c : c8) run_gemm_case(c);
+    kd_set_option("wstat_waves", 0);
+  }
+  printf("%s (%d failing case%s)\n", g_fail ? "HARNESS FAILED" : "HARNESS OK", g_fail, g_fail == 1 ? "" : "s");
+  return g_fail ? 1 : 0;
+}

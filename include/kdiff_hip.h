@@ -31,6 +31,12 @@ extern "C" {
 
 int kd_version(void);
 const char* kd_last_error(void);
+/* Tuning / A-B switches of the library (benchmarks and tests; defaults are the shipped configuration).  The library reads no
+ * environment variables: the Python package maps its documented KDIFF_* variables onto these calls.  Thread-safe.
+ *   "skinny" (1) "astat" (1) "ksplit" (1) "astat_max_k" (512) "astat_waves" (4) "astat_storewait" (0)
+ *   "wstat" (1) "wstat_waves" (0 = per shape) */
+int kd_set_option(const char* name, int value);
+int kd_get_option(const char* name, int dflt);
 
 /* ------------------------------------------------------------------------------------------
  * Fused GEMM  C = epilogue( prologue(A) @ W^T ).   W is [N_w, K] row-major (nn.Linear.weight).
@@ -43,7 +49,9 @@ const char* kd_last_error(void);
 enum { KD_A_PLAIN = 0, KD_A_MERGE2x2 = 1, KD_A_PATCH_NCHW = 2 };
 /* arithmetic of the products: exact fp32 MFMA (bit-for-bit an fmaf chain), or each fp32 operand split into two
  * bf16 (hi + lo, 16 significand bits) with hi*hi + hi*lo + lo*hi on the bf16 MFMA and fp32 accumulation */
-enum { KD_PREC_EXACT = 0, KD_PREC_SPLIT3 = 1 };
+enum { KD_PREC_EXACT = 0, KD_PREC_SPLIT3 = 1,
+       KD_PREC_BF16 = 2 /* kd_gemm_bf16 only: bf16 activations in HBM, one bf16 MFMA per product, fp32 accumulate -- the
+                           arithmetic of the reference under torch.autocast(bfloat16) (image_transformer_v2.py:98-103,376-384) */ };
 enum { KD_EPI_STORE = 0, KD_EPI_RESIDUAL = 1, KD_EPI_GEGLU = 2, KD_EPI_SPLIT_LERP = 3, KD_EPI_UNPATCH_NCHW = 4,
        KD_EPI_QKV = 5 /* store a qkv projection with q,k prepared: cosine-sim scaling + axial RoPE
                          (image_transformer_v2.py:106-121,187-231) applied in the epilogue, v untouched */ };
@@ -79,9 +87,22 @@ typedef struct {
   int qkv_packed;       /* KD_EPI_QKV + KD_PREC_SPLIT3: store every 4-column chunk of q, k, v as [hi: 4 x bf16][lo: 4 x bf16]
                            (hi = bf16(x), lo = bf16(x - hi)) in the 16 bytes of its 4 floats -- the operand format of the
                            split-bf16x3 attention cores, which then take it as stored (their prep = 2)        */
+  const float* rope_pos;  /* kd_gemm_bf16 + KD_EPI_QKV: [rows_per_sample, 2] axial position (y, x) of every token       */
+  const float* rope_freq; /* kd_gemm_bf16 + KD_EPI_QKV: [n_heads, 8] AxialRoPE freqs / (2 pi) (angles in revolutions)   */
 } KdGemm;
 
 int kd_gemm_f32(const KdGemm* desc, void* stream);
+
+/* The same fused GEMM in bf16 arithmetic (precision must be KD_PREC_BF16).  Buffers: A, C, R are bf16 row-major (2 bytes per
+ * element) EXCEPT the image side of the patch modes, which stays fp32 like the solver state: A of KD_A_PATCH_NCHW, C and R of
+ * KD_EPI_UNPATCH_NCHW.  scale / sigma / fac / qk_scale are fp32.  Wp = image from kd_pack_weight_bf16 (W itself is not read).
+ * KD_EPI_QKV computes the RoPE angles in the epilogue from rope_pos / rope_freq (hardware sin / cos) instead of reading
+ * rope_cos / rope_sin tables.  Products: one v_mfma_f32_32x32x16_bf16 each, fp32 accumulation; RMS statistics, GELU, RoPE,
+ * lerp and the Karras scalings in fp32 registers; one rounding to bf16 at the store. */
+int kd_gemm_bf16(const KdGemm* desc, void* stream);
+long long kd_packed_weight_bytes_bf16(int N, int K, int geglu);
+/* W [N or 2N (geglu), K] fp32 -> blocks [n-tile][k-step][128 rows][64 k] bf16 (16 KiB each, the kernels' swizzled LDS image) */
+int kd_pack_weight_bf16(const float* W, void* out, int N, int K, int geglu, void* stream);
 
 /* One-off packing of a weight for KD_PREC_SPLIT3 (weights are static during sampling): W [N or 2N (geglu), K]
  * fp32 -> `out`, kd_packed_weight_bytes(N, K, geglu) bytes: [n-tile][k-step][hi|lo][128 rows][32 bf16] in the

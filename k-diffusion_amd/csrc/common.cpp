@@ -1,5 +1,7 @@
 // Error reporting + per-launch event timing shared by all entry points of libkdiff_hip.so.
 #include "kd_common.h"
+#include <map>
+#include <mutex>
 
 namespace kd {
 
@@ -34,7 +36,26 @@ void prof_end(hipStream_t s) { hipEventRecord(g_recs.back().e1, s); }
 
 using namespace kd;
 
-extern "C" int kd_version(void) { return 100; }
+// ---- library options (explicit switches instead of environment variables read inside the library) -------------------------
+namespace kd {
+static std::mutex g_opt_mu;
+static std::map<std::string, int> g_opts;
+int option(const char* name, int dflt) {
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  auto it = g_opts.find(name);
+  return it == g_opts.end() ? dflt : it->second;
+}
+}  // namespace kd
+
+extern "C" int kd_set_option(const char* name, int value) {
+  if (!name) return fail(KD_EINVAL, "kd_set_option: null name");
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  g_opts[name] = value;
+  return KD_OK;
+}
+extern "C" int kd_get_option(const char* name, int dflt) { return name ? option(name, dflt) : dflt; }
+
+extern "C" int kd_version(void) { return 200; }
 extern "C" const char* kd_last_error(void) { return err_buf(); }
 
 extern "C" int kd_prof_enable(int on) { g_prof = on != 0; return KD_OK; }

@@ -19,6 +19,7 @@ constexpr int WAVE = 64;
 // ---- error reporting (thread-local message, C ABI returns a code) -------------------------------
 char* err_buf();
 int fail(int code, const char* fmt, ...);
+int option(const char* name, int dflt);   // kd_set_option() values (tuning / A-B switches), thread-safe
 
 // ---- per-launch profiling (bench.py): hipEvent pairs around launches when enabled ---------------
 struct ProfRec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
