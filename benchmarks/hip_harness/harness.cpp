@@ -81,6 +81,7 @@ static double gelu(double x) { return 0.5 * x * (1.0 + erf(x * 0.707106781186547
 // ---------------------------------------------------------------------------------------------------------------------
 struct GemmCase {
   const char* name; int M, N, K, epi, norm, rps, nh;
+  int a_mode = KD_A_PLAIN, gh = 0, gw = 0;     // merge / split: coarse token grid (M = batch * gh * gw)
 };
 
 static void run_gemm_case(const GemmCase& c) {
@@ -90,6 +91,20 @@ static void run_gemm_case(const GemmCase& c) {
   const int NW = geglu ? 2 * N : N;      // weight rows
   const int B = (M + c.rps - 1) / c.rps;
   auto A_f = randn((size_t)M * K);
+  const bool merge = c.a_mode == KD_A_MERGE2x2, split = c.epi == KD_EPI_SPLIT_LERP;
+  // merge: A is the FINE grid [B, 2gh, 2gw, K/4]; the GEMM row m = (b, h, w) of the coarse grid reads k = quadrant * cin + e
+  auto a_index = [&](int m, int k) -> size_t {
+    if (!merge) return (size_t)m * K + k;
+    const int cin = K / 4, hw = c.gh * c.gw, b = m / hw, rr = m % hw, h = rr / c.gw, w = rr % c.gw, qd = k / cin, e = k % cin;
+    return (((size_t)b * (2 * c.gh) + 2 * h + (qd >> 1)) * (2 * c.gw) + 2 * w + (qd & 1)) * cin + e;
+  };
+  // split: C (and the skip R) is the FINE grid [B, 2gh, 2gw, N/4]; output feature n = quadrant * cout + e
+  auto c_index = [&](int m, int n) -> size_t {
+    if (!split) return (size_t)m * N + n;
+    const int cout = N / 4, hw = c.gh * c.gw, b = m / hw, rr = m % hw, h = rr / c.gw, w = rr % c.gw, qd = n / cout, e = n % cout;
+    return (((size_t)b * (2 * c.gh) + 2 * h + (qd >> 1)) * (2 * c.gw) + 2 * w + (qd & 1)) * cout + e;
+  };
+  const float fac_h = 0.37f;
   auto W_f = randn((size_t)NW * K, 1.0f / sqrtf((float)K));
   auto A_h = to_bf(A_f);
   std::vector<float> scale_h((size_t)B * K), pos_h((size_t)c.rps * 2), freq_h((size_t)std::max(c.nh, 1) * 8), qks_h(std::max(c.nh, 1));
@@ -102,8 +117,8 @@ static void run_gemm_case(const GemmCase& c) {
   auto R_h = to_bf(randn((size_t)M * N));
 
   DevBuf<uint16_t> dA(A_h.size()), dC((size_t)M * N), dR(R_h.size());
-  DevBuf<float> dW(W_f.size()), dS(scale_h.size()), dP(pos_h.size()), dF(freq_h.size()), dQ(qks_h.size());
-  dA.up(A_h); dR.up(R_h); dW.up(W_f); dS.up(scale_h); dP.up(pos_h); dF.up(freq_h); dQ.up(qks_h);
+  DevBuf<float> dW(W_f.size()), dS(scale_h.size()), dP(pos_h.size()), dF(freq_h.size()), dQ(qks_h.size()), dFac(1);
+  dA.up(A_h); dR.up(R_h); dW.up(W_f); dS.up(scale_h); dP.up(pos_h); dF.up(freq_h); dQ.up(qks_h); dFac.up(std::vector<float>{fac_h});
   const long long wb = kd_packed_weight_bytes_bf16(N, K, geglu);
   DevBuf<char> dWp((size_t)wb);
   if (kd_pack_weight_bf16(dW.p, dWp.p, N, K, geglu, nullptr)) { printf("%s: pack failed: %s\n", c.name, kd_last_error()); ++g_fail; return; }
@@ -111,7 +126,7 @@ static void run_gemm_case(const GemmCase& c) {
 
   KdGemm d;
   memset(&d, 0, sizeof(d));
-  d.M = M; d.N = N; d.K = K; d.a_mode = KD_A_PLAIN; d.epi = c.epi; d.norm = c.norm;
+  d.M = M; d.N = N; d.K = K; d.a_mode = c.a_mode; d.epi = c.epi; d.norm = c.norm; d.gh = c.gh; d.gw = c.gw; d.fac = dFac.p;
   d.rows_per_sample = c.rps; d.scale_stride = K; d.eps = 1e-6f;
   d.A = reinterpret_cast<const float*>(dA.p); d.C = reinterpret_cast<float*>(dC.p); d.R = reinterpret_cast<const float*>(dR.p);
   d.W = dW.p; d.Wp = dWp.p; d.scale = c.norm ? dS.p : nullptr; d.precision = KD_PREC_BF16;
@@ -133,7 +148,7 @@ static void run_gemm_case(const GemmCase& c) {
     const int b = m / c.rps;
     std::vector<double> a(K);
     double ssq = 0;
-    for (int k = 0; k < K; ++k) { a[k] = bf2f(A_h[(size_t)m * K + k]); ssq += a[k] * a[k]; }
+    for (int k = 0; k < K; ++k) { a[k] = bf2f(A_h[a_index(m, k)]); ssq += a[k] * a[k]; }
     double rs = 1.0;
     if (c.norm) {
       rs = 1.0 / sqrt(ssq / K + 1e-6);
@@ -167,10 +182,17 @@ static void run_gemm_case(const GemmCase& c) {
         for (int e = 0; e < 64; ++e) out[vec * 64 + e] = v[e];
       }
     } else {
-      for (int n = 0; n < N; ++n) out[n] = acc[n] + (c.epi == KD_EPI_RESIDUAL ? (double)bf2f(R_h[(size_t)m * N + n]) : 0.0);
+      for (int n = 0; n < N; ++n) {
+        if (split) {
+          const double skip = bf2f(R_h[c_index(m, n)]);
+          out[n] = skip + (double)fac_h * (acc[n] - skip);
+        } else {
+          out[n] = acc[n] + (c.epi == KD_EPI_RESIDUAL ? (double)bf2f(R_h[(size_t)m * N + n]) : 0.0);
+        }
+      }
     }
     for (int n = 0; n < N; ++n) {
-      const double got = bf2f(C_h[(size_t)m * N + n]);
+      const double got = bf2f(C_h[c_index(m, n)]);
       const double err = fabs(got - out[n]);
       max_ref = std::max(max_ref, fabs(out[n]));
       if (!(err <= 0.01 * fabs(out[n]) + 0.02)) ++bad;          // bf16 output rounding (2^-9 rel) + accumulation slack
@@ -179,7 +201,7 @@ static void run_gemm_case(const GemmCase& c) {
   }
   const float us = time_us([&] { kd_gemm_bf16(&d, nullptr); });
   const double flops = 2.0 * M * (double)NW * K;
-  const double bytes = 2.0 * ((double)M * K + (double)M * N + (c.epi == KD_EPI_RESIDUAL ? (double)M * N : 0.0));
+  const double bytes = 2.0 * ((double)M * K + (double)M * N + ((c.epi == KD_EPI_RESIDUAL || split) ? (double)M * N : 0.0));
   printf("%-28s M=%6d N=%4d K=%4d  max|err|=%.4g (max|ref|=%.3g) bad=%ld  %8.1f us  %7.1f TF/s  %6.0f GB/s  %s\n", c.name, M, N, K, max_err, max_ref, bad,
          us, flops / us * 1e-6, bytes / us * 1e-3, bad ? "FAIL" : "ok");
   if (bad) ++g_fail;
@@ -294,20 +316,81 @@ int main(int argc, char** argv) {
       {"wstat L0 geglu", 131072, 384, 128, KD_EPI_GEGLU, 1, 4096, 0},
       {"wstat L0 out+res", 131072, 128, 128, KD_EPI_RESIDUAL, 0, 4096, 0},
       {"wstat L0 down+res", 131072, 128, 384, KD_EPI_RESIDUAL, 0, 4096, 0},
-      {"wstat L0 store norm", 131072, 128, 128, KD_EPI_STORE, 1, 4096, 0},
+      {"wstat L1 qkv", 32768, 768, 256, KD_EPI_QKV, 1, 1024, 4},
+      {"wstat L1 geglu", 32768, 768, 256, KD_EPI_GEGLU, 1, 1024, 0},
       {"wstat L1 out+res", 32768, 256, 256, KD_EPI_RESIDUAL, 0, 1024, 0},
+      {"wstat L2 qkv", 8192, 1536, 512, KD_EPI_QKV, 1, 256, 8},
+      {"wstat L2 geglu", 8192, 1536, 512, KD_EPI_GEGLU, 1, 256, 0},
+      {"wstat L2 out+res", 8192, 512, 512, KD_EPI_RESIDUAL, 0, 256, 0},
       {"wstat ragged qkv", 4128, 384, 128, KD_EPI_QKV, 1, 96, 2},
       {"wstat ragged geglu", 4128, 96, 128, KD_EPI_GEGLU, 1, 96, 0},
+      {"tiled L1 down+res", 32768, 256, 768, KD_EPI_RESIDUAL, 0, 1024, 0},
+      {"tiled L2 down+res", 8192, 512, 1536, KD_EPI_RESIDUAL, 0, 256, 0},
+      {"tiled merge0", 32768, 256, 512, KD_EPI_STORE, 0, 1024, 0, KD_A_MERGE2x2, 32, 32},
+      {"tiled merge1", 8192, 512, 1024, KD_EPI_STORE, 0, 256, 0, KD_A_MERGE2x2, 16, 16},
+      {"tiled split1", 8192, 1024, 512, KD_EPI_SPLIT_LERP, 0, 256, 0, KD_A_PLAIN, 16, 16},
+      {"tiled split0", 32768, 512, 256, KD_EPI_SPLIT_LERP, 0, 1024, 0, KD_A_PLAIN, 32, 32},
+      {"tiled ragged store", 1000, 96, 192, KD_EPI_STORE, 0, 1000, 0},
+      {"tiled ragged res", 300, 160, 64, KD_EPI_RESIDUAL, 0, 300, 0},
   };
   for (const auto& c : cases) run_gemm_case(c);
-  if (want("waves8")) {
-    kd_set_option("wstat_waves", 8);
-    const GemmCase c8[] = {
-        {"waves8 L0 qkv", 131072, 384, 128, KD_EPI_QKV, 1, 4096, 2},
-        {"waves8 L0 geglu", 131072, 384, 128, KD_EPI_GEGLU, 1, 4096, 0},
-        {"waves8 L0 out+res", 131072, 128, 128, KD_EPI_RESIDUAL, 0, 4096, 0},
+  if (want("astat")) {
+    const GemmCase ca[] = {
+        {"astat L1 qkv", 32768, 768, 256, KD_EPI_QKV, 1, 1024, 4},
+        {"astat L1 geglu", 32768, 768, 256, KD_EPI_GEGLU, 1, 1024, 0},
+        {"astat L1 store", 32768, 256, 256, KD_EPI_STORE, 1, 1024, 0},
+        {"astat L2 qkv", 8192, 1536, 512, KD_EPI_QKV, 1, 256, 8},
+        {"astat L2 geglu", 8192, 1536, 512, KD_EPI_GEGLU, 1, 256, 0},
+        {"astat cifar L1 qkv", 4096, 1536, 512, KD_EPI_QKV, 1, 64, 8},
+        {"astat ragged qkv", 1000, 768, 256, KD_EPI_QKV, 1, 50, 4},
+        {"astat ragged geglu", 1000, 192, 256, KD_EPI_GEGLU, 1, 50, 0},
     };
-    for (const auto& c : c8) run_gemm_case(c);
+    for (const auto& c : ca) run_gemm_case(c);
+    for (int sp : {1, 2, 3, 6}) {
+      kd_set_option("astat_splits", sp);
+      printf("-- astat_splits = %d\n", sp);
+      const GemmCase cs[] = {
+          {"astat L1 qkv", 32768, 768, 256, KD_EPI_QKV, 1, 1024, 4},
+          {"astat L1 geglu", 32768, 768, 256, KD_EPI_GEGLU, 1, 1024, 0},
+          {"astat L2 qkv", 8192, 1536, 512, KD_EPI_QKV, 1, 256, 8},
+          {"astat L2 geglu", 8192, 1536, 512, KD_EPI_GEGLU, 1, 256, 0},
+      };
+      for (const auto& c : cs) run_gemm_case(c);
+    }
+    kd_set_option("astat_splits", 0);
+  }
+  if (want("tiled")) {      // the same residual shapes forced through the tiled kernel, both tile heights
+    kd_set_option("wstat", 0);
+    for (int bm : {128, 256}) {
+      kd_set_option("tiled_bm", bm);
+      printf("-- tiled_bm = %d, wstat off\n", bm);
+      const GemmCase ct[] = {
+          {"tiled L0 out+res", 131072, 128, 128, KD_EPI_RESIDUAL, 0, 4096, 0},
+          {"tiled L0 down+res", 131072, 128, 384, KD_EPI_RESIDUAL, 0, 4096, 0},
+          {"tiled L1 out+res", 32768, 256, 256, KD_EPI_RESIDUAL, 0, 1024, 0},
+          {"tiled L1 down+res", 32768, 256, 768, KD_EPI_RESIDUAL, 0, 1024, 0},
+          {"tiled L2 out+res", 8192, 512, 512, KD_EPI_RESIDUAL, 0, 256, 0},
+          {"tiled L2 down+res", 8192, 512, 1536, KD_EPI_RESIDUAL, 0, 256, 0},
+      };
+      for (const auto& c : ct) run_gemm_case(c);
+    }
+    kd_set_option("tiled_bm", 0);
+    kd_set_option("wstat", 1);
+  }
+  if (want("waves")) {
+    for (int w : {4, 12}) {
+      kd_set_option("wstat_waves", w);
+      printf("-- wstat_waves = %d\n", w);
+      const GemmCase cw[] = {
+          {"waves L0 qkv", 131072, 384, 128, KD_EPI_QKV, 1, 4096, 2},
+          {"waves L0 geglu", 131072, 384, 128, KD_EPI_GEGLU, 1, 4096, 0},
+          {"waves L1 qkv", 32768, 768, 256, KD_EPI_QKV, 1, 1024, 4},
+          {"waves L1 geglu", 32768, 768, 256, KD_EPI_GEGLU, 1, 1024, 0},
+          {"waves L2 qkv", 8192, 1536, 512, KD_EPI_QKV, 1, 256, 8},
+          {"waves L2 geglu", 8192, 1536, 512, KD_EPI_GEGLU, 1, 256, 0},
+      };
+      for (const auto& c : cw) run_gemm_case(c);
+    }
     kd_set_option("wstat_waves", 0);
   }
   printf("%s (%d failing case%s)\n", g_fail ? "HARNESS FAILED" : "HARNESS OK", g_fail, g_fail == 1 ? "" : "s");

@@ -81,8 +81,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
           for (int u = 0; u < 4; ++u) { x[2 * u] = bf_lo(raw[c][u]); x[2 * u + 1] = bf_hi(raw[c][u]); }
 #pragma unroll
           for (int u = 0; u < 8; ++u) ssq = fmaf(x[u], x[u], ssq);
-          const u32x4 o = {pack_bf16(x[0] * s0[0], x[1] * s0[1]), pack_bf16(x[2] * s0[2], x[3] * s0[3]),
-                           pack_bf16(x[4] * s1[0], x[5] * s1[1]), pack_bf16(x[6] * s1[2], x[7] * s1[3])};
+          u32x4 o = {pack_bf16(x[0] * s0[0], x[1] * s0[1]), pack_bf16(x[2] * s0[2], x[3] * s0[3]),
+                     pack_bf16(x[4] * s1[0], x[5] * s1[1]), pack_bf16(x[6] * s1[2], x[7] * s1[3])};
+          asm volatile("" : "+v"(o));    // materialise the fragment here (see the astat kernel)
           a[c] = __builtin_bit_cast(bf16x8, o);
         }
         ssq += __shfl_xor(ssq, 32, 64);
@@ -214,7 +215,7 @@ static int launch_wstat(const GArgs& a, int lds, const char* nm, double flops, d
 int gemm_wstat_try(const KdGemm& d, hipStream_t s, int* rc) {
   if (d.a_mode != KD_A_PLAIN || !d.Wp || !option("wstat", 1)) return 1;
   if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_QKV && d.epi != KD_EPI_GEGLU && d.epi != KD_EPI_RESIDUAL) return 1;
-  if (d.K != 128 && d.K != 256 && d.K != 384) return 1;
+  if (d.K != 128 && d.K != 256 && d.K != 384 && d.K != 512) return 1;
   if ((d.N & 31) || d.M < 2048) return 1;
   if (d.epi == KD_EPI_RESIDUAL && d.norm) return 1;
   if (d.epi != KD_EPI_RESIDUAL && !d.norm && d.epi != KD_EPI_STORE) return 1;
@@ -227,7 +228,9 @@ int gemm_wstat_try(const KdGemm& d, hipStream_t s, int* rc) {
   const int max_tiles = WSTAT_LDS_MAX / (nk * WBLK);
   if (max_tiles < 1) return 1;
   const int n_slices = (n_tiles + max_tiles - 1) / max_tiles;
-  if (n_slices > 2) return 1;                                  // every slice re-reads A
+  // every slice re-reads (and, with a norm, re-normalises) A: mostly L2 / MALL hits, cheap next to a weight ring with barriers,
+  // but a slice count near the CU count leaves too few row groups
+  if (n_slices > option("wstat_max_slices", 24) || n_slices * 4 > cu_count()) return 1;
   const int tps = (n_tiles + n_slices - 1) / n_slices;
   GArgs a{};
   a.A = reinterpret_cast<const u16*>(d.A); a.Wp = reinterpret_cast<const char*>(d.Wp);
@@ -242,30 +245,459 @@ int gemm_wstat_try(const KdGemm& d, hipStream_t s, int* rc) {
   char nm[96] = "gemm_wstat";
   if (prof_on()) snprintf(nm, sizeof(nm), "gemm_bf16_wstat<e%d,n%d> M=%d N=%d K=%d", d.epi, d.norm, d.M, d.N, d.K);
 #define KD_WS(NCV, EP, NO, NWV) { *rc = launch_wstat<NCV, EP, NO, NWV>(a, lds, nm, flops, bytes, s); return 0; }
-  const int ww = option("wstat_waves", 0);        // 0: per-shape default
-  if (d.K == 128 && ww != 8) {
-    if (d.epi == KD_EPI_QKV) KD_WS(8, KD_EPI_QKV, true, 12)
-    if (d.epi == KD_EPI_GEGLU) KD_WS(8, KD_EPI_GEGLU, true, 12)
-    if (d.epi == KD_EPI_STORE && d.norm) KD_WS(8, KD_EPI_STORE, true, 12)
-    if (d.epi == KD_EPI_STORE) KD_WS(8, KD_EPI_STORE, false, 12)
-    if (d.epi == KD_EPI_RESIDUAL) KD_WS(8, KD_EPI_RESIDUAL, false, 12)
-  } else if (d.K == 128) {
-    if (d.epi == KD_EPI_QKV) KD_WS(8, KD_EPI_QKV, true, 8)
-    if (d.epi == KD_EPI_GEGLU) KD_WS(8, KD_EPI_GEGLU, true, 8)
-    if (d.epi == KD_EPI_STORE && d.norm) KD_WS(8, KD_EPI_STORE, true, 8)
-    if (d.epi == KD_EPI_STORE) KD_WS(8, KD_EPI_STORE, false, 8)
-    if (d.epi == KD_EPI_RESIDUAL) KD_WS(8, KD_EPI_RESIDUAL, false, 8)
-  } else if (d.K == 256) {
-    if (d.epi == KD_EPI_QKV) KD_WS(16, KD_EPI_QKV, true, 8)
-    if (d.epi == KD_EPI_GEGLU) KD_WS(16, KD_EPI_GEGLU, true, 8)
-    if (d.epi == KD_EPI_STORE && d.norm) KD_WS(16, KD_EPI_STORE, true, 8)
-    if (d.epi == KD_EPI_STORE) KD_WS(16, KD_EPI_STORE, false, 8)
-    if (d.epi == KD_EPI_RESIDUAL) KD_WS(16, KD_EPI_RESIDUAL, false, 8)
-  } else {
+#define KD_WS_ALL(NCV, NWV)                                                       \
+  {                                                                               \
+    if (d.epi == KD_EPI_QKV) KD_WS(NCV, KD_EPI_QKV, true, NWV)                    \
+    if (d.epi == KD_EPI_GEGLU) KD_WS(NCV, KD_EPI_GEGLU, true, NWV)                \
+    if (d.epi == KD_EPI_STORE && d.norm) KD_WS(NCV, KD_EPI_STORE, true, NWV)      \
+    if (d.epi == KD_EPI_STORE) KD_WS(NCV, KD_EPI_STORE, false, NWV)               \
+    if (d.epi == KD_EPI_RESIDUAL) KD_WS(NCV, KD_EPI_RESIDUAL, false, NWV)         \
+  }
+  const int ww = option("wstat_waves", 0);        // 0: per-shape default (8 waves: 2 per SIMD, up to 256 registers each)
+  if (d.K == 128 && ww == 12) KD_WS_ALL(8, 12)
+  if (d.K == 128 && ww == 4) KD_WS_ALL(8, 4)
+  if (d.K == 128) KD_WS_ALL(8, 8)
+  if (d.K == 256 && ww == 4) KD_WS_ALL(16, 4)
+  if (d.K == 256) KD_WS_ALL(16, 8)
+  if (d.K == 384) {
     if (d.epi == KD_EPI_RESIDUAL) KD_WS(24, KD_EPI_RESIDUAL, false, 8)
     if (d.epi == KD_EPI_STORE && !d.norm) KD_WS(24, KD_EPI_STORE, false, 8)
   }
+  if (d.K == 512 && ww == 4) KD_WS_ALL(32, 4)
+  if (d.K == 512) KD_WS_ALL(32, 8)
+#undef KD_WS_ALL
 #undef KD_WS
+  return 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// tiled: C tile [128 * BMT rows][128 features] per workgroup, BOTH operands through LDS by global_load_lds (the packed weight
+// block verbatim; the activation tile as 8-row x 128-byte pieces whose 16-byte chunks are permuted on the SOURCE side into
+// the same swizzled image), K stepped by 64 through a 3-slot ring with one barrier per step (counted vmcnt: the next step's
+// pieces stay in flight across it).  The K loop is ds_read + MFMA only.  For the projections whose K is too long to keep a
+// row's fragments in registers (down projections, token merges) or whose weight is too large to park (splits).
+//   A gather  : plain | 2x2 token merge (a 64-wide k-step lies inside ONE fine token: Cin % 64 == 0)
+//   epilogue  : store | + residual | 2x2 token split + lerp(skip)          (all bf16, in the lane that owns the row)
+struct TArgs {
+  const u16* A; const char* Wp; u16* C; const u16* R; const float* fac;
+  int M, N, K, n_tiles_n, nk;
+  int gh, gw, cin;
+};
+
+#define KD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define KD_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+template <int AMODE, int EPI, int BMT>
+__global__ __launch_bounds__(256 * BMT, BMT == 1 ? 2 : 1) void gemm_tiled_kernel(const TArgs p) {
+  constexpr int NWV = 4 * BMT, BMR = 128 * BMT;
+  constexpr int A_IMG = BMR * 128, STG = A_IMG + WBLK, NSTG = BMT == 1 ? 2 : 3;
+  constexpr int WPC = 16 / NWV;                      // weight pieces (1 KiB) per wave per step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wc = wid & 1, wr = wid >> 1;
+  int tile;
+  {   // XCD-aware order, n fastest: the n-tiles of one row panel run back to back on ONE L2 (bijective for any grid)
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int nt = tile % p.n_tiles_n, mt = tile / p.n_tiles_n;
+  const int m0 = mt * BMR, n0 = nt * 128;
+  const int K = p.K, nk = p.nk;
+
+  // ---- this lane's 4 activation pieces per step: piece i = 4 * wid + ii covers tile rows 8i .. 8i+7 ----------------------------
+  const char* aptr[4];
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) {
+    const int row = 8 * (4 * wid + ii) + (lane >> 3);
+    const int q = (lane & 7) ^ ((row >> 1) & 7);
+    const int gm = min(m0 + row, p.M - 1);
+    if (AMODE == KD_A_PLAIN) {
+      aptr[ii] = reinterpret_cast<const char*>(p.A + (size_t)gm * K) + q * 16;
+    } else {      // merged token gm = (b, h, w) of the coarse grid; k = quadrant * cin + e
+      const int hw = p.gh * p.gw, b = gm / hw, rr = gm - b * hw, h = rr / p.gw, w = rr - h * p.gw;
+      aptr[ii] = reinterpret_cast<const char*>(p.A + (((size_t)b * (2 * p.gh) + 2 * h) * (2 * p.gw) + 2 * w) * p.cin) + q * 16;
+    }
+  }
+  const char* wsrc = p.Wp + (size_t)nt * nk * WBLK + (wid * WPC) * 1024 + lane * 16;
+  auto issue = [&](int kt) {
+    char* st = smem + (kt % NSTG) * STG;
+    size_t koff;
+    if (AMODE == KD_A_PLAIN) {
+      koff = (size_t)kt * 128;
+    } else {
+      const int k0 = kt * 64, qd = k0 / p.cin, e0 = k0 - qd * p.cin;
+      koff = ((size_t)((qd >> 1) * (2 * p.gw) + (qd & 1)) * p.cin + e0) * 2;
+    }
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(aptr[ii] + koff),
+                                       (__attribute__((address_space(3))) void*)(st + (4 * wid + ii) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < WPC; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)kt * WBLK + j * 1024),
+                                       (__attribute__((address_space(3))) void*)(st + A_IMG + (wid * WPC + j) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];      // [feature block i][row block j]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int off4[4];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) off4[cc] = swz128(l31, 2 * cc + lh);
+
+  issue(0);
+  if (NSTG == 3 && nk > 1) issue(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (NSTG == 3) {
+      if (kt + 1 < nk) { if (WPC == 4) KD_WAIT_VM(8); else KD_WAIT_VM(6); } else KD_WAIT_VM(0);
+    } else {
+      KD_WAIT_VM(0);
+    }
+    KD_BARRIER();                 // every wave's pieces of step kt are in; everyone is done reading the slot refilled next
+    if (kt + NSTG - 1 < nk) issue(kt + NSTG - 1);
+    const char* st = smem + (kt % NSTG) * STG;
+    const char* ab = st + (wr * 64) * 128;
+    const char* wb = st + A_IMG + (wc * 64) * 128;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      bf16x8 af[2], wf[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        af[u] = *reinterpret_cast<const bf16x8*>(ab + u * 32 * 128 + off4[cc]);
+        wf[u] = *reinterpret_cast<const bf16x8*>(wb + u * 32 * 128 + off4[cc]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------------------------------------
+  const float fac = EPI == KD_EPI_SPLIT_LERP ? *p.fac : 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int gm = m0 + wr * 64 + 32 * j + l31;
+    const bool ok = gm < p.M;
+    const int gmc = ok ? gm : p.M - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int nb = n0 + wc * 64 + 32 * i;
+      const int nbc = min(nb, p.N - 32);
+      size_t off;
+      if (EPI == KD_EPI_SPLIT_LERP) {
+        const int hw = p.gh * p.gw, cout = p.N >> 2;
+        const int b = gmc / hw, rr = gmc - b * hw, h = rr / p.gw, w = rr - h * p.gw;
+        const int qd = nbc / cout, e = nbc - qd * cout;
+        off = (((size_t)b * (2 * p.gh) + 2 * h + (qd >> 1)) * (2 * p.gw) + 2 * w + (qd & 1)) * cout + e;
+      } else {
+        off = (size_t)gmc * p.N + nbc;
+      }
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+      if (EPI == KD_EPI_RESIDUAL || EPI == KD_EPI_SPLIT_LERP) {
+        float rr_[16];
+        load_block_bf16(p.R + off, rr_, lh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (EPI == KD_EPI_RESIDUAL) {
+            v[r] += rr_[r];
+          } else {                                   // torch.lerp(skip, x, fac), ATen's two-branch form
+            const float skip = rr_[r], diff = v[r] - skip;
+            v[r] = (fabsf(fac) < 0.5f) ? skip + fac * diff : v[r] - diff * (1.0f - fac);
+          }
+        }
+      }
+      store_block_bf16(p.C + off, v, lh, ok && nb < p.N);
+    }
+  }
+}
+
+template <int AMODE, int EPI, int BMT>
+static int launch_tiled(const TArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {
+  auto kern = gemm_tiled_kernel<AMODE, EPI, BMT>;
+  constexpr int LDS = (BMT == 1 ? 2 : 3) * (128 * BMT * 128 + WBLK);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const long tiles = (long)((a.M + 128 * BMT - 1) / (128 * BMT)) * a.n_tiles_n;
+  LaunchScope prof(nm, flops, bytes, s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256 * BMT), LDS, s, a);
+  return check_launch("kd_gemm_bf16(tiled)");
+}
+
+int gemm_tiled_try(const KdGemm& d, hipStream_t s, int* rc) {
+  if (!d.Wp || d.norm || (d.K & 63) || (d.N & 31)) return 1;
+  if (d.a_mode != KD_A_PLAIN && d.a_mode != KD_A_MERGE2x2) return 1;
+  if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_RESIDUAL && d.epi != KD_EPI_SPLIT_LERP) return 1;
+  if (d.epi == KD_EPI_STORE && d.out_add != 0.f) return 1;
+  if (d.a_mode == KD_A_MERGE2x2 && (d.epi == KD_EPI_SPLIT_LERP || ((d.K >> 2) & 63))) return 1;
+  if (d.epi == KD_EPI_SPLIT_LERP && ((d.N >> 2) & 31)) return 1;
+  TArgs a{};
+  a.A = reinterpret_cast<const u16*>(d.A); a.Wp = reinterpret_cast<const char*>(d.Wp);
+  a.C = reinterpret_cast<u16*>(d.C); a.R = reinterpret_cast<const u16*>(d.R); a.fac = d.fac;
+  a.M = d.M; a.N = d.N; a.K = d.K; a.n_tiles_n = (d.N + 127) / 128; a.nk = d.K / 64;
+  a.gh = d.gh; a.gw = d.gw; a.cin = d.K >> 2;
+  const double flops = 2.0 * d.M * (double)d.N * d.K;
+  const double bytes = 2.0 * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N) + (d.epi != KD_EPI_STORE ? 2.0 * d.M * d.N : 0.0);
+  char nm[96] = "gemm_tiled";
+  if (prof_on()) snprintf(nm, sizeof(nm), "gemm_bf16_tiled<a%d,e%d> M=%d N=%d K=%d", d.a_mode, d.epi, d.M, d.N, d.K);
+  // 256-row tiles halve the weight traffic per flop; worth it once they still give every CU a workgroup
+  const long tiles256 = (long)((d.M + 255) / 256) * a.n_tiles_n;
+  const int bmt = option("tiled_bm", 0);
+  const bool big = bmt ? bmt == 256 : tiles256 >= cu_count();
+#define KD_TL(AM, EP)                                                                       \
+  if (d.a_mode == AM && d.epi == EP) {                                                      \
+    *rc = big ? launch_tiled<AM, EP, 2>(a, nm, flops, bytes, s) : launch_tiled<AM, EP, 1>(a, nm, flops, bytes, s); \
+    return 0;                                                                               \
+  }
+  KD_TL(KD_A_PLAIN, KD_EPI_STORE)
+  KD_TL(KD_A_PLAIN, KD_EPI_RESIDUAL)
+  KD_TL(KD_A_PLAIN, KD_EPI_SPLIT_LERP)
+  KD_TL(KD_A_MERGE2x2, KD_EPI_STORE)
+#undef KD_TL
+  return 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// astat: AdaRMSNorm -> wide projection (qkv, up-projection + GEGLU) at K = 256 / 512, where the weight is too large to park.
+// A workgroup (4 waves) owns a 128-row panel for a range of n-tiles: each wave keeps its 32 rows of the normalised, scaled
+// panel in registers as B-operand fragments (read and converted once), the packed weight streams through a 4-slot LDS ring
+// (one 16 KiB block = [128 features][64 k] per slot, global_load_lds three blocks ahead, counted vmcnt, one barrier per block),
+// the epilogue of an n-tile runs in the lanes that own the rows while the next blocks are in flight.  Two workgroups per CU.
+// vmcnt bookkeeping (loads and stores retire in issue order): the blocks needed right after an epilogue are confirmed BEFORE
+// its stores enter the queue; the first wait behind them allows exactly those stores to stay outstanding (full panels only).
+template <int NC, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const GArgs p) {
+  constexpr int K = NC * 16, NK = NC / 4, NSTG = 4;
+  constexpr bool GEGLU = EPI == KD_EPI_GEGLU;
+  constexpr int NCOL = GEGLU ? 64 : 128;
+  constexpr int NST = GEGLU ? 4 : 8;                 // 16-byte stores per lane per n-tile
+  static_assert(NK % NSTG == 0, "ring slot of a block must be a compile-time constant");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int nt_begin = (int)((long)p.n_tiles * blockIdx.y / gridDim.y), nt_end = (int)((long)p.n_tiles * (blockIdx.y + 1) / gridDim.y);
+  const int n_tiles = nt_end - nt_begin, total = n_tiles * NK;
+  const int m0 = blockIdx.x * 128;
+
+  const char* wp = p.Wp + (size_t)nt_begin * NK * WBLK + wid * 4096 + lane * 16;
+  auto issue = [&](int s) {
+    const char* src = wp + (size_t)s * WBLK;
+    char* dst = smem + (s % NSTG) * WBLK + wid * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+  };
+  issue(0);
+  issue(1);
+  issue(2);
+
+  const int row = m0 + wid * 32 + l31;
+  const bool ok = row < p.M;
+  const int rowc = ok ? row : p.M - 1;
+  bf16x8 a[NC];
+  float rs;
+  {
+    const u32x4* ap = reinterpret_cast<const u32x4*>(p.A + (size_t)rowc * K + 8 * lh);
+    const int b = rowc / p.rows_per_sample;
+    const float* sp = p.scale + (size_t)b * p.scale_stride + 8 * lh;
+    float ssq = 0.f;
+    // groups of 4 chunks, fenced: the loads of one group are in flight while the previous one is converted, and the live set
+    // stays at the fragments plus one group of raw rows / scales (all loads hoisted to the top would not fit the register file)
+#pragma unroll
+    for (int c0 = 0; c0 < NC; c0 += 4) {
+      u32x4 raw[4];
+      f32x4 s0[4], s1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        raw[u] = ap[2 * (c0 + u)];
+        s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
+        s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[2 * e] = bf_lo(raw[u][e]); x[2 * e + 1] = bf_hi(raw[u][e]); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ssq = fmaf(x[e], x[e], ssq);
+        u32x4 o = {pack_bf16(x[0] * s0[u][0], x[1] * s0[u][1]), pack_bf16(x[2] * s0[u][2], x[3] * s0[u][3]),
+                   pack_bf16(x[4] * s1[u][0], x[5] * s1[u][1]), pack_bf16(x[6] * s1[u][2], x[7] * s1[u][3])};
+        asm volatile("" : "+v"(o));      // materialise the fragment HERE: hipcc otherwise sinks the multiply + pack down to the
+                                         // first MFMA that uses it and keeps x and the scales (4x the registers) alive until then
+        a[c0 + u] = __builtin_bit_cast(bf16x8, o);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ssq += __shfl_xor(ssq, 32, 64);
+    rs = rsqrtf(ssq / (float)K + p.eps);
+  }
+  float py = 0.f, px = 0.f;
+  if (EPI == KD_EPI_QKV) {
+    const int tok = rowc % p.rows_per_sample;
+    py = p.pos[2 * tok];
+    px = p.pos[2 * tok + 1];
+  }
+  const bool full_panel = m0 + 128 <= p.M;
+  // every ordinary load above has been consumed (the compiler waited for them, which also drained the first ring blocks)
+
+  int off4[4];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) off4[cc] = swz128(l31, 2 * cc + lh);
+  u16* crow = p.C + (size_t)rowc * p.N;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  for (int nt = 0; nt < n_tiles; ++nt) {
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const int s = nt * NK + ks;
+      if (nt > 0 && ks == 2 && full_panel) {
+        // queue: [block s][NST epilogue stores][block s+1][block s+2]
+        if (s + 2 < total) { if (NST == 4) KD_WAIT_VM(12); else KD_WAIT_VM(16); }
+        else if (s + 1 < total) { if (NST == 4) KD_WAIT_VM(8); else KD_WAIT_VM(12); }
+        else { if (NST == 4) KD_WAIT_VM(4); else KD_WAIT_VM(8); }
+      } else if (nt == 0 || ks >= 2) {
+        if (s + 2 < total) KD_WAIT_VM(8); else if (s + 1 < total) KD_WAIT_VM(4); else KD_WAIT_VM(0);
+      }
+      KD_BARRIER();                      // every wave's quarter of block s is in; everyone is done reading slot (s-1) % NSTG
+      if (s + 3 < total) issue(s + 3);
+      const char* st = smem + (ks % NSTG) * WBLK;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(st + j * 32 * 128 + off4[cc]);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, a[4 * ks + cc], acc[j], 0, 0, 0);
+        }
+      }
+      // issue order: the 4 fragment reads of chunk cc+1 go out before the 4 MFMAs of chunk cc (two chunks of fragments live,
+      // not the whole block: with K = 512 the A fragments already hold half the register file)
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // blocks (nt+1, ks = 0, 1) were requested >= 2 blocks ago: confirm them before this epilogue's stores enter the queue
+    if (nt + 1 < n_tiles) KD_WAIT_VM(4);
+    const int n0 = (nt_begin + nt) * NCOL;
+    if (GEGLU) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        float v[16];
+        const float rsh = 0.5f * rs;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 o = geglu_pair(f32x2{acc[2 * jj][r], acc[2 * jj][r + 1]} * rsh, f32x2{acc[2 * jj + 1][r], acc[2 * jj + 1][r + 1]} * rs);
+          v[r] = o.x;
+          v[r + 1] = o.y;
+        }
+        store_block_bf16(crow + n0 + 32 * jj, v, lh, ok);
+      }
+    } else if (EPI == KD_EPI_QKV) {
+#pragma unroll
+      for (int vv = 0; vv < 2; ++vv) {
+        const int vec = (n0 >> 6) + vv;
+        const int which = vec / p.n_heads, head = vec - which * p.n_heads;
+        if (which < 2) {
+          float fr[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) fr[u] = lh ? p.freq[head * 8 + 4 + u] : p.freq[head * 8 + u];
+          qk_prep_blocks(acc[2 * vv], acc[2 * vv + 1], rs, sqrtf(p.qk_scale[head]), p.eps, py, px, fr);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc[2 * vv][r] *= rs; acc[2 * vv + 1][r] *= rs; }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = acc[2 * vv + jj][r];
+          store_block_bf16(crow + n0 + 64 * vv + 32 * jj, v, lh, ok);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[j][r] * rs;
+        store_block_bf16(crow + n0 + 32 * j, v, lh, ok);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  }
+}
+
+template <int NC, int EPI>
+static int launch_astat(const GArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {
+  auto kern = gemm_astat_kernel<NC, EPI>;
+  constexpr int LDS = 4 * WBLK;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  // panels x n-splits: two workgroups fit a CU; split the n-tiles of a panel until the grid fills them
+  const int panels = (a.M + 127) / 128;
+  const int want = 2 * cu_count();
+  int splits = 1;
+  for (int sp = 1; sp <= a.n_tiles; ++sp) {
+    if (a.n_tiles % sp) continue;
+    splits = sp;
+    if (panels * sp >= want) break;
+  }
+  const int forced = option("astat_splits", 0);
+  if (forced > 0 && forced <= a.n_tiles) splits = forced;
+  LaunchScope prof(nm, flops, bytes, s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)panels, (unsigned)splits), dim3(256), LDS, s, a);
+  return check_launch("kd_gemm_bf16(astat)");
+}
+
+int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
+  if (d.a_mode != KD_A_PLAIN || !d.Wp || !d.norm || !option("astat_bf16", 1)) return 1;
+  if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_QKV && d.epi != KD_EPI_GEGLU) return 1;
+  if (d.K != 256 && d.K != 512) return 1;
+  if (d.epi == KD_EPI_STORE && d.out_add != 0.f) return 1;
+  const bool geglu = d.epi == KD_EPI_GEGLU;
+  const int ncol = geglu ? 64 : 128;
+  if (d.N % ncol || d.M < 512) return 1;
+  if (d.rows_per_sample <= 0) return 1;
+  GArgs a{};
+  a.A = reinterpret_cast<const u16*>(d.A); a.Wp = reinterpret_cast<const char*>(d.Wp); a.C = reinterpret_cast<u16*>(d.C);
+  a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample; a.eps = d.eps;
+  a.M = d.M; a.N = d.N; a.n_tiles = d.N / ncol;
+  a.n_heads = d.n_heads; a.qk_scale = d.qk_scale; a.pos = d.rope_pos; a.freq = d.rope_freq;
+  const double n_eff = geglu ? 2.0 * d.N : (double)d.N;
+  const double flops = 2.0 * d.M * n_eff * d.K;
+  const double bytes = 2.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N);
+  char nm[96] = "gemm_astat";
+  if (prof_on()) snprintf(nm, sizeof(nm), "gemm_bf16_astat<e%d> M=%d N=%d K=%d", d.epi, d.M, d.N, d.K);
+#define KD_AS(NCV, EP) if (d.K == NCV * 16 && d.epi == EP) { *rc = launch_astat<NCV, EP>(a, nm, flops, bytes, s); return 0; }
+  KD_AS(16, KD_EPI_STORE) KD_AS(16, KD_EPI_QKV) KD_AS(16, KD_EPI_GEGLU)
+  KD_AS(32, KD_EPI_STORE) KD_AS(32, KD_EPI_QKV) KD_AS(32, KD_EPI_GEGLU)
+#undef KD_AS
   return 1;
 }
 
@@ -321,7 +753,15 @@ extern "C" int kd_gemm_bf16(const KdGemm* dp, void* stream) {
   if (d.epi == KD_EPI_RESIDUAL && !d.R) return fail(KD_EINVAL, "kd_gemm_bf16: residual needs R");
   if (d.epi == KD_EPI_QKV && (d.n_heads <= 0 || d.N != 3 * d.n_heads * 64 || d.rows_per_sample <= 0 || !d.qk_scale || !d.rope_pos || !d.rope_freq))
     return fail(KD_EINVAL, "kd_gemm_bf16: qkv epilogue needs N == 3*n_heads*64, rows_per_sample, qk_scale, rope_pos, rope_freq");
+  if (d.a_mode != KD_A_PLAIN && (d.gh <= 0 || d.gw <= 0 || d.M % (d.gh * d.gw))) return fail(KD_EINVAL, "kd_gemm_bf16: gather mode needs gh, gw with M %% (gh*gw) == 0");
+  if (d.epi == KD_EPI_SPLIT_LERP && (!d.R || !d.fac || (d.N & 3) || d.gh <= 0 || d.gw <= 0 || d.M % (d.gh * d.gw))) return fail(KD_EINVAL, "kd_gemm_bf16: split needs R, fac, N%%4==0, gh, gw");
   int rc = 0;
+  // shape-driven choice (benchmarks/hip_harness, profiles/r02_*): level-0 shapes (K = 128, and K = 384 with N = 128) park the
+  // weight; norm projections at K = 256 / 512 keep A in registers and stream the weight; the rest is tiled
+  const bool small_k = d.K == 128 || (d.K == 384 && d.N <= 128);
+  if (small_k && !b16::gemm_wstat_try(d, s, &rc)) return rc;
+  if (!b16::gemm_astat_try(d, s, &rc)) return rc;
+  if (!b16::gemm_tiled_try(d, s, &rc)) return rc;
   if (!b16::gemm_wstat_try(d, s, &rc)) return rc;
   return fail(KD_EINVAL, "kd_gemm_bf16: unsupported combination a_mode=%d norm=%d epi=%d M=%d N=%d K=%d", d.a_mode, d.norm, d.epi, d.M, d.N, d.K);
 }
