@@ -208,6 +208,92 @@ static void run_gemm_case(const GemmCase& c) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// attention cores: mode 0 global, 1 window (ws, shift), 2 neighbourhood (ks)
+struct AttnCase { const char* name; int mode, B, H, W, nh, p0, p1; };
+
+static void run_attn_case(const AttnCase& c) {
+  if (!want(c.name)) return;
+  const int T = c.H * c.W, nh = c.nh, B = c.B;
+  const size_t rowlen = (size_t)3 * nh * 64;
+  std::vector<float> qkv_f((size_t)B * T * rowlen);
+  {
+    std::normal_distribution<float> d(0.f, 1.f);
+    for (size_t t = 0; t < (size_t)B * T; ++t)
+      for (int which = 0; which < 3; ++which)
+        for (int h = 0; h < nh; ++h) {
+          float* v = &qkv_f[t * rowlen + (size_t)(which * nh + h) * 64];
+          double ss = 0;
+          for (int e = 0; e < 64; ++e) { v[e] = d(rng); ss += (double)v[e] * v[e]; }
+          if (which < 2) { const float f = (float)(sqrt(10.0) / sqrt(ss)); for (int e = 0; e < 64; ++e) v[e] *= f; }   // cosine-sim scaled, like the model
+        }
+  }
+  auto qkv_h = to_bf(qkv_f);
+  DevBuf<uint16_t> dQ(qkv_h.size()), dO((size_t)B * T * nh * 64);
+  dQ.up(qkv_h);
+  HIPCHK(hipMemset(dO.p, 0xFF, dO.n * 2));
+  auto launch = [&]() -> int {
+    if (c.mode == 0) return kd_attn_global_bf16(dQ.p, dO.p, B, T, nh, nullptr);
+    if (c.mode == 1) return kd_attn_window_bf16(dQ.p, dO.p, B, c.H, c.W, nh, c.p0, c.p1, nullptr);
+    return kd_attn_na2d_bf16(dQ.p, dO.p, B, c.H, c.W, nh, c.p0, nullptr);
+  };
+  if (int rc = launch()) { printf("%-28s REJECTED (%d): %s\n", c.name, rc, kd_last_error()); ++g_fail; return; }
+  HIPCHK(hipDeviceSynchronize());
+  auto O_h = dO.down();
+  auto at = [&](int b, int tok, int which, int h, int e) -> double { return bf2f(qkv_h[((size_t)b * T + tok) * rowlen + (size_t)(which * nh + h) * 64 + e]); };
+  std::uniform_int_distribution<int> rb(0, B - 1), rt(0, T - 1), rh(0, nh - 1);
+  double max_err = 0;
+  long bad = 0;
+  const int nq = 300;
+  for (int s = 0; s < nq; ++s) {
+    const int b = s < 4 ? 0 : rb(rng), h = rh(rng);
+    int tok = rt(rng);
+    if (s == 0) tok = 0; if (s == 1) tok = T - 1; if (s == 2) tok = c.W - 1; if (s == 3) tok = T - c.W;
+    const int qi = tok / c.W, qj = tok % c.W;
+    std::vector<int> keys;
+    if (c.mode == 0) {
+      for (int k = 0; k < T; ++k) keys.push_back(k);
+    } else if (c.mode == 1) {
+      const int ws = c.p0, sh = c.p1;
+      auto info = [&](int i, int j, int& win, int& reg) {
+        const int ri = (i + sh) % c.H, rj = (j + sh) % c.W, wi = ri / ws, wj = rj / ws;
+        win = wi * (c.W / ws) + wj;
+        reg = sh ? (((wi == 0 && (ri % ws) < sh) ? 2 : 0) + ((wj == 0 && (rj % ws) < sh) ? 1 : 0)) : 0;
+      };
+      int qw, qr;
+      info(qi, qj, qw, qr);
+      for (int k = 0; k < T; ++k) { int kw, kr; info(k / c.W, k % c.W, kw, kr); if (kw == qw && kr == qr) keys.push_back(k); }
+    } else {
+      const int ks = c.p0;
+      const int si = std::max(0, std::min(qi - ks / 2, c.H - ks)), sj = std::max(0, std::min(qj - ks / 2, c.W - ks));
+      for (int i = si; i < si + ks; ++i) for (int j = sj; j < sj + ks; ++j) keys.push_back(i * c.W + j);
+    }
+    std::vector<double> sc(keys.size());
+    double m = -1e300;
+    for (size_t k = 0; k < keys.size(); ++k) {
+      double d = 0;
+      for (int e = 0; e < 64; ++e) d += at(b, tok, 0, h, e) * at(b, keys[k], 1, h, e);
+      sc[k] = d; m = std::max(m, d);
+    }
+    double l = 0;
+    for (auto& x : sc) { x = exp(x - m); l += x; }
+    for (int e = 0; e < 64; ++e) {
+      double o = 0;
+      for (size_t k = 0; k < keys.size(); ++k) o += sc[k] * at(b, keys[k], 2, h, e);
+      o /= l;
+      const double got = bf2f(O_h[((size_t)b * T + tok) * (nh * 64) + h * 64 + e]);
+      const double err = fabs(got - o);
+      if (!(err <= 0.02 * fabs(o) + 0.02)) ++bad;
+      if (err == err) max_err = std::max(max_err, err); else max_err = 1e30;
+    }
+  }
+  const float us = time_us([&] { launch(); });
+  const double bytes = 2.0 * (double)B * T * nh * 64 * 4;
+  printf("%-28s B=%3d %3dx%-3d nh=%d p=%d,%d  max|err|=%.4g bad=%ld  %8.1f us  %6.0f GB/s  %s\n", c.name, B, c.H, c.W, nh, c.p0, c.p1, max_err, bad, us,
+         bytes / us * 1e-3, bad ? "FAIL" : "ok");
+  if (bad) ++g_fail;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // memory-path probes (what does a CU take in per clock, and what does a row-per-lane store pattern cost)
 __global__ __launch_bounds__(1024) void probe_glds(const char* src, int bytes_per_block, int iters, int* sink) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -392,6 +478,35 @@ int main(int argc, char** argv) {
       for (const auto& c : cw) run_gemm_case(c);
     }
     kd_set_option("wstat_waves", 0);
+  }
+  const AttnCase acs[] = {
+      {"attn global L2", 0, 32, 16, 16, 8, 0, 0},
+      {"attn global 49", 0, 4, 7, 7, 4, 0, 0},
+      {"attn global 64", 0, 64, 8, 8, 8, 0, 0},
+      {"attn global 100", 0, 3, 10, 10, 2, 0, 0},
+      {"attn global long 1024", 0, 4, 32, 32, 4, 0, 0},
+      {"attn global long 900", 0, 2, 30, 30, 2, 0, 0},
+      {"attn window L0 s0", 1, 32, 64, 64, 2, 8, 0},
+      {"attn window L0 s4", 1, 32, 64, 64, 2, 8, 4},
+      {"attn window L1 s4", 1, 32, 32, 32, 4, 8, 4},
+      {"attn window4 s2", 1, 2, 16, 24, 2, 4, 2},
+      {"attn window16 s8", 1, 2, 32, 48, 2, 16, 8},
+      {"attn na L0 k7", 2, 32, 64, 64, 2, 7, 0},
+      {"attn na L1 k7", 2, 32, 32, 32, 4, 7, 0},
+      {"attn na small k7", 2, 2, 9, 11, 2, 7, 0},
+      {"attn na odd k7", 2, 2, 21, 37, 2, 7, 0},
+      {"attn na k3", 2, 2, 20, 33, 2, 3, 0},
+      {"attn na k5", 2, 2, 20, 33, 2, 5, 0},
+      {"attn na k9", 2, 2, 20, 33, 2, 9, 0},
+  };
+  for (const auto& c : acs) run_attn_case(c);
+  if (want("attn global L2")) {
+    for (int qw : {2, 4}) {
+      kd_set_option("attn_global_qw", qw);
+      printf("-- attn_global_qw = %d\n", qw);
+      run_attn_case({"attn global L2", 0, 32, 16, 16, 8, 0, 0});
+    }
+    kd_set_option("attn_global_qw", 8);
   }
   printf("%s (%d failing case%s)\n", g_fail ? "HARNESS FAILED" : "HARNESS OK", g_fail, g_fail == 1 ? "" : "s");
   return g_fail ? 1 : 0;

@@ -159,6 +159,13 @@ int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, int W, int 
                      int prep, const float* scale_h, const float* cos_t, const float* sin_t, float eps,
                      void* stream);
 
+/* The three attention cores in bf16 arithmetic (KD_PREC_BF16): qkv is the bf16 output of kd_gemm_bf16's KD_EPI_QKV epilogue
+ * ([tokens, 3, nh, 64], q and k already prepared), out is bf16 [tokens, nh * 64].  bf16 MFMA products, fp32 scores / softmax /
+ * accumulators.  Same reference call sites as the fp32 entry points above; kd_attn_na2d_bf16 takes kernel sizes 3, 5, 7, 9. */
+int kd_attn_global_bf16(const void* qkv, void* out, int batch, int T, int nh, void* stream);
+int kd_attn_window_bf16(const void* qkv, void* out, int batch, int H, int W, int nh, int ws, int shift, void* stream);
+int kd_attn_na2d_bf16(const void* qkv, void* out, int batch, int H, int W, int nh, int ks, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Solver step arithmetic (k_diffusion/sampling.py), one fused elementwise launch per step with
  * host-precomputed fp32 coefficients.  Operation order follows the reference expression trees
