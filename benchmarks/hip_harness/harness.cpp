@@ -208,6 +208,97 @@ static void run_gemm_case(const GemmCase& c) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// patch-in (fp32 NCHW image -> bf16 tokens, * c_in) and patch-out (RMSNorm -> projection -> fp32 NCHW image, Karras c_out / c_skip)
+static void run_patch_case(const char* name, int B, int C, int gh, int gw, int ps, int width) {
+  if (!want(name)) return;
+  const int H = gh * ps, W = gw * ps, M = B * gh * gw, Kin = C * ps * ps;
+  auto img = randn((size_t)B * C * H * W, 3.0f);
+  std::vector<float> sigma(B);
+  for (auto& x : sigma) x = std::uniform_real_distribution<float>(0.05f, 20.f)(rng);
+  const float sd = 0.5f;
+  auto img_at = [&](int b, int c, int y, int x) { return img[(((size_t)b * C + c) * H + y) * W + x]; };
+  DevBuf<float> dImg(img.size()), dSig(B);
+  dImg.up(img); dSig.up(sigma);
+  long bad = 0; double max_err = 0;
+  // ---- patch in ----
+  {
+    auto W_f = randn((size_t)width * Kin, 1.0f / sqrtf((float)Kin));
+    DevBuf<float> dW(W_f.size());
+    dW.up(W_f);
+    DevBuf<char> dWp((size_t)kd_packed_weight_bytes_bf16(width, Kin, 0));
+    kd_pack_weight_bf16(dW.p, dWp.p, width, Kin, 0, nullptr);
+    DevBuf<uint16_t> dC((size_t)M * width);
+    KdGemm d; memset(&d, 0, sizeof(d));
+    d.M = M; d.N = width; d.K = Kin; d.a_mode = KD_A_PATCH_NCHW; d.epi = KD_EPI_STORE; d.gh = gh; d.gw = gw; d.ph = ps; d.pw = ps; d.chan = C;
+    d.sigma_data = sd; d.sigma = dSig.p; d.A = dImg.p; d.C = reinterpret_cast<float*>(dC.p); d.Wp = dWp.p; d.precision = KD_PREC_BF16; d.eps = 1e-6f;
+    if (int rc = kd_gemm_bf16(&d, nullptr)) { printf("%-28s patch-in REJECTED (%d): %s\n", name, rc, kd_last_error()); ++g_fail; return; }
+    HIPCHK(hipDeviceSynchronize());
+    auto C_h = dC.down();
+    std::uniform_int_distribution<int> rd(0, M - 1);
+    for (int s = 0; s < 200; ++s) {
+      const int m = s == 0 ? 0 : (s == 1 ? M - 1 : rd(rng));
+      const int b = m / (gh * gw), rr = m % (gh * gw), h = rr / gw, w = rr % gw;
+      const double cin = 1.0 / sqrt((double)sigma[b] * sigma[b] + (double)sd * sd);
+      for (int n = 0; n < width; ++n) {
+        double acc = 0;
+        for (int k = 0; k < Kin; ++k) {
+          const int c = k % C, q = k / C, nh = q / ps, nw = q % ps;
+          acc += (double)bf2f(f2bf((float)(img_at(b, c, h * ps + nh, w * ps + nw) * (float)cin))) * bf2f(f2bf(W_f[(size_t)n * Kin + k]));
+        }
+        const double err = fabs(bf2f(C_h[(size_t)m * width + n]) - acc);
+        if (!(err <= 0.012 * fabs(acc) + 0.02)) ++bad;
+        max_err = std::max(max_err, err == err ? err : 1e30);
+      }
+    }
+    const float us = time_us([&] { kd_gemm_bf16(&d, nullptr); });
+    printf("%-28s patch-in  M=%6d N=%4d K=%3d max|err|=%.4g bad=%ld %8.1f us %s\n", name, M, width, Kin, max_err, bad, us, bad ? "FAIL" : "ok");
+  }
+  // ---- patch out ----
+  {
+    const int N = Kin, K = width;
+    auto X_h = to_bf(randn((size_t)M * K));
+    auto W_f = randn((size_t)N * K, 1.0f / sqrtf((float)K));
+    std::vector<float> gain(K);
+    for (auto& x : gain) x = 1.0f + 0.2f * std::normal_distribution<float>(0, 1)(rng);
+    DevBuf<uint16_t> dX(X_h.size());
+    DevBuf<float> dW(W_f.size()), dG(K), dOut(img.size());
+    dX.up(X_h); dW.up(W_f); dG.up(gain);
+    DevBuf<char> dWp((size_t)kd_packed_weight_bytes_bf16(N, K, 0));
+    kd_pack_weight_bf16(dW.p, dWp.p, N, K, 0, nullptr);
+    KdGemm d; memset(&d, 0, sizeof(d));
+    d.M = M; d.N = N; d.K = K; d.a_mode = KD_A_PLAIN; d.epi = KD_EPI_UNPATCH_NCHW; d.gh = gh; d.gw = gw; d.ph = ps; d.pw = ps; d.chan = C;
+    d.norm = 1; d.scale = dG.p; d.scale_stride = 0; d.rows_per_sample = gh * gw; d.eps = 1e-6f;
+    d.sigma_data = sd; d.sigma = dSig.p; d.A = reinterpret_cast<const float*>(dX.p); d.C = dOut.p; d.R = dImg.p; d.Wp = dWp.p; d.precision = KD_PREC_BF16;
+    if (int rc = kd_gemm_bf16(&d, nullptr)) { printf("%-28s patch-out REJECTED (%d): %s\n", name, rc, kd_last_error()); ++g_fail; return; }
+    HIPCHK(hipDeviceSynchronize());
+    auto O_h = dOut.down();
+    std::uniform_int_distribution<int> rd(0, M - 1);
+    double max_err2 = 0;
+    for (int s = 0; s < 200; ++s) {
+      const int m = s == 0 ? 0 : (s == 1 ? M - 1 : rd(rng));
+      const int b = m / (gh * gw), rr = m % (gh * gw), h = rr / gw, w = rr % gw;
+      const double var = (double)sigma[b] * sigma[b] + (double)sd * sd, c_out = sigma[b] * sd / sqrt(var), c_skip = sd * sd / var;
+      double ssq = 0;
+      for (int k = 0; k < K; ++k) { const double x = bf2f(X_h[(size_t)m * K + k]); ssq += x * x; }
+      const double rs = 1.0 / sqrt(ssq / K + 1e-6);
+      for (int n = 0; n < N; ++n) {
+        double acc = 0;
+        for (int k = 0; k < K; ++k) acc += (double)bf2f(f2bf(bf2f(X_h[(size_t)m * K + k]) * gain[k])) * bf2f(f2bf(W_f[(size_t)n * K + k]));
+        const int c = n % C, q = n / C, nh = q / ps, nw = q % ps;
+        const size_t o = (((size_t)b * C + c) * H + h * ps + nh) * W + w * ps + nw;
+        const double ref = acc * rs * c_out + img[o] * c_skip;
+        const double err = fabs(O_h[o] - ref);
+        if (!(err <= 2e-3 * fabs(ref) + 2e-2)) ++bad;
+        max_err2 = std::max(max_err2, err == err ? err : 1e30);
+      }
+    }
+    const float us = time_us([&] { kd_gemm_bf16(&d, nullptr); });
+    printf("%-28s patch-out M=%6d N=%4d K=%3d max|err|=%.4g bad=%ld %8.1f us %s\n", name, M, N, K, max_err2, bad, us, bad ? "FAIL" : "ok");
+  }
+  if (bad) ++g_fail;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // attention cores: mode 0 global, 1 window (ws, shift), 2 neighbourhood (ks)
 struct AttnCase { const char* name; int mode, B, H, W, nh, p0, p1; };
 
@@ -478,6 +569,27 @@ int main(int argc, char** argv) {
       for (const auto& c : cw) run_gemm_case(c);
     }
     kd_set_option("wstat_waves", 0);
+  }
+  run_patch_case("generic patch flowers", 32, 3, 64, 64, 4, 128);
+  run_patch_case("generic patch mnist", 4, 1, 7, 7, 4, 256);
+  run_patch_case("generic patch cifar", 8, 3, 16, 16, 2, 256);
+  if (want("generic")) {      // the generic kernel on every mode it serves (fast kernels switched off)
+    kd_set_option("bf16_fast", 0);
+    const GemmCase cg[] = {
+        {"generic qkv", 8192, 768, 256, KD_EPI_QKV, 1, 1024, 4},
+        {"generic qkv mnist", 196, 768, 256, KD_EPI_QKV, 1, 49, 4},
+        {"generic geglu", 8192, 384, 128, KD_EPI_GEGLU, 1, 4096, 0},
+        {"generic geglu mnist", 196, 768, 256, KD_EPI_GEGLU, 1, 49, 0},
+        {"generic out+res", 8192, 128, 128, KD_EPI_RESIDUAL, 0, 4096, 0},
+        {"generic down+res mnist", 196, 256, 768, KD_EPI_RESIDUAL, 0, 49, 0},
+        {"generic store norm", 300, 96, 100, KD_EPI_STORE, 1, 50, 0},
+        {"generic store K=52", 260, 64, 52, KD_EPI_STORE, 0, 260, 0},
+        {"generic merge", 2048, 256, 512, KD_EPI_STORE, 0, 256, 0, KD_A_MERGE2x2, 16, 16},
+        {"generic merge small", 72, 64, 48, KD_EPI_STORE, 0, 36, 0, KD_A_MERGE2x2, 6, 6},
+        {"generic split", 2048, 512, 256, KD_EPI_SPLIT_LERP, 0, 256, 0, KD_A_PLAIN, 16, 16},
+    };
+    for (const auto& c : cg) run_gemm_case(c);
+    kd_set_option("bf16_fast", 1);
   }
   const AttnCase acs[] = {
       {"attn global L2", 0, 32, 16, 16, 8, 0, 0},

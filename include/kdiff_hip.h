@@ -33,8 +33,10 @@ int kd_version(void);
 const char* kd_last_error(void);
 /* Tuning / A-B switches of the library (benchmarks and tests; defaults are the shipped configuration).  The library reads no
  * environment variables: the Python package maps its documented KDIFF_* variables onto these calls.  Thread-safe.
- *   "skinny" (1) "astat" (1) "ksplit" (1) "astat_max_k" (512) "astat_waves" (4) "astat_storewait" (0)
- *   "wstat" (1) "wstat_waves" (0 = per shape) */
+ *   fp32 kernels : "skinny" (1) "astat" (1) "ksplit" (1) "astat_max_k" (512) "astat_waves" (4) "astat_storewait" (0)
+ *                  "gemm_debug" (0; profiling ablations of benchmarks/: 1 no C stores, 2 no MFMA, 8 GEGLU without erf)
+ *   bf16 kernels : "bf16_fast" (1; 0 = generic kernel only) "wstat" (1) "wstat_waves" (0 = per shape) "wstat_max_slices" (24)
+ *                  "astat_bf16" (1) "astat_splits" (0 = auto) "tiled_bm" (0 = auto, 128, 256) "attn_global_qw" (8) */
 int kd_set_option(const char* name, int value);
 int kd_get_option(const char* name, int dflt);
 
@@ -77,9 +79,6 @@ typedef struct {
   const float* fac;     /* split: device pointer to the lerp factor                               */
   int precision;        /* KD_PREC_*                                                              */
   const void* Wp;       /* KD_PREC_SPLIT3: packed split image of W from kd_pack_weight_bf16x3     */
-  int debug;            /* must be 0.  Profiling ablations (benchmarks/ only): 1 no C stores, 2 no MFMA,
-                           8 GEGLU without erf                                                    */
-  int scale_tab;        /* internal, overwritten by the library: norm scales staged in LDS        */
   int n_heads;          /* KD_EPI_QKV: N == 3 * n_heads * 64; token of row m = m % rows_per_sample   */
   const float* qk_scale;  /* KD_EPI_QKV: [n_heads] cosine-sim scale (self_attn.scale)                 */
   const float* rope_cos;  /* KD_EPI_QKV: [rows_per_sample, n_heads, 16] cos / sin of AxialRoPE theta  */
@@ -133,7 +132,9 @@ int kd_cond_sum_f32(float* out, const float* a, const float* b, int b_rows, cons
  *   0  q, k already prepared (by this call or by the KD_EPI_QKV epilogue), fp32
  *   1  raw fp32 q, k: prepared on the fly (needs scale_h, cos_t, sin_t)
  *   2  prepared AND stored split (KdGemm.qkv_packed: [hi: 4 x bf16][lo: 4 x bf16] per 4-column chunk): the split-bf16x3
- *      cores use the operands as stored; not available with KDIFF_GEMM=exact */
+ *      cores use the operands as stored; not available with KD_PREC_EXACT
+ * `precision` (KD_PREC_EXACT / KD_PREC_SPLIT3) selects the arithmetic of the two products, as in KdGemm; the neighbourhood
+ * core has the split-bf16x3 form only (the argument is accepted for symmetry). */
 int kd_qk_prep_f32(float* qkv, const float* scale_h, const float* cos_t, const float* sin_t,
                    int batch, int tokens_per_sample, int nh, float eps, void* stream);
 
@@ -143,21 +144,21 @@ int kd_qk_prep_f32(float* qkv, const float* scale_h, const float* cos_t, const f
  * image_transformer_v2.py:383,392.  out: [batch*T, nh*64]. */
 int kd_attn_global_f32(const float* qkv, float* out, int batch, int T, int nh,
                        int prep, const float* scale_h, const float* cos_t, const float* sin_t, float eps,
-                       void* stream);
+                       int precision, void* stream);
 
 /* Shifted-window attention (window ws x ws tokens, ws in {4, 8, 16}), roll/window/mask/unwindow
  * folded into addressing.  Replaces apply_window_attention image_transformer_v2.py:319-337
  * (+ :253-316).  shift is 0 or ws/2. */
 int kd_attn_window_f32(const float* qkv, float* out, int batch, int H, int W, int nh, int ws, int shift,
                        int prep, const float* scale_h, const float* cos_t, const float* sin_t, float eps,
-                       void* stream);
+                       int precision, void* stream);
 
 /* 2-D neighbourhood attention, kernel ks x ks (ks == 7), window clamped inside the image,
  * dilation 1, heads-last.  Replaces natten.functional.na2d(q,k,v,7,scale=1.0)
  * image_transformer_v2.py:428 (and the unfused pair :437-439). */
 int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, int W, int nh, int ks,
                      int prep, const float* scale_h, const float* cos_t, const float* sin_t, float eps,
-                     void* stream);
+                     int precision, void* stream);
 
 /* The three attention cores in bf16 arithmetic (KD_PREC_BF16): qkv is the bf16 output of kd_gemm_bf16's KD_EPI_QKV epilogue
  * ([tokens, 3, nh, 64], q and k already prepared), out is bf16 [tokens, nh * 64].  bf16 MFMA products, fp32 scores / softmax /

@@ -12,15 +12,25 @@ LIB_PATH = os.environ.get("KDIFF_HIP_LIB") or os.path.join(_HERE, "csrc", "libkd
 # enums (include/kdiff_hip.h)
 A_PLAIN, A_MERGE2x2, A_PATCH_NCHW = 0, 1, 2
 EPI_STORE, EPI_RESIDUAL, EPI_GEGLU, EPI_SPLIT_LERP, EPI_UNPATCH_NCHW, EPI_QKV = 0, 1, 2, 3, 4, 5
-PREC_EXACT, PREC_SPLIT3 = 0, 1
+PREC_EXACT, PREC_SPLIT3, PREC_BF16 = 0, 1, 2
+_MODES = {"exact": PREC_EXACT, "split3": PREC_SPLIT3, "bf16": PREC_BF16}
 
 
 def default_precision():
-    """GEMM arithmetic: KDIFF_GEMM=exact -> fp32 MFMA; split3 (default) -> 3x bf16 split products, fp32 accumulate."""
+    """Arithmetic mode of the network (KDIFF_GEMM):
+    exact   fp32-input MFMA, bit-for-bit an fmaf chain (fp32 activations);
+    split3  (default) every fp32 operand split into two bf16, 3 bf16 MFMAs per product, fp32 accumulate (fp32 activations):
+            the fp32-parity mode, inside the 1e-3 tolerance of the reference's fp32 path;
+    bf16    bf16 activations in HBM, one bf16 MFMA per product, fp32 accumulate / statistics / softmax: the arithmetic of the
+            reference under torch.autocast(bfloat16)."""
     mode = os.environ.get("KDIFF_GEMM", "split3").lower()
-    if mode not in ("exact", "split3"):
-        raise ValueError(f"KDIFF_GEMM={mode!r}: expected 'exact' or 'split3'")
-    return PREC_EXACT if mode == "exact" else PREC_SPLIT3
+    if mode not in _MODES:
+        raise ValueError(f"KDIFF_GEMM={mode!r}: expected one of {sorted(_MODES)}")
+    return _MODES[mode]
+
+
+def precision_name(p):
+    return {v: k for k, v in _MODES.items()}[p]
 (STEP_EULER, STEP_HEUN_PRED, STEP_HEUN_CORR, STEP_DPMPP_2M1, STEP_DPMPP_2M2, STEP_ADD_NOISE, STEP_LERP2, STEP_AXPY,
  STEP_EULER_FROM, STEP_AXPBY, STEP_ADD_DIFF, STEP_TO_D) = range(12)
 
@@ -34,9 +44,9 @@ class KdGemm(C.Structure):
         ("eps", C.c_float), ("out_add", C.c_float), ("sigma_data", C.c_float),
         ("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("R", C.c_void_p),
         ("scale", C.c_void_p), ("sigma", C.c_void_p), ("fac", C.c_void_p),
-        ("precision", C.c_int), ("Wp", C.c_void_p), ("debug", C.c_int), ("scale_tab", C.c_int),
+        ("precision", C.c_int), ("Wp", C.c_void_p),
         ("n_heads", C.c_int), ("qk_scale", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
-        ("qkv_packed", C.c_int),
+        ("qkv_packed", C.c_int), ("rope_pos", C.c_void_p), ("rope_freq", C.c_void_p),
     ]
 
 
@@ -46,7 +56,15 @@ _vp, _i, _f, _ll, _d = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_double
 SIGNATURES = {
     "kd_version": [],
     "kd_last_error": [],
+    "kd_set_option": [C.c_char_p, _i],
+    "kd_get_option": [C.c_char_p, _i],
     "kd_gemm_f32": [C.POINTER(KdGemm), _vp],
+    "kd_gemm_bf16": [C.POINTER(KdGemm), _vp],
+    "kd_packed_weight_bytes_bf16": [_i, _i, _i],
+    "kd_pack_weight_bf16": [_vp, _vp, _i, _i, _i, _vp],
+    "kd_attn_global_bf16": [_vp, _vp, _i, _i, _i, _vp],
+    "kd_attn_window_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "kd_attn_na2d_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "kd_packed_weight_bytes": [_i, _i, _i],
     "kd_pack_weight_bf16x3": [_vp, _vp, _i, _i, _i, _vp],
     "kd_rmsnorm_f32": [_vp, _vp, _vp, _i, _i, _f, _vp],
@@ -54,9 +72,9 @@ SIGNATURES = {
     "kd_fourier_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "kd_cond_sum_f32": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "kd_qk_prep_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
-    "kd_attn_global_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp],
-    "kd_attn_window_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp],
-    "kd_attn_na2d_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp],
+    "kd_attn_global_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _vp],
+    "kd_attn_window_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _vp],
+    "kd_attn_na2d_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _vp],
     "kd_sampler_step_f32": [_i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _ll, _vp],
     "kd_precond_in_f32": [_vp, _vp, _vp, _f, _i, _ll, _vp],
     "kd_precond_out_f32": [_vp, _vp, _vp, _vp, _f, _i, _ll, _vp],
@@ -99,9 +117,32 @@ def lib():
             except AttributeError as e:
                 raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.argtypes = argtypes
-            fn.restype = C.c_char_p if name == "kd_last_error" else (C.c_longlong if name == "kd_packed_weight_bytes" else C.c_int)
+            fn.restype = C.c_char_p if name == "kd_last_error" else (C.c_longlong if name.startswith("kd_packed_weight_bytes") else C.c_int)
         _lib = handle
+    _sync_options(_lib)
     return _lib
+
+
+# The library reads no environment variables; the package's documented A/B switches are mapped onto kd_set_option here
+# (re-read whenever they change, so that tests can flip them inside one process).
+_ENV_OPTIONS = {"KDIFF_SKINNY": ("skinny", 1), "KDIFF_ASTAT": ("astat", 1), "KDIFF_KSPLIT": ("ksplit", 1), "KDIFF_ASTAT_MAXK": ("astat_max_k", 512),
+                "KDIFF_ASTAT_WAVES": ("astat_waves", 4), "KDIFF_ASTAT_STOREWAIT": ("astat_storewait", 0), "KD_GEMM_DEBUG": ("gemm_debug", 0),
+                "KDIFF_BF16_FAST": ("bf16_fast", 1)}
+_env_applied = None
+
+
+def _sync_options(handle):
+    global _env_applied
+    cur = tuple(os.environ.get(k) for k in _ENV_OPTIONS)
+    if cur != _env_applied:
+        for (env, (name, dflt)), val in zip(_ENV_OPTIONS.items(), cur):
+            handle.kd_set_option(name.encode(), dflt if val is None or val == "" else int(val))
+        _env_applied = cur
+
+
+def set_option(name, value):
+    """Tuning / A-B switch of the library (include/kdiff_hip.h: kd_set_option)."""
+    check(lib().kd_set_option(name.encode(), int(value)), "kd_set_option")
 
 
 def check(code, what="libkdiff_hip"):

@@ -18,10 +18,8 @@
 // K and V tiles are staged once per (sample, head[, window]) in LDS with rows padded to 68 floats
 // (conflict-free ds_read_b128 for K fragments, ds_read_b32 for V^T fragments).
 //
-// The neighbourhood core is VALU + LDS: at fp32 the MFMA rate equals the VALU rate, and a dense
-// MFMA tiling of a 7x7 window wastes >55% of its work on masked keys.  Four lanes share a query
-// (16 head dims each, two DPP shuffles per score); the 14x14 key halo of an 8x8 query tile is staged
-// in LDS, K first, then V in the same buffer.
+// The neighbourhood core (and, with KD_PREC_SPLIT3, the global / window cores) run on the bf16 MFMA with the 3-term split
+// of every fp32 operand (hi*hi + hi*lo + lo*hi, fp32 accumulate): see attn_na2d_kernel / attn_global_split_kernel below.
 #include "kd_common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -1230,18 +1228,17 @@ extern "C" int kd_qk_prep_f32(float* qkv, const float* scale_h, const float* cos
 }
 
 extern "C" int kd_attn_global_f32(const float* qkv, float* out, int batch, int T, int nh, int prep, const float* scale_h,
-                                  const float* cos_t, const float* sin_t, float eps, void* stream) {
+                                  const float* cos_t, const float* sin_t, float eps, int precision, void* stream) {
   if (!qkv || !out || batch <= 0 || nh <= 0 || T <= 0) return fail(KD_EINVAL, "kd_attn_global_f32: bad arguments");
   if (int e = check_prep(prep, scale_h, cos_t, sin_t, "kd_attn_global_f32")) return e;
   DenseArgs a{qkv, out, scale_h, cos_t, sin_t, batch, T, nh, 0, 0, 0, 0, eps};
   const long nb = (long)batch * nh;
   hipStream_t s = (hipStream_t)stream;
-  // default: split-bf16x3 MFMA core (like the GEMMs); KDIFF_GEMM=exact keeps the exact-fp32 MFMA core
-  const char* mode = getenv("KDIFF_GEMM");                    // read per call (tests switch modes inside one process)
-  const bool exact = mode && !strcmp(mode, "exact");
-  if (exact && prep == 2) return fail(KD_EINVAL, "kd_attn_global_f32: split-stored qkv (prep = 2) is for the split-bf16x3 cores, not KDIFF_GEMM=exact");
+  if (precision != KD_PREC_EXACT && precision != KD_PREC_SPLIT3) return fail(KD_EINVAL, "kd_attn_global_f32: precision must be KD_PREC_EXACT or KD_PREC_SPLIT3");
+  const bool exact = precision == KD_PREC_EXACT;
+  if (exact && prep == 2) return fail(KD_EINVAL, "kd_attn_global_f32: split-stored qkv (prep = 2) is for the split-bf16x3 cores, not KD_PREC_EXACT");
   if (T > 256) {
-    if (exact) return fail(KD_EINVAL, "kd_attn_global_f32: T=%d > 256 tokens is served by the streaming split-bf16x3 core only (unset KDIFF_GEMM=exact)", T);
+    if (exact) return fail(KD_EINVAL, "kd_attn_global_f32: T=%d > 256 tokens is served by the streaming split-bf16x3 core only (KD_PREC_SPLIT3)", T);
     return launch_global_long(a, prep, s);
   }
   if (!exact) {
@@ -1255,7 +1252,7 @@ extern "C" int kd_attn_global_f32(const float* qkv, float* out, int batch, int T
 }
 
 extern "C" int kd_attn_window_f32(const float* qkv, float* out, int batch, int H, int W, int nh, int ws, int shift, int prep,
-                                  const float* scale_h, const float* cos_t, const float* sin_t, float eps, void* stream) {
+                                  const float* scale_h, const float* cos_t, const float* sin_t, float eps, int precision, void* stream) {
   if (!qkv || !out || batch <= 0 || nh <= 0 || H <= 0 || W <= 0) return fail(KD_EINVAL, "kd_attn_window_f32: bad arguments");
   if (ws != 4 && ws != 8 && ws != 16) return fail(KD_EINVAL, "kd_attn_window_f32: window_size %d unsupported (4, 8 or 16)", ws);
   if ((H % ws) || (W % ws)) return fail(KD_EINVAL, "kd_attn_window_f32: grid %dx%d not divisible by the window", H, W);
@@ -1263,21 +1260,22 @@ extern "C" int kd_attn_window_f32(const float* qkv, float* out, int batch, int H
   if (int e = check_prep(prep, scale_h, cos_t, sin_t, "kd_attn_window_f32")) return e;
   DenseArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H * W, nh, H, W, ws, shift, eps};
   const long nb = (long)batch * nh * (H / ws) * (W / ws);
-  const char* mode = getenv("KDIFF_GEMM");
+  if (precision != KD_PREC_EXACT && precision != KD_PREC_SPLIT3) return fail(KD_EINVAL, "kd_attn_window_f32: precision must be KD_PREC_EXACT or KD_PREC_SPLIT3");
   hipStream_t s = (hipStream_t)stream;
-  if (!(mode && !strcmp(mode, "exact"))) {
+  if (precision == KD_PREC_SPLIT3) {
     if (ws == 8) return launch_global_split<MODE_WINDOW, 2>(a, prep, nb, s);
     if (ws == 4) return launch_global_split<MODE_WINDOW4, 1>(a, prep, nb, s);
     return launch_global_split<MODE_WINDOW16, 8>(a, prep, nb, s);
   }
-  if (prep == 2) return fail(KD_EINVAL, "kd_attn_window_f32: split-stored qkv (prep = 2) is for the split-bf16x3 cores, not KDIFF_GEMM=exact");
+  if (prep == 2) return fail(KD_EINVAL, "kd_attn_window_f32: split-stored qkv (prep = 2) is for the split-bf16x3 cores, not KD_PREC_EXACT");
   if (ws == 8) return launch_dense<MODE_WINDOW, 2>(a, prep, nb, "attn_window_f32", s);
   if (ws == 4) return launch_dense<MODE_WINDOW4, 1>(a, prep, nb, "attn_window_f32", s);
   return launch_dense<MODE_WINDOW16, 8>(a, prep, nb, "attn_window_f32", s);
 }
 
 extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, int W, int nh, int ks, int prep,
-                                const float* scale_h, const float* cos_t, const float* sin_t, float eps, void* stream) {
+                                const float* scale_h, const float* cos_t, const float* sin_t, float eps, int precision, void* stream) {
+  (void)precision;
   if (!qkv || !out || batch <= 0 || nh <= 0) return fail(KD_EINVAL, "kd_attn_na2d_f32: bad arguments");
   if (ks != NA_K) return fail(KD_EINVAL, "kd_attn_na2d_f32: kernel_size %d unsupported (only 7)", ks);
   if (H < ks || W < ks) return fail(KD_EINVAL, "kd_attn_na2d_f32: grid %dx%d smaller than the %dx%d neighbourhood", H, W, ks, ks);

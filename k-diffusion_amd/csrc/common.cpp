@@ -24,13 +24,13 @@ bool prof_on() { return g_prof; }
 void prof_begin(const char* name, double flops, double bytes, hipStream_t s) {
   ProfRec r;
   r.name = name; r.flops = flops; r.bytes = bytes;
-  hipEventCreate(&r.e0);
-  hipEventCreate(&r.e1);
-  hipEventRecord(r.e0, s);
+  (void)hipEventCreate(&r.e0);
+  (void)hipEventCreate(&r.e1);
+  (void)hipEventRecord(r.e0, s);
   g_recs.push_back(r);
 }
 
-void prof_end(hipStream_t s) { hipEventRecord(g_recs.back().e1, s); }
+void prof_end(hipStream_t s) { (void)hipEventRecord(g_recs.back().e1, s); }
 
 }  // namespace kd
 
@@ -73,7 +73,7 @@ extern "C" int kd_prof_get(int i, char* name, int name_cap, float* ms, double* f
   return KD_OK;
 }
 extern "C" int kd_prof_reset(void) {
-  for (auto& r : g_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  for (auto& r : g_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   g_recs.clear();
   return KD_OK;
 }

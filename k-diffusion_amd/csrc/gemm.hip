@@ -87,7 +87,7 @@ __device__ __host__ __forceinline__ int w_row_of(int nt, int r, int N, bool gegl
 // does not even fill the chip once (level-2 out / down projections: 256 tiles, 16-48 K-steps each) this doubles the waves
 // per SIMD and halves the serial K walk, where splitting K over workgroups would need atomics or a second pass.
 template <int AMODE, bool NORM, int EPI, int PREC, int KS = 1>
-__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_kernel(const KdGemm p) {
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_kernel(const GemmP p) {
   constexpr bool SPLIT = PREC == KD_PREC_SPLIT3;
   static_assert(KS == 1 || (SPLIT && !NORM && AMODE == KD_A_PLAIN), "K split: split3, plain A, no norm prologue");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
 }
 
 template <int AMODE, bool NORM, int EPI, int PREC, int KS = 1>
-static int launch(const KdGemm& d, hipStream_t s) {
+static int launch(const GemmP& d, hipStream_t s) {
   constexpr size_t LDS_BASE = PREC == KD_PREC_SPLIT3 ? LDS_SPLIT + (KS - 1) * 2 * STAGE : LDS_EXACT;
   constexpr size_t LDS_BYTES = LDS_BASE + (NORM ? SCALE_TAB_MAX_K * sizeof(float) : 0);
   constexpr int NCOL = (EPI == KD_EPI_GEGLU) ? 64 : BN;
@@ -589,8 +589,8 @@ static int launch(const KdGemm& d, hipStream_t s) {
 
 }  // namespace kd
 
-namespace kd { int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc); }    // gemm_astat.hip
-namespace kd { int gemm_skinny_try(const KdGemm& d, hipStream_t s, int* rc); }   // gemm_skinny.hip
+namespace kd { int gemm_astat_try(const GemmP& d, hipStream_t s, int* rc); }    // gemm_astat.hip
+namespace kd { int gemm_skinny_try(const GemmP& d, hipStream_t s, int* rc); }   // gemm_skinny.hip
 
 using namespace kd;
 
@@ -613,18 +613,20 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
     return fail(KD_EINVAL, "kd_gemm_f32: qkv epilogue needs N == 3*n_heads*64, rows_per_sample, qk_scale, rope_cos, rope_sin");
   if (d.qkv_packed && (d.epi != KD_EPI_QKV || d.precision != KD_PREC_SPLIT3))
     return fail(KD_EINVAL, "kd_gemm_f32: qkv_packed needs the qkv epilogue and split3 precision");
-  KdGemm e = d;
+  GemmP e;
+  static_cast<KdGemm&>(e) = d;
+  e.debug = option("gemm_debug", 0);
   if (e.rows_per_sample <= 0) e.rows_per_sample = e.M;
   // all rows of a 128-row tile share their scale vector: stage it in LDS once per tile
   e.scale_tab = e.norm && e.a_mode == KD_A_PLAIN && e.K <= SCALE_TAB_MAX_K && (e.scale_stride == 0 || e.rows_per_sample % BM == 0);
 
   {
-    static const bool skinny_on = !(getenv("KDIFF_SKINNY") && getenv("KDIFF_SKINNY")[0] == '0');
+    const bool skinny_on = option("skinny", 1) != 0;
     int rc = 0;
     if (skinny_on && !gemm_skinny_try(e, s, &rc)) return rc;   // <= 128 rows (one per sample): the conditioning chain
   }
   {
-    static const bool astat_on = !(getenv("KDIFF_ASTAT") && getenv("KDIFF_ASTAT")[0] == '0');
+    const bool astat_on = option("astat", 1) != 0;
     int rc = 0;
     if (astat_on && !gemm_astat_try(e, s, &rc)) return rc;     // wide K <= 256 projections: A-stationary kernel
   }
@@ -633,7 +635,7 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
   {
     // residual / plain projections whose tiles do not even fill the chip once and that walk a long K: split K inside the
     // workgroup (two wave groups, deterministic in-LDS reduction)
-    static const bool ks_on = !(getenv("KDIFF_KSPLIT") && getenv("KDIFF_KSPLIT")[0] == '0');
+    const bool ks_on = option("ksplit", 1) != 0;
     const long tiles = (long)((e.M + BM - 1) / BM) * ((e.N + BN - 1) / BN);
     const int nk = (e.K + BK - 1) / BK;
     if (ks_on && e.precision == KD_PREC_SPLIT3 && e.Wp && e.a_mode == KD_A_PLAIN && !e.norm && !e.debug && tiles <= 256 && nk >= 8 && nk % 4 == 0) {

@@ -60,7 +60,7 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
 // bytes per flop of two co-resident 4-wave workgroups.  The vector-memory path delivers ~10-13 B/clk/CU even on L2 hits
 // (every tiled / streamed kernel here tops out there), so bytes per flop into the CU is what the main loop pays for.
 template <int NC, int EPI, int NWV>
-__global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_astat_kernel(const KdGemm p) {
+__global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_astat_kernel(const GemmP p) {
   constexpr int BMW = NWV * 32;                           // rows of this workgroup's panel
   constexpr int PCS = 4 * 4 / NWV;                        // 1 KiB pieces of a W stage moved by each wave (4 or 2)
   constexpr int K = NC * 16, NK = NC / 2;                 // NK: W stages per n-tile (multiple of NSTG)
@@ -126,22 +126,6 @@ __global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_
   float rsv[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) rsv[r] = rs_tab[wid * 32 + mfma32_row(r, lane)];
-#ifdef KD_PHASE
-#ifndef KD_PHASE_REPEAT
-#define KD_PHASE_REPEAT 1
-#endif
-  {   // timing experiment: de-phase the two co-resident workgroups of a CU (main loop of one over the epilogue of the other)
-#if KD_PHASE == 1
-    const unsigned odd = __builtin_amdgcn_s_getreg((11 << 11) | (0 << 6) | 6) != 0;          // LDS_ALLOC.base != 0: second workgroup on the CU
-#else
-    const unsigned odd = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 1;           // HW_ID.TG_ID parity
-#endif
-    if (odd) {
-#pragma unroll
-      for (int i = 0; i < KD_PHASE_REPEAT; ++i) __builtin_amdgcn_s_sleep(KD_PHASE_SLEEP);
-    }
-  }
-#endif
 
   f32x16 acc[4];
 #pragma unroll
@@ -193,11 +177,7 @@ __global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_
           const f32x2 rsh = rs2 * 0.5f;
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
-#ifdef KD_ABL_NOGELU
-            const f32x2 o = (f32x2{acc[2 * hh][r], acc[2 * hh][r + 1]} * rs2) * (f32x2{acc[2 * hh + 1][r], acc[2 * hh + 1][r + 1]} * rs2);
-#else
             const f32x2 o = geglu_pair(f32x2{acc[2 * hh][r], acc[2 * hh][r + 1]} * rsh, f32x2{acc[2 * hh + 1][r], acc[2 * hh + 1][r + 1]} * rs2);
-#endif
             strip[row8 * 64 + 32 * hh + l31] = o.x;
             strip[(row8 + 1) * 64 + 32 * hh + l31] = o.y;
           }
@@ -225,12 +205,7 @@ __global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_
           split4(v, hi, lo);
           v = f32x4{__uint_as_float(hi[0]), __uint_as_float(hi[1]), __uint_as_float(lo[0]), __uint_as_float(lo[1])};
         }
-#ifdef KD_ABL_NOSTORE
-        if (p.eps < 0.f) *reinterpret_cast<f32x4*>(p.C + (long)gm * N + gn) = v;     // never true
-        else asm volatile("" ::"v"(v));
-#else
         if (gm < M) *reinterpret_cast<f32x4*>(p.C + (long)gm * N + gn) = v;
-#endif
       }
     };
 #pragma unroll
@@ -246,7 +221,6 @@ __global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_
     for (int ks = 0; ks < NK; ++ks) {
       const int s = nt * NK + ks;
       // Stage s has landed?  Stages ks = 0, 1 of every tile but the first were confirmed before the previous epilogue.
-#ifndef KD_ABL_NOSYNC
       if (nt > 0 && ks == 2 && full_panel && NWV == 4) {
         // First counted wait after an epilogue.  vmcnt retires in issue order on gfx9-class hardware, loads and stores
         // alike, and this wave's queue now reads [stage s][NST epilogue stores][stage s+1][stage s+2]: allowing the
@@ -262,7 +236,6 @@ __global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_
         else { if (s + 2 < total) KD_WAIT_VM(4); else if (s + 1 < total) KD_WAIT_VM(2); else KD_WAIT_VM(0); }
       }
       KD_BARRIER();                      // every wave's quarter of stage s is in; everyone is done reading slot (s-1) % NSTG
-#endif
       if (s + 3 < total) issue(s + 3);   // refill the slot freed by stage s-1
       const char* st = ring + (ks % NSTG) * STAGE;
 #pragma unroll
@@ -272,34 +245,21 @@ __global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_
         bf16x8 bh[4], bl[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#ifdef KD_ABL_NOLDS
-          bh[j] = ah[(c + j) % NC]; bl[j] = al[(c + j) % NC];
-#else
           bh[j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 64 + o);
           bl[j] = *reinterpret_cast<const bf16x8*>(st + IMG + j * 32 * 64 + o);
-#endif
         }
-#ifdef KD_ABL_NOMFMA
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(bh[j]), "v"(bl[j]), "v"(ah[c]), "v"(al[c]));
-#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[c], bh[j], acc[j], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c], bl[j], acc[j], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[c], bh[j], acc[j], 0, 0, 0);
-#endif
       }
     }
     // stages (nt+1, ks = 0, 1) were requested >= 2 stages ago: confirm them now, before the stores of this epilogue
     // enter the vector-memory queue (outstanding after the last issue: stages s+1, s+2, s+3 -> leave only s+3)
     if (nt + 1 < n_tiles) { if (NWV == 4) KD_WAIT_VM(4); else KD_WAIT_VM(2); }
-#ifdef KD_ABL_NOEPI
-    if (p.eps < 0.f) epilogue(nt);       // never true: keeps the accumulators alive without the epilogue's cost
-#else
     epilogue(nt);
-#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -308,7 +268,7 @@ __global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_
 }
 
 template <int NC, int EPI, int NWV>
-static int launch(const KdGemm& d, hipStream_t s) {
+static int launch(const GemmP& d, hipStream_t s) {
   auto kern = gemm_astat_kernel<NC, EPI, NWV>;
   constexpr int LDS_BYTES = lds_bytes(NWV), BMW = NWV * 32;
   static bool attr_set = false;
@@ -324,9 +284,8 @@ static int launch(const KdGemm& d, hipStream_t s) {
   const int panels = (d.M + BMW - 1) / BMW, n_tiles = d.N / (EPI == KD_EPI_GEGLU ? 64 : 128);
   int splits = 1;
   while (panels * splits < 256 && n_tiles / (splits * 2) >= 2) splits *= 2;
-  KdGemm e = d;
-  static const bool conservative = getenv("KDIFF_ASTAT_STOREWAIT") && getenv("KDIFF_ASTAT_STOREWAIT")[0] == '1';
-  if (conservative) e.debug |= 32;
+  GemmP e = d;
+  if (option("astat_storewait", 0)) e.debug |= 32;
   hipLaunchKernelGGL(kern, dim3((unsigned)panels, (unsigned)splits), dim3(64 * NWV), LDS_BYTES, s, e);
   return check_launch("kd_gemm_f32(astat)");
 }
@@ -334,11 +293,11 @@ static int launch(const KdGemm& d, hipStream_t s) {
 }  // namespace astat
 
 // Eligibility + dispatch (called by kd_gemm_f32).  Returns 1 if the descriptor was not taken.
-int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
+int gemm_astat_try(const GemmP& d, hipStream_t s, int* rc) {
   using namespace astat;
   if (d.precision != KD_PREC_SPLIT3 || d.a_mode != KD_A_PLAIN || !d.norm || !d.Wp || (d.debug & ~32)) return 1;
   if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_QKV && d.epi != KD_EPI_GEGLU) return 1;
-  static const int max_k = getenv("KDIFF_ASTAT_MAXK") ? atoi(getenv("KDIFF_ASTAT_MAXK")) : 512;    // A/B switch for benchmarks/
+  const int max_k = option("astat_max_k", 512);    // A/B switch for benchmarks/
   if ((d.K != 128 && d.K != 256 && d.K != 512) || d.K > max_k) return 1;
   const int ncol = d.epi == KD_EPI_GEGLU ? 64 : 128;
   if (d.N % ncol || d.N / ncol < 2) return 1;                                   // one n-tile: nothing to amortise
@@ -349,8 +308,7 @@ int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
   // (K = 128) and the panel grid still fills the chip.  Measured neutral against two co-resident 4-wave workgroups
   // (level-0 qkv 59 -> 65 us, GEGLU 117 -> 114 us, end to end -0.4 %: profiles/r01_astat_ablation.md), so the 4-wave
   // form stays the default: halving the W bytes into the CU is not what the main loop waits for.
-  const char* mw = getenv("KDIFF_ASTAT_WAVES");             // read per call (tests switch it inside one process)
-  const int max_waves = mw ? atoi(mw) : 4;
+  const int max_waves = option("astat_waves", 4);
   const bool wide = max_waves >= 8 && d.K == 128 && d.M >= 256 * 2 * BM && (d.scale_stride == 0 || d.rows_per_sample % (2 * BM) == 0) &&
                     (d.epi != KD_EPI_QKV || d.rows_per_sample % (2 * BM) == 0);
 #define KD_AS(NCV, EP) if (d.K == NCV * 16 && d.epi == EP) { *rc = launch<NCV, EP, 4>(d, s); return 0; }

@@ -701,6 +701,284 @@ int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
   return 1;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// generic: every A gather (plain | 2x2 merge | NCHW patch of the fp32 image), optional norm prologue, every epilogue, ragged
+// M / N / K (K % 4 == 0).  128 x 128 tile, A register-staged (converted / scaled / zero-padded on its way into the swizzled LDS
+// image), the packed weight block by global_load_lds, one K step of 64 at a time.  The fallback for the shapes the three fast
+// kernels do not take (patch-in / patch-out, tiny models, odd sizes): correctness first, not tuned.
+__device__ __forceinline__ float karras_c_in(float sigma, float sd) { return 1.0f / sqrtf(sigma * sigma + sd * sd); }
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_generic_bf16_kernel(const KdGemm p) {
+  constexpr bool GEGLU = EPI == KD_EPI_GEGLU;
+  constexpr int NCOL = GEGLU ? 64 : 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Aimg = smem;
+  char* Wimg = smem + WBLK;
+  float* rs_tab = reinterpret_cast<float*>(smem + 2 * WBLK);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wc = wid & 1, wr = wid >> 1;
+  const int n_tiles = (p.N + NCOL - 1) / NCOL;
+  const int nt = blockIdx.x % n_tiles, mt = blockIdx.x / n_tiles;
+  const int m0 = mt * 128, n0 = nt * NCOL;
+  const int M = p.M, N = p.N, K = p.K, nk = (K + 63) / 64;
+  const u16* A16 = reinterpret_cast<const u16*>(p.A);
+
+  // staging coordinates: rows tid/8 + 32 j, 8-wide k chunk (tid & 7)
+  const int kq = tid & 7;
+  int a_b[4]; bool row_ok[4]; float a_cin[4]; long a_base[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int gm = m0 + (tid >> 3) + 32 * j;
+    row_ok[j] = gm < M;
+    const int gmc = row_ok[j] ? gm : M - 1;
+    if (AMODE == KD_A_PLAIN) {
+      a_b[j] = gmc / p.rows_per_sample;
+      a_base[j] = (long)gmc * K;
+      a_cin[j] = 1.f;
+    } else {
+      const int hw = p.gh * p.gw, b = gmc / hw, rr = gmc - b * hw, h = rr / p.gw, w = rr - h * p.gw;
+      a_b[j] = b;
+      if (AMODE == KD_A_MERGE2x2) {
+        a_base[j] = (((long)b * (2 * p.gh) + 2 * h) * (2 * p.gw) + 2 * w) * (K >> 2);
+        a_cin[j] = 1.f;
+      } else {
+        a_base[j] = (((long)b * p.chan) * (p.gh * p.ph) + h * p.ph) * (long)(p.gw * p.pw) + w * p.pw;
+        a_cin[j] = p.sigma ? karras_c_in(p.sigma[b], p.sigma_data) : 1.0f;
+      }
+    }
+  }
+  f32x4 ra[4][2];
+  float ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  auto load_regs = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int k4 = min(kt * 64 + kq * 8 + 4 * g, K - 4);          // clamped; zeroed at the store when out of range
+        f32x4 v;
+        if (AMODE == KD_A_PLAIN) {
+          const u32x2 w = *reinterpret_cast<const u32x2*>(A16 + a_base[j] + k4);
+          v = f32x4{bf_lo(w[0]), bf_hi(w[0]), bf_lo(w[1]), bf_hi(w[1])};
+        } else if (AMODE == KD_A_MERGE2x2) {
+          const int cin = K >> 2, qd = k4 / cin, e = k4 - qd * cin;
+          const u32x2 w = *reinterpret_cast<const u32x2*>(A16 + a_base[j] + ((long)(qd >> 1) * (2 * p.gw) + (qd & 1)) * cin + e);
+          v = f32x4{bf_lo(w[0]), bf_hi(w[0]), bf_lo(w[1]), bf_hi(w[1])};
+        } else {      // fp32 NCHW image: k = (nh * pw + nw) * chan + c
+          const long plane = (long)(p.gh * p.ph) * (p.gw * p.pw);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int k = k4 + u, c = k % p.chan, q = k / p.chan, nh_ = q / p.pw, nw = q - nh_ * p.pw;
+            v[u] = p.A[a_base[j] + c * plane + (long)nh_ * (p.gw * p.pw) + nw];
+          }
+        }
+        ra[j][g] = v;
+      }
+  };
+  auto store_regs = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned o[4];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int k4r = kt * 64 + kq * 8 + 4 * g;
+        const int k4 = min(k4r, K - 4);
+        f32x4 v = (row_ok[j] && k4r < K) ? ra[j][g] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (AMODE == KD_A_PATCH_NCHW) v = v * a_cin[j];
+        if (p.norm) {
+          ssq[j] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+          v = v * *reinterpret_cast<const f32x4*>(p.scale + (long)a_b[j] * p.scale_stride + k4);
+        }
+        o[2 * g] = pack_bf16(v[0], v[1]);
+        o[2 * g + 1] = pack_bf16(v[2], v[3]);
+      }
+      *reinterpret_cast<u32x4*>(Aimg + swz128((tid >> 3) + 32 * j, kq)) = u32x4{o[0], o[1], o[2], o[3]};
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int off4[4];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) off4[cc] = swz128(l31, 2 * cc + lh);
+  const char* wsrc = reinterpret_cast<const char*>(p.Wp) + (size_t)nt * nk * WBLK + wid * 4096 + lane * 16;
+
+  load_regs(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();                                 // the previous step's fragment reads are done
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)kt * WBLK + j * 1024),
+                                       (__attribute__((address_space(3))) void*)(Wimg + wid * 4096 + j * 1024), 16, 0, 0);
+    store_regs(kt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) load_regs(kt + 1);
+    const char* ab = Aimg + (wr * 64) * 128;
+    const char* wb = Wimg + (wc * 64) * 128;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      bf16x8 af[2], wf[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        af[u] = *reinterpret_cast<const bf16x8*>(ab + u * 32 * 128 + off4[cc]);
+        wf[u] = *reinterpret_cast<const bf16x8*>(wb + u * 32 * 128 + off4[cc]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  if (p.norm) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sm = wave_sum_xor(ssq[j], 8);
+      if (kq == 0) rs_tab[(tid >> 3) + 32 * j] = rsqrtf(sm / (float)K + p.eps);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: lane owns rows m0 + 64 wr + 32 j + l31 ------------------------------------------------------------------------
+  const float fac = EPI == KD_EPI_SPLIT_LERP ? *p.fac : 0.f;
+  u16* C16 = reinterpret_cast<u16*>(p.C);
+  const u16* R16 = reinterpret_cast<const u16*>(p.R);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rt = wr * 64 + 32 * j + l31, gm = m0 + rt;
+    const bool ok = gm < M;
+    const int gmc = ok ? gm : M - 1;
+    const float rs = p.norm ? rs_tab[rt] : 1.0f;
+    if (GEGLU) {
+      float v[16];
+      const float rsh = 0.5f * rs;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 o = geglu_pair(f32x2{acc[0][j][r], acc[0][j][r + 1]} * rsh, f32x2{acc[1][j][r], acc[1][j][r + 1]} * rs);
+        v[r] = o.x;
+        v[r + 1] = o.y;
+      }
+      const int nb = n0 + 32 * wc;
+      store_block_bf16(C16 + (size_t)gmc * N + min(nb, N - 32), v, lh, ok && nb < N);
+    } else if (EPI == KD_EPI_QKV) {
+      const int vec = (n0 >> 6) + wc;
+      if (vec * 64 < N) {
+        const int which = vec / p.n_heads, head = vec - which * p.n_heads;
+        if (which < 2) {
+          const int tok = gmc % p.rows_per_sample;
+          float fr[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) fr[u] = lh ? p.rope_freq[head * 8 + 4 + u] : p.rope_freq[head * 8 + u];
+          qk_prep_blocks(acc[0][j], acc[1][j], rs, sqrtf(p.qk_scale[head]), p.eps, p.rope_pos[2 * tok], p.rope_pos[2 * tok + 1], fr);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc[0][j][r] *= rs; acc[1][j][r] *= rs; }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+          store_block_bf16(C16 + (size_t)gmc * N + vec * 64 + 32 * i, v, lh, ok);
+        }
+      }
+    } else if (EPI == KD_EPI_UNPATCH_NCHW) {
+      // fp32 image out (+ Karras c_out / c_skip against the fp32 input image), element by element: n = (nh * pw + nw) * chan + c
+      const int hw = p.gh * p.gw, b = gmc / hw, rr = gmc - b * hw, h = rr / p.gw, w = rr - h * p.gw;
+      float c_out = 1.f, c_skip = 0.f;
+      if (p.sigma) {
+        const float sg = p.sigma[b], sd = p.sigma_data, var = sg * sg + sd * sd;
+        c_out = sg * sd / sqrtf(var);
+        c_skip = sd * sd / var;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + wc * 64 + 32 * i + mfma32_row(r, lane);
+          if (ok && n < N) {
+            const int c = n % p.chan, q = n / p.chan, nh_ = q / p.pw, nw = q - nh_ * p.pw;
+            const long o = (((long)b * p.chan + c) * (p.gh * p.ph) + h * p.ph + nh_) * (long)(p.gw * p.pw) + w * p.pw + nw;
+            float v = acc[i][j][r] * rs;
+            if (p.sigma) v = v * c_out + p.R[o] * c_skip;
+            p.C[o] = v;
+          }
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int nb = n0 + wc * 64 + 32 * i, nbc = min(nb, N - 32);
+        size_t off;
+        if (EPI == KD_EPI_SPLIT_LERP) {
+          const int hw = p.gh * p.gw, cout = N >> 2;
+          const int b = gmc / hw, rr = gmc - b * hw, h = rr / p.gw, w = rr - h * p.gw;
+          const int qd = nbc / cout, e = nbc - qd * cout;
+          off = (((size_t)b * (2 * p.gh) + 2 * h + (qd >> 1)) * (2 * p.gw) + 2 * w + (qd & 1)) * cout + e;
+        } else {
+          off = (size_t)gmc * N + nbc;
+        }
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] * rs;
+        if (EPI == KD_EPI_RESIDUAL || EPI == KD_EPI_SPLIT_LERP) {
+          float rr_[16];
+          load_block_bf16(R16 + off, rr_, lh);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (EPI == KD_EPI_RESIDUAL) {
+              v[r] += rr_[r];
+            } else {
+              const float skip = rr_[r], diff = v[r] - skip;
+              v[r] = (fabsf(fac) < 0.5f) ? skip + fac * diff : v[r] - diff * (1.0f - fac);
+            }
+          }
+        }
+        store_block_bf16(C16 + off, v, lh, ok && nb < N);
+      }
+    }
+  }
+}
+
+template <int AMODE, int EPI>
+static int launch_generic(const KdGemm& d, hipStream_t s) {
+  auto kern = gemm_generic_bf16_kernel<AMODE, EPI>;
+  constexpr int LDS = 2 * WBLK + 128 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  constexpr int NCOL = EPI == KD_EPI_GEGLU ? 64 : 128;
+  const long tiles = (long)((d.M + 127) / 128) * ((d.N + NCOL - 1) / NCOL);
+  const double n_eff = EPI == KD_EPI_GEGLU ? 2.0 * d.N : (double)d.N;
+  char nm[96] = "gemm_generic";
+  if (prof_on()) snprintf(nm, sizeof(nm), "gemm_bf16_generic<a%d,e%d> M=%d N=%d K=%d", AMODE, EPI, d.M, d.N, d.K);
+  const double a_bytes = (AMODE == KD_A_PATCH_NCHW ? 4.0 : 2.0) * d.M * d.K;
+  const double c_bytes = (EPI == KD_EPI_UNPATCH_NCHW ? (d.sigma ? 8.0 : 4.0) : (EPI == KD_EPI_RESIDUAL || EPI == KD_EPI_SPLIT_LERP ? 4.0 : 2.0)) * d.M * d.N;
+  LaunchScope prof(nm, 2.0 * d.M * n_eff * d.K, a_bytes + 2.0 * n_eff * d.K + c_bytes, s);
+  KdGemm e = d;
+  if (e.rows_per_sample <= 0) e.rows_per_sample = e.M;
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), LDS, s, e);
+  return check_launch("kd_gemm_bf16(generic)");
+}
+
+int gemm_generic_try(const KdGemm& d, hipStream_t s, int* rc) {
+  if (d.epi != KD_EPI_UNPATCH_NCHW && (d.N & 31)) return 1;
+  if (d.epi == KD_EPI_STORE && d.out_add != 0.f) return 1;
+  if (d.a_mode == KD_A_MERGE2x2 && ((d.K >> 2) & 3)) return 1;
+#define KD_GN(AM, EP) if (d.a_mode == AM && d.epi == EP) { *rc = launch_generic<AM, EP>(d, s); return 0; }
+  KD_GN(KD_A_PLAIN, KD_EPI_STORE) KD_GN(KD_A_PLAIN, KD_EPI_RESIDUAL) KD_GN(KD_A_PLAIN, KD_EPI_GEGLU) KD_GN(KD_A_PLAIN, KD_EPI_QKV)
+  KD_GN(KD_A_PLAIN, KD_EPI_SPLIT_LERP) KD_GN(KD_A_PLAIN, KD_EPI_UNPATCH_NCHW)
+  KD_GN(KD_A_MERGE2x2, KD_EPI_STORE) KD_GN(KD_A_PATCH_NCHW, KD_EPI_STORE)
+#undef KD_GN
+  return 1;
+}
+
 // ---- one-off weight packing -------------------------------------------------------------------------------------------
 // one thread per (block, row, 16-byte chunk)
 __global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* __restrict__ W, char* __restrict__ out, int N, int K, int geglu,
@@ -758,10 +1036,15 @@ extern "C" int kd_gemm_bf16(const KdGemm* dp, void* stream) {
   int rc = 0;
   // shape-driven choice (benchmarks/hip_harness, profiles/r02_*): level-0 shapes (K = 128, and K = 384 with N = 128) park the
   // weight; norm projections at K = 256 / 512 keep A in registers and stream the weight; the rest is tiled
+  if (!option("bf16_fast", 1)) {
+    if (!b16::gemm_generic_try(d, s, &rc)) return rc;
+    return fail(KD_EINVAL, "kd_gemm_bf16: no generic kernel for a_mode=%d epi=%d N=%d", d.a_mode, d.epi, d.N);
+  }
   const bool small_k = d.K == 128 || (d.K == 384 && d.N <= 128);
   if (small_k && !b16::gemm_wstat_try(d, s, &rc)) return rc;
   if (!b16::gemm_astat_try(d, s, &rc)) return rc;
   if (!b16::gemm_tiled_try(d, s, &rc)) return rc;
   if (!b16::gemm_wstat_try(d, s, &rc)) return rc;
+  if (!b16::gemm_generic_try(d, s, &rc)) return rc;
   return fail(KD_EINVAL, "kd_gemm_bf16: unsupported combination a_mode=%d norm=%d epi=%d M=%d N=%d K=%d", d.a_mode, d.norm, d.epi, d.M, d.N, d.K);
 }

@@ -96,7 +96,7 @@ static int launch(const KdGemm& d, hipStream_t s) {
 }  // namespace skinny
 
 // returns 0 when the descriptor was served here (*rc = launch status), 1 when it is not eligible
-int gemm_skinny_try(const KdGemm& d, hipStream_t s, int* rc) {
+int gemm_skinny_try(const GemmP& d, hipStream_t s, int* rc) {
   using namespace skinny;
   if (d.M > 2 * ROWS || d.a_mode != KD_A_PLAIN || !d.W || d.debug) return 1;
   if (d.norm && d.scale_stride != 0) return 1;            // per-sample scale vectors: not the conditioning chain's case

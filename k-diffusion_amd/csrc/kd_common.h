@@ -16,6 +16,12 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int WAVE = 64;
 
+// the public descriptor plus what only the library sets (kept out of the ABI)
+struct GemmP : KdGemm {
+  int debug;        // benchmarks/ only (kd_set_option("gemm_debug")): 1 no C stores, 2 no MFMA, 8 GEGLU without erf, 32 conservative store wait
+  int scale_tab;    // norm scales of a tile's sample staged in LDS
+};
+
 // ---- error reporting (thread-local message, C ABI returns a code) -------------------------------
 char* err_buf();
 int fail(int code, const char* fmt, ...);

@@ -145,9 +145,12 @@ class _Plan:
         lib = nat.lib()
         m = model
         precision = nat.default_precision()
+        bf = precision == nat.PREC_BF16
+        cond_precision = nat.PREC_SPLIT3 if bf else precision      # the per-sample conditioning chain stays fp32 in every mode
         self.keep = []           # descriptors and tensors that must outlive the plan
         self.launches = []
         f32 = dict(device=device, dtype=torch.float32)
+        act = dict(device=device, dtype=torch.bfloat16 if bf else torch.float32)   # residual stream, qkv, attention out, FF hidden
         ph, pw = m.patch_size
         if H % ph or W % pw:
             raise ValueError(f"input {H}x{W} not divisible by the patch size {ph}x{pw}")
@@ -170,11 +173,11 @@ class _Plan:
         self.class_ids = torch.zeros(B, device=device, dtype=torch.int64)
         self.aug_in = torch.zeros(B, 9, **f32) if has_aug else None
         self.map_in = torch.zeros(B, m.mapping_cond_dim, **f32) if has_mapping_cond else None
-        xs = [torch.empty(B, gh, gw, lv.width, **f32) for (gh, gw), lv in zip(grids, levels)]
+        xs = [torch.empty(B, gh, gw, lv.width, **act) for (gh, gw), lv in zip(grids, levels)]
         toks = [B * gh * gw for gh, gw in grids]
-        qkv = torch.empty(max(t * 3 * lv.width for t, lv in zip(toks, levels)), **f32)
-        att = torch.empty(max(t * lv.width for t, lv in zip(toks, levels)), **f32)
-        hid = torch.empty(max(t * lv.d_ff for t, lv in zip(toks, levels)), **f32)
+        qkv = torch.empty(max(t * 3 * lv.width for t, lv in zip(toks, levels)), **act)
+        att = torch.empty(max(t * lv.width for t, lv in zip(toks, levels)), **act)
+        hid = torch.empty(max(t * lv.d_ff for t, lv in zip(toks, levels)), **act)
         ff, temb, emb, mres, cond = (torch.empty(B, mw, **f32) for _ in range(5))
         mh = torch.empty(B, mdff, **f32)
         norm_mods = m._ada_norm_modules()
@@ -197,8 +200,11 @@ class _Plan:
                  rows_per_sample=0, R=None, grid=(0, 0), patch=(0, 0, 0), out_add=0.0, sigma=None, fac=None, qk=None):
             d = nat.KdGemm()
             d.M, d.N, d.K, d.a_mode, d.epi = M, N, K, a_mode, epi
-            d.precision = precision
-            if precision == nat.PREC_SPLIT3:
+            main = target is self.launches
+            d.precision = precision if main else cond_precision
+            if d.precision == nat.PREC_BF16:
+                d.Wp = m._packed_image(Wt, N, K, epi == nat.EPI_GEGLU, bf16=True).data_ptr()
+            elif d.precision == nat.PREC_SPLIT3:
                 d.Wp = m._packed_image(Wt, N, K, epi == nat.EPI_GEGLU).data_ptr()
             d.norm = 1 if scale_ptr is not None else 0
             d.rows_per_sample, d.scale_stride = rows_per_sample, scale_stride
@@ -213,10 +219,12 @@ class _Plan:
                 self.norm_descs.append((d, scale_ptr[1]))
             d.sigma = None if sigma is None else sigma.data_ptr()
             d.fac = None if fac is None else fac.data_ptr()
-            if qk is not None:
+            if qk is not None and d.precision == nat.PREC_BF16:      # (scale_h, rope_pos, rope_freq, nh)
+                d.qk_scale, d.rope_pos, d.rope_freq, d.n_heads = qk[0].data_ptr(), qk[1].data_ptr(), qk[2].data_ptr(), qk[3]
+            elif qk is not None:
                 d.qk_scale, d.rope_cos, d.rope_sin, d.n_heads = qk[0].data_ptr(), qk[1].data_ptr(), qk[2].data_ptr(), qk[3]
             self.keep.append(d)
-            target.append(_Launch(lib.kd_gemm_f32, (C.byref(d),), what))
+            target.append(_Launch(lib.kd_gemm_bf16 if d.precision == nat.PREC_BF16 else lib.kd_gemm_f32, (C.byref(d),), what))
             return d
 
         def call(what, fn, *args):
@@ -275,7 +283,12 @@ class _Plan:
             if hasattr(mod, "self_attn"):
                 sa, spec = mod.self_attn, lv.self_attn
                 nh = d // spec.d_head
-                cos_t, sin_t = m._rope_tables(li, grids, sa, device)
+                if bf:
+                    # bf16 mode: the qkv epilogue evaluates the RoPE angles itself (hardware sin / cos) from the token's axial
+                    # position and the head's frequencies in revolutions -- two tiny tables instead of cos / sin per (token, head)
+                    cos_t, sin_t = m._rope_pos_freq(li, grids, sa, device)
+                else:
+                    cos_t, sin_t = m._rope_tables(li, grids, sa, device)
                 self.keep += [cos_t, sin_t]
                 # q, k leave the qkv GEMM already prepared (cosine-sim scale + RoPE in its epilogue): every halo /
                 # window / key tile of the attention cores would otherwise redo that work per use
@@ -285,13 +298,21 @@ class _Plan:
                           scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps,
                           qk=(sa.scale, cos_t, sin_t, nh))
                 dq.qkv_packed = 1 if packed_qkv else 0
-                prep = (2 if packed_qkv else 0, None, None, None, C.c_float(1e-6))
-                if isinstance(spec, GlobalAttentionSpec):
+                prep = (2 if packed_qkv else 0, None, None, None, C.c_float(1e-6), precision)
+                shift = 0
+                if isinstance(spec, ShiftedWindowAttentionSpec):
+                    shift = spec.window_size // 2 if index % 2 == 1 else 0          # :523
+                if bf and isinstance(spec, GlobalAttentionSpec):
+                    call(prefix + "attn_global", lib.kd_attn_global_bf16, _ptr(qkv), _ptr(att), B, gh * gw, nh)
+                elif bf and isinstance(spec, NeighborhoodAttentionSpec):
+                    call(prefix + "attn_na2d", lib.kd_attn_na2d_bf16, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.kernel_size)
+                elif bf:
+                    call(prefix + "attn_window", lib.kd_attn_window_bf16, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.window_size, shift)
+                elif isinstance(spec, GlobalAttentionSpec):
                     call(prefix + "attn_global", lib.kd_attn_global_f32, _ptr(qkv), _ptr(att), B, gh * gw, nh, *prep)
                 elif isinstance(spec, NeighborhoodAttentionSpec):
                     call(prefix + "attn_na2d", lib.kd_attn_na2d_f32, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.kernel_size, *prep)
                 else:
-                    shift = spec.window_size // 2 if index % 2 == 1 else 0          # :523
                     call(prefix + "attn_window", lib.kd_attn_window_f32, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.window_size, shift, *prep)
                 gemm(prefix + "out_proj", att, sa.out_proj.weight, x, T, d, d, epi=nat.EPI_RESIDUAL, R=x)
             gemm(prefix + "up_proj", x, mod.ff.up_proj.weight, hid, T, lv.d_ff, d, epi=nat.EPI_GEGLU,
@@ -416,14 +437,23 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         cos_t, sin_t = axial_rope.rope_tables(pos, sa.pos_emb.freqs)
         return cos_t.to(device), sin_t.to(device)
 
-    def _packed_image(self, W, N, K, geglu):
-        """Packed split-bf16 image of a weight, shared by all plans of this model.  The entry keeps the source tensor
-        alive, so its address cannot be recycled under the cached image; the dict is dropped with the plans whenever
-        the weights change (``_weights_fingerprint``)."""
-        key = (id(W), N, K, bool(geglu))
+    def _rope_pos_freq(self, li, grids, sa, device):
+        """bf16 mode: ([tokens, 2] axial positions (y, x) of the level's grid, [nh, 8] frequencies in revolutions)."""
+        h0, w0 = grids[0]
+        pos = axial_rope.make_axial_pos(h0, w0).view(h0, w0, 2)
+        for _ in range(li):
+            pos = axial_rope.downscale_pos(pos)
+        freq = sa.pos_emb.freqs.detach().to(torch.float32).cpu() / (2.0 * math.pi)
+        return pos.reshape(-1, 2).to(torch.float32).contiguous().to(device), freq.contiguous().to(device)
+
+    def _packed_image(self, W, N, K, geglu, bf16=False):
+        """Packed image of a weight (split-bf16, or plain bf16 for the bf16 mode), shared by all plans of this model.  The
+        entry keeps the source tensor alive, so its address cannot be recycled under the cached image; the dict is dropped
+        with the plans whenever the weights change (``_weights_fingerprint``)."""
+        key = (id(W), N, K, bool(geglu), bool(bf16))
         ent = self._packed.get(key)
         if ent is None:
-            ent = self._packed[key] = (W, ops.pack_weight(W, N, K, geglu, cache=False))
+            ent = self._packed[key] = (W, ops.pack_weight(W, N, K, geglu, cache=False, bf16=bf16))
         return ent[1]
 
     def _weights_fingerprint(self):

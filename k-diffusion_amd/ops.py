@@ -1,8 +1,9 @@
 """Tensor-level wrappers over the C ABI (include/kdiff_hip.h).
 
 PyTorch is plumbing here: it owns device memory and the stream; every computation below is a HIP
-kernel from libkdiff_hip.so launched on ``torch.cuda.current_stream()``.  Tensors must be fp32,
-contiguous and on a ROCm device -- anything else raises (there is no eager fallback).
+kernel from libkdiff_hip.so launched on ``torch.cuda.current_stream()``.  Tensors must be contiguous,
+on a ROCm device and fp32 -- or, for the activation tensors of the bf16 arithmetic mode (``precision=PREC_BF16`` /
+``KDIFF_GEMM=bf16``), bf16 -- anything else raises (there is no eager fallback).
 
 The op names mirror the reference functions they replace
 (k_diffusion/models/image_transformer_v2.py): ``rms_norm`` (:98), ``linear_geglu`` (:89),
@@ -42,14 +43,13 @@ def _p(t):
 
 
 _packed = {}
-_GEMM_DEBUG = int(os.environ.get("KD_GEMM_DEBUG", "0"))      # profiling ablations, benchmarks/ only
 
 
-def pack_weight(W, N, K, geglu, cache=True):
-    """Packed split-bf16 image of a weight for KD_PREC_SPLIT3 (uint8 tensor).  Weights are static while sampling, so
-    the image is cached per tensor OBJECT (weak reference + version counter: a new tensor that happens to reuse the
-    address of a freed one never hits a stale image)."""
-    key = id(W)
+def pack_weight(W, N, K, geglu, cache=True, bf16=False):
+    """Packed image of a weight (uint8 tensor): the split-bf16 image of KD_PREC_SPLIT3, or with ``bf16=True`` the plain bf16
+    image of KD_PREC_BF16.  Weights are static while sampling, so the image is cached per tensor OBJECT (weak reference +
+    version counter: a new tensor that happens to reuse the address of a freed one never hits a stale image)."""
+    key = (id(W), bool(bf16))
     ent = _packed.get(key) if cache else None
     if ent is not None:
         ref, version, meta, img = ent
@@ -57,8 +57,12 @@ def pack_weight(W, N, K, geglu, cache=True):
             return img
     _chk(W, "W")
     lib = nat.lib()
-    img = torch.empty(lib.kd_packed_weight_bytes(N, K, int(geglu)), device=W.device, dtype=torch.uint8)
-    nat.check(lib.kd_pack_weight_bf16x3(_p(W), _p(img), N, K, int(geglu), _stream()), "kd_pack_weight_bf16x3")
+    if bf16:
+        img = torch.empty(lib.kd_packed_weight_bytes_bf16(N, K, int(geglu)), device=W.device, dtype=torch.uint8)
+        nat.check(lib.kd_pack_weight_bf16(_p(W), _p(img), N, K, int(geglu), _stream()), "kd_pack_weight_bf16")
+    else:
+        img = torch.empty(lib.kd_packed_weight_bytes(N, K, int(geglu)), device=W.device, dtype=torch.uint8)
+        nat.check(lib.kd_pack_weight_bf16x3(_p(W), _p(img), N, K, int(geglu), _stream()), "kd_pack_weight_bf16x3")
     if cache:
         if len(_packed) > 512:
             for k in [k for k, e in _packed.items() if e[0]() is None]:
@@ -74,11 +78,17 @@ def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scal
          sigma=None, sigma_data=1.0, fac=None, scale_ptr=None, precision=None, qk=None, qkv_packed=False):
     """Fused GEMM (see KdGemm in include/kdiff_hip.h).  ``norm_scale`` may be a tensor or, with
     ``scale_ptr``, a raw device address inside a larger scale table.  ``precision``: nat.PREC_EXACT /
-    nat.PREC_SPLIT3 (default: KDIFF_GEMM env, split3)."""
+    nat.PREC_SPLIT3 / nat.PREC_BF16 (default: KDIFF_GEMM env, split3).  In bf16 mode A, out and residual are bf16 tensors
+    (except the fp32 image side of the patch modes) and ``qk`` = (scale_h, rope_pos [T, 2], rope_freq [nh, 8], nh)."""
     d = nat.KdGemm()
     d.precision = nat.default_precision() if precision is None else precision
-    d.debug = _GEMM_DEBUG
-    if d.precision == nat.PREC_SPLIT3:
+    bf = d.precision == nat.PREC_BF16
+    act = torch.bfloat16 if bf else torch.float32
+    a_dt = torch.float32 if a_mode == nat.A_PATCH_NCHW else act
+    c_dt = torch.float32 if epi == nat.EPI_UNPATCH_NCHW else act
+    if bf:
+        d.Wp = pack_weight(W, N, K, epi == nat.EPI_GEGLU, bf16=True).data_ptr()
+    elif d.precision == nat.PREC_SPLIT3:
         d.Wp = pack_weight(W, N, K, epi == nat.EPI_GEGLU).data_ptr()
     d.M, d.N, d.K = M, N, K
     d.a_mode, d.epi = a_mode, epi
@@ -87,17 +97,31 @@ def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scal
     d.gh, d.gw = grid
     d.ph, d.pw, d.chan = patch
     d.eps, d.out_add, d.sigma_data = eps, out_add, sigma_data
-    d.A, d.W, d.C = _chk(A, "A").data_ptr(), _chk(W, "W").data_ptr(), _chk(out, "C").data_ptr()
-    d.R = None if residual is None else _chk(residual, "R").data_ptr()
+    d.A, d.W, d.C = _chk(A, "A", a_dt).data_ptr(), _chk(W, "W").data_ptr(), _chk(out, "C", c_dt).data_ptr()
+    d.R = None if residual is None else _chk(residual, "R", c_dt).data_ptr()
     d.scale = scale_ptr if scale_ptr is not None else (None if norm_scale is None else _chk(norm_scale, "scale").data_ptr())
     d.sigma = None if sigma is None else _chk(sigma, "sigma").data_ptr()
     d.fac = None if fac is None else _chk(fac, "fac").data_ptr()
-    if qk is not None:          # EPI_QKV: (scale_h [nh], cos [T, nh, 16], sin [T, nh, 16], nh)
+    if qk is not None and bf:   # EPI_QKV, bf16 mode: (scale_h [nh], rope_pos [T, 2], rope_freq [nh, 8] in revolutions, nh)
+        d.qk_scale, d.rope_pos, d.rope_freq = (_chk(t, n).data_ptr() for t, n in zip(qk[:3], ("qk_scale", "rope_pos", "rope_freq")))
+        d.n_heads = qk[3]
+    elif qk is not None:        # EPI_QKV: (scale_h [nh], cos [T, nh, 16], sin [T, nh, 16], nh)
         d.qk_scale, d.rope_cos, d.rope_sin = (_chk(t, n).data_ptr() for t, n in zip(qk[:3], ("qk_scale", "cos", "sin")))
         d.n_heads = qk[3]
         d.qkv_packed = 1 if qkv_packed else 0      # q, k, v stored as split-bf16 chunks for the attention cores (prep="packed")
-    nat.check(nat.lib().kd_gemm_f32(C.byref(d), _stream()), "kd_gemm_f32")
+    if bf:
+        nat.check(nat.lib().kd_gemm_bf16(C.byref(d), _stream()), "kd_gemm_bf16")
+    else:
+        nat.check(nat.lib().kd_gemm_f32(C.byref(d), _stream()), "kd_gemm_f32")
     return out
+
+
+def _prec_of(x):
+    """Arithmetic mode implied by an activation tensor: bf16 tensors run the bf16 kernels, fp32 ones the KDIFF_GEMM fp32 mode."""
+    if x.dtype == torch.bfloat16:
+        return nat.PREC_BF16
+    p = nat.default_precision()
+    return nat.PREC_SPLIT3 if p == nat.PREC_BF16 else p
 
 
 def linear(x, weight, residual=None, out=None, out_add=0.0):
@@ -107,7 +131,7 @@ def linear(x, weight, residual=None, out=None, out_add=0.0):
     Nn = weight.shape[0]
     out = torch.empty(*x.shape[:-1], Nn, device=x.device, dtype=x.dtype) if out is None else out
     return gemm(x, weight, out, M=M, N=Nn, K=K, epi=nat.EPI_RESIDUAL if residual is not None else nat.EPI_STORE,
-                residual=residual, out_add=out_add)
+                residual=residual, out_add=out_add, precision=_prec_of(x))
 
 
 def linear_geglu(x, weight, out=None):
@@ -116,7 +140,7 @@ def linear_geglu(x, weight, out=None):
     M = x.numel() // K
     d_ff = weight.shape[0] // 2
     out = torch.empty(*x.shape[:-1], d_ff, device=x.device, dtype=x.dtype) if out is None else out
-    return gemm(x, weight, out, M=M, N=d_ff, K=K, epi=nat.EPI_GEGLU)
+    return gemm(x, weight, out, M=M, N=d_ff, K=K, epi=nat.EPI_GEGLU, precision=_prec_of(x))
 
 
 def rms_norm(x, scale, eps=1e-6, out=None):
@@ -138,7 +162,7 @@ def norm_linear(x, scale, weight, *, rows_per_sample, epi=nat.EPI_STORE, out=Non
     Nn = weight.shape[0] // (2 if epi == nat.EPI_GEGLU else 1)
     out = torch.empty(*x.shape[:-1], Nn, device=x.device, dtype=x.dtype) if out is None else out
     return gemm(x, weight, out, M=M, N=Nn, K=K, epi=epi, norm_scale=scale, scale_stride=K if scale.dim() == 2 else 0,
-                rows_per_sample=rows_per_sample, eps=eps, qk=qk, qkv_packed=qkv_packed)
+                rows_per_sample=rows_per_sample, eps=eps, qk=qk, qkv_packed=qkv_packed, precision=_prec_of(x))
 
 
 def token_merge(x, weight, out=None):
@@ -147,7 +171,7 @@ def token_merge(x, weight, out=None):
     h, w = H2 // 2, W2 // 2
     Nn = weight.shape[0]
     out = torch.empty(B, h, w, Nn, device=x.device, dtype=x.dtype) if out is None else out
-    return gemm(x, weight, out, M=B * h * w, N=Nn, K=4 * Cc, a_mode=nat.A_MERGE2x2, grid=(h, w))
+    return gemm(x, weight, out, M=B * h * w, N=Nn, K=4 * Cc, a_mode=nat.A_MERGE2x2, grid=(h, w), precision=_prec_of(x))
 
 
 def token_split_lerp(x, weight, skip, fac, out=None):
@@ -155,18 +179,21 @@ def token_split_lerp(x, weight, skip, fac, out=None):
     B, h, w, K = x.shape
     Nn = weight.shape[0]
     out = torch.empty_like(skip) if out is None else out
-    return gemm(x, weight, out, M=B * h * w, N=Nn, K=K, epi=nat.EPI_SPLIT_LERP, residual=skip, fac=fac, grid=(h, w))
+    return gemm(x, weight, out, M=B * h * w, N=Nn, K=K, epi=nat.EPI_SPLIT_LERP, residual=skip, fac=fac, grid=(h, w), precision=_prec_of(x))
 
 
-def patch_in(image, weight, patch, sigma=None, sigma_data=1.0, out=None):
-    """NCHW->NHWC (:723) + TokenMerge(patch) (:672,:724) (+ Denoiser's x * c_in, layers.py:90)."""
+def patch_in(image, weight, patch, sigma=None, sigma_data=1.0, out=None, precision=None):
+    """NCHW->NHWC (:723) + TokenMerge(patch) (:672,:724) (+ Denoiser's x * c_in, layers.py:90).  The image is fp32; the tokens come
+    out in the activation type of the arithmetic mode (bf16 for PREC_BF16)."""
     B, Cc, H, W = image.shape
     ph, pw = patch
     h, w = H // ph, W // pw
     Nn = weight.shape[0]
-    out = torch.empty(B, h, w, Nn, device=image.device, dtype=image.dtype) if out is None else out
+    precision = nat.default_precision() if precision is None else precision
+    act = torch.bfloat16 if precision == nat.PREC_BF16 else torch.float32
+    out = torch.empty(B, h, w, Nn, device=image.device, dtype=act) if out is None else out
     return gemm(image, weight, out, M=B * h * w, N=Nn, K=Cc * ph * pw, a_mode=nat.A_PATCH_NCHW, grid=(h, w),
-                patch=(ph, pw, Cc), sigma=sigma, sigma_data=sigma_data)
+                patch=(ph, pw, Cc), sigma=sigma, sigma_data=sigma_data, precision=precision)
 
 
 def patch_out(x, norm_scale, weight, patch, channels, x_in=None, sigma=None, sigma_data=1.0, out=None, eps=1e-6):
@@ -174,10 +201,10 @@ def patch_out(x, norm_scale, weight, patch, channels, x_in=None, sigma=None, sig
     (+ Denoiser's F * c_out + x * c_skip, layers.py:90).  x: [B, h, w, K]."""
     B, h, w, K = x.shape
     ph, pw = patch
-    out = torch.empty(B, channels, h * ph, w * pw, device=x.device, dtype=x.dtype) if out is None else out
+    out = torch.empty(B, channels, h * ph, w * pw, device=x.device, dtype=torch.float32) if out is None else out
     return gemm(x, weight, out, M=B * h * w, N=channels * ph * pw, K=K, epi=nat.EPI_UNPATCH_NCHW, norm_scale=norm_scale,
                 scale_stride=0, rows_per_sample=h * w, grid=(h, w), patch=(ph, pw, channels), residual=x_in, sigma=sigma,
-                sigma_data=sigma_data, eps=eps)
+                sigma_data=sigma_data, eps=eps, precision=_prec_of(x))
 
 
 def fourier_sigma(sigma, weight, out=None):
@@ -236,6 +263,11 @@ def _prep_args(prep):
     return 1, _p(_chk(scale_h, "scale")), _p(_chk(cos_t, "cos")), _p(_chk(sin_t, "sin")), eps
 
 
+def _bf16_prep(prep):
+    if prep is not None:
+        raise ValueError("the bf16 attention cores take q, k already prepared by the qkv GEMM's epilogue (prep=None)")
+
+
 def attn_global(qkv, nh, prep=None, out=None):
     """qkv: [B, T, 3*nh*64] -> [B, T, nh*64].  ``prep=(scale_h, cos, sin[, eps])`` applies the q/k
     preparation on the fly; ``None`` means q,k are already prepared."""
@@ -243,8 +275,13 @@ def attn_global(qkv, nh, prep=None, out=None):
     B = qkv.shape[0]
     T = qkv.numel() // (B * 3 * nh * 64)
     out = torch.empty(*qkv.shape[:-1], nh * 64, device=qkv.device, dtype=qkv.dtype) if out is None else out
+    if qkv.dtype == torch.bfloat16:
+        _bf16_prep(prep)
+        nat.check(nat.lib().kd_attn_global_bf16(_p(_chk(qkv, "qkv", torch.bfloat16)), _p(_chk(out, "out", torch.bfloat16)), B, T, nh, _stream()),
+                  "kd_attn_global_bf16")
+        return out
     f, s, c, sn, eps = _prep_args(prep)
-    nat.check(nat.lib().kd_attn_global_f32(_p(_chk(qkv, "qkv")), _p(_chk(out, "out")), B, T, nh, f, s, c, sn, eps, _stream()), "kd_attn_global_f32")
+    nat.check(nat.lib().kd_attn_global_f32(_p(_chk(qkv, "qkv")), _p(_chk(out, "out")), B, T, nh, f, s, c, sn, eps, _prec_of(qkv), _stream()), "kd_attn_global_f32")
     return out
 
 
@@ -253,9 +290,14 @@ def attn_window(qkv, nh, window_size, shift, prep=None, out=None):
     _qkv_dims(qkv, nh)
     B, H, W, _ = qkv.shape
     out = torch.empty(B, H, W, nh * 64, device=qkv.device, dtype=qkv.dtype) if out is None else out
+    if qkv.dtype == torch.bfloat16:
+        _bf16_prep(prep)
+        nat.check(nat.lib().kd_attn_window_bf16(_p(_chk(qkv, "qkv", torch.bfloat16)), _p(_chk(out, "out", torch.bfloat16)), B, H, W, nh, window_size, shift,
+                                                _stream()), "kd_attn_window_bf16")
+        return out
     f, s, c, sn, eps = _prep_args(prep)
-    nat.check(nat.lib().kd_attn_window_f32(_p(_chk(qkv, "qkv")), _p(_chk(out, "out")), B, H, W, nh, window_size, shift, f, s, c, sn, eps, _stream()),
-            "kd_attn_window_f32")
+    nat.check(nat.lib().kd_attn_window_f32(_p(_chk(qkv, "qkv")), _p(_chk(out, "out")), B, H, W, nh, window_size, shift, f, s, c, sn, eps, _prec_of(qkv),
+                                           _stream()), "kd_attn_window_f32")
     return out
 
 
@@ -264,8 +306,13 @@ def attn_na2d(qkv, nh, kernel_size, prep=None, out=None):
     _qkv_dims(qkv, nh)
     B, H, W, _ = qkv.shape
     out = torch.empty(B, H, W, nh * 64, device=qkv.device, dtype=qkv.dtype) if out is None else out
+    if qkv.dtype == torch.bfloat16:
+        _bf16_prep(prep)
+        nat.check(nat.lib().kd_attn_na2d_bf16(_p(_chk(qkv, "qkv", torch.bfloat16)), _p(_chk(out, "out", torch.bfloat16)), B, H, W, nh, kernel_size, _stream()),
+                  "kd_attn_na2d_bf16")
+        return out
     f, s, c, sn, eps = _prep_args(prep)
-    nat.check(nat.lib().kd_attn_na2d_f32(_p(_chk(qkv, "qkv")), _p(_chk(out, "out")), B, H, W, nh, kernel_size, f, s, c, sn, eps, _stream()),
+    nat.check(nat.lib().kd_attn_na2d_f32(_p(_chk(qkv, "qkv")), _p(_chk(out, "out")), B, H, W, nh, kernel_size, f, s, c, sn, eps, _prec_of(qkv), _stream()),
             "kd_attn_na2d_f32")
     return out
 

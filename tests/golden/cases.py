@@ -71,6 +71,25 @@ SAMPLE_CASES = [
 ]
 
 
+# round 2 ------------------------------------------------------------------------------------------------
+# full-batch forwards of the two 256x256 configs (the batch at which the n-split / wide-panel kernels are selected); the golden
+# file keeps the reference's outputs for the images B32_KEEP only (the reference is per-sample, the inputs are rebuilt from seeds)
+FORWARD_B32_CASES = [
+    ("fwd32_flowers_sw", "flowers_sw", 32),
+    ("fwd32_flowers_na", "flowers_na", 32),
+]
+B32_KEEP = [0, 17, 31]
+
+
+def b32_sigmas(batch):
+    return [float(v) for v in torch.logspace(-1.7, 2.1, batch)]
+
+
+# cases recorded under torch.autocast("cpu", torch.bfloat16) (the reference's reduced-precision mode) for the bf16 arithmetic mode
+BF16_SAMPLE_CASES = ["smp_tiny_global_euler", "smp_tiny_sw_heun", "smp_tiny_na_2m", "smp_mnist_euler10", "smp_cifar_heun50",
+                     "smp_flowers_sw_2m50", "smp_flowers_na_2m50"]
+
+
 def raw_config(name):
     c = CONFIGS[name]
     if isinstance(c, str):

@@ -41,12 +41,24 @@ def test_bad_arguments_are_rejected_without_a_gpu(KD):
     d = KD._native.KdGemm()
     d.M, d.N, d.K = 8, 8, 6          # K % 4 != 0
     assert lib.kd_gemm_f32(ctypes.byref(d), None) == -1
-    assert lib.kd_attn_window_f32(1, 1, 1, 16, 16, 1, 7, 0, 0, None, None, None, 1e-6, None) == -1
+    assert lib.kd_attn_window_f32(1, 1, 1, 16, 16, 1, 7, 0, 0, None, None, None, 1e-6, 1, None) == -1
     assert b"window_size" in lib.kd_last_error()
-    assert lib.kd_attn_na2d_f32(1, 1, 1, 16, 16, 1, 5, 0, None, None, None, 1e-6, None) == -1
-    assert lib.kd_attn_global_f32(1, 1, 1, 0, 1, 0, None, None, None, 1e-6, None) == -1
-    assert lib.kd_attn_global_f32(1, 1, 1, 64, 1, 1, None, None, None, 1e-6, None) == -1          # prep without its tables
+    assert lib.kd_attn_na2d_f32(1, 1, 1, 16, 16, 1, 5, 0, None, None, None, 1e-6, 1, None) == -1
+    assert lib.kd_attn_global_f32(1, 1, 1, 0, 1, 0, None, None, None, 1e-6, 1, None) == -1
+    assert lib.kd_attn_global_f32(1, 1, 1, 64, 1, 1, None, None, None, 1e-6, 1, None) == -1          # prep without its tables
     assert b"prep" in lib.kd_last_error()
+    assert lib.kd_attn_global_f32(1, 1, 1, 64, 1, 0, None, None, None, 1e-6, 2, None) == -1          # bf16 is not an fp32-core precision
+    assert b"precision" in lib.kd_last_error()
+    # bf16 mode entry points
+    d = KD._native.KdGemm()
+    d.M, d.N, d.K, d.precision = 8, 8, 8, 1
+    assert lib.kd_gemm_bf16(ctypes.byref(d), None) == -1
+    assert b"KD_PREC_BF16" in lib.kd_last_error()
+    assert lib.kd_attn_na2d_bf16(1, 1, 1, 16, 16, 1, 11, None) == -1
+    assert b"kernel_size" in lib.kd_last_error()
+    assert lib.kd_attn_window_bf16(1, 1, 1, 16, 16, 1, 7, 0, None) == -1
+    assert lib.kd_attn_global_bf16(None, 1, 1, 16, 1, None) == -1
+    assert lib.kd_set_option(None, 1) == -1 and lib.kd_set_option(b"wstat", 1) == 0 and lib.kd_get_option(b"wstat", 7) == 1
     assert lib.kd_brownian_cached_f32(1, None, None, 1, 0, 1, 1, 8, 0.0, 1.0, 0.2, 0.4, 1.0, 36, None) == -1
     assert b"cached end point" in lib.kd_last_error()
     assert lib.kd_brownian_f32(1, 1, 1, 8, 0.0, 1.0, 0.5, 0.4, 1.0, 36, None) == -1            # t0 > t1
