@@ -15,10 +15,11 @@ def main(argv=None):
     p.add_argument("--config", type=Path, help="override the checkpoint's configuration")
     p.add_argument("--output", "-o", type=Path, help="the output slim checkpoint")
     p.add_argument("--dtype", type=str, choices=sorted(K.checkpoint.DTYPES), default="fp16", help="the output dtype")
+    p.add_argument("--unsafe", action="store_true", help="fall back to the full unpickler for checkpoints that need it (trusted files only)")
     args = p.parse_args(argv)
     override = json.loads(args.config.read_text()) if args.config else None
     print(f"Loading training checkpoint {args.checkpoint}...", file=sys.stderr)
-    out = K.checkpoint.convert_training_checkpoint(args.checkpoint, args.output, override, args.dtype)
+    out = K.checkpoint.convert_training_checkpoint(args.checkpoint, args.output, override, args.dtype, unsafe=args.unsafe)
     print(f"Saved inference checkpoint to {out}", file=sys.stderr)
 
 

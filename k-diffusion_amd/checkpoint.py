@@ -31,10 +31,19 @@ def write_inference_checkpoint(state_dict, config, path, dtype="fp16"):
     return Path(path)
 
 
-def convert_training_checkpoint(checkpoint, output=None, config_override=None, dtype="fp16"):
-    """``.pth`` training checkpoint ({'config', 'model_ema', ...}, train.py:397-423) -> slim inference checkpoint."""
+def convert_training_checkpoint(checkpoint, output=None, config_override=None, dtype="fp16", unsafe=False):
+    """``.pth`` training checkpoint ({'config', 'model_ema', ...}, train.py:397-423) -> slim inference checkpoint.
+    The file is read with ``weights_only=True`` (tensors, plain containers and scalars: everything the conversion needs); a
+    checkpoint that only loads through the full unpickler (arbitrary code execution from an untrusted file) needs
+    ``unsafe=True`` / ``--unsafe``."""
     checkpoint = Path(checkpoint)
-    ckpt = torch.load(checkpoint, map_location="cpu", weights_only=False)
+    try:
+        ckpt = torch.load(checkpoint, map_location="cpu", weights_only=True)
+    except Exception as e:  # noqa: BLE001 -- pickle.UnpicklingError and friends
+        if not unsafe:
+            raise RuntimeError(f"{checkpoint} does not load with weights_only=True ({type(e).__name__}: {e}); "
+                               "pass unsafe=True / --unsafe to unpickle it fully (only for files you trust)") from e
+        ckpt = torch.load(checkpoint, map_location="cpu", weights_only=False)
     config = ckpt.get("config") if config_override is None else config_override
     weights = ckpt["model_ema"]
     del ckpt

@@ -498,6 +498,13 @@ class ImageTransformerDenoiserModelV2(nn.Module):
             if self.patch_in.proj.weight.device != x.device:
                 raise RuntimeError(f"model weights are on {self.patch_in.proj.weight.device}, input on {x.device}")
             plan = self._plans[key] = _Plan(self, B, H, W, key[3], has_class, key[5], x.device)
+            if has_class:
+                # nn.Embedding raises on an out-of-range id; the HIP kernel would read past the table.  Checked once per plan
+                # (one device->host read), not per call: the per-step path stays sync-free.
+                lo, hi = int(class_cond.min()), int(class_cond.max())
+                if lo < 0 or hi >= self.class_emb.weight.shape[0]:
+                    del self._plans[key]
+                    raise IndexError(f"class_cond ids must lie in [0, {self.class_emb.weight.shape[0] - 1}] (got {lo}..{hi})")
         cur = torch.cuda.current_stream()
         ident = self._cond_identity(sigma, aug_cond, class_cond, mapping_cond)
         pre, plan.prefetched = plan.prefetched, None
@@ -554,4 +561,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
             plan.run_cond(buf, C.c_void_p(side.cuda_stream))
             done = torch.cuda.Event()
             done.record(side)
-        plan.prefetched = (self._cond_identity(sigma, aug_cond, class_cond, mapping_cond), buf, done)
+        # the record keeps the hinted tensors alive: while it is pending their storage cannot be freed and handed to another
+        # tensor, so a later call whose (address, version, shape) key matches really is the same data (a sampler aborted
+        # mid-loop leaves a record behind; the next run's schedule then necessarily lives at other addresses)
+        plan.prefetched = (self._cond_identity(sigma, aug_cond, class_cond, mapping_cond), buf, done, (sigma, aug_cond, class_cond, mapping_cond))

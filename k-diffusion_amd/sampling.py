@@ -160,8 +160,12 @@ class BrownianTreeNoiseSampler:
         self.tree = BatchedBrownianTree(x, t0, t1, seed)
 
     def __call__(self, sigma, sigma_next):
+        """``sigma`` / ``sigma_next``: python floats or tensors.  The sampler loops hand over their HOST copy of the schedule
+        (``_noise_args``): a device scalar here costs a blocking device->host read per query."""
         t0, t1 = _f(self.transform(torch.as_tensor(_f(sigma)))), _f(self.transform(torch.as_tensor(_f(sigma_next))))
-        return self.tree.increment(t0, t1, mult=1.0 / math.sqrt(abs(t1 - t0)))
+        d = abs(t1 - t0)
+        # equal end points: the reference divides a zero increment by sqrt(0) (nan); same here instead of a ZeroDivisionError
+        return self.tree.increment(t0, t1, mult=1.0 / math.sqrt(d) if d > 0 else float('inf'))
 
 
 class _Loop:
@@ -216,6 +220,15 @@ class _Loop:
     def add_noise(self, noise, c0, c1, c2=1.0):
         self.update(nat.STEP_ADD_NOISE, noise.contiguous(), c0=c0, c1=c1, c2=c2)
 
+    def noise_args(self, noise_sampler, i, j=None):
+        """Arguments of ``noise_sampler(sigma_i, sigma_{i+1})``: the caller's schedule entries (device tensors, what the
+        reference passes to a user-supplied sampler) -- except for the built-in Brownian sampler, which only needs the values
+        and gets the host copies (no per-step device->host sync)."""
+        j = i + 1 if j is None else j
+        if isinstance(noise_sampler, BrownianTreeNoiseSampler):
+            return self.sig[i], self.sig[j]
+        return self.sigmas[i], self.sigmas[j]
+
 
 def _churn_plan(sig, s_churn, s_tmin, s_tmax):
     """Per-step (gamma, sigma_hat) of Karras Alg. 2 (sampling.py:123-125)."""
@@ -224,10 +237,16 @@ def _churn_plan(sig, s_churn, s_tmin, s_tmax):
     return gammas, [sig[i] * (g + 1) for i, g in enumerate(gammas)]
 
 
-def _apply_churn(lp, i, gamma, sigma_hat, s_noise):
-    if gamma > 0:
+def _apply_churn(lp, i, gamma, sigma_hat, s_noise, s_churn):
+    """Karras Alg. 2 noise injection.  The reference draws ``eps = randn_like(x)`` on EVERY step (sampling.py:124,165,195) and
+    uses it only where gamma > 0.  With churn requested the draw is made on every step too, so the generator advances exactly
+    like the reference's (steps outside [s_tmin, s_tmax] included); with s_churn == 0 (the default) no noise is ever used and
+    none is drawn -- the one deliberate deviation: code that reads the global generator AFTER such a run sees a stream that
+    is len(sigmas) - 1 draws behind the reference's."""
+    if s_churn > 0:
         eps = torch.randn_like(lp.x)
-        lp.add_noise(eps, s_noise, (sigma_hat ** 2 - lp.sig[i] ** 2) ** 0.5)
+        if gamma > 0:
+            lp.add_noise(eps, s_noise, (sigma_hat ** 2 - lp.sig[i] ** 2) ** 0.5)
 
 
 # --------------------------------------------------------------------------------- samplers
@@ -240,7 +259,7 @@ def sample_euler(model, x, sigmas, extra_args=None, callback=None, disable=None,
     gammas, hats = _churn_plan(sig, s_churn, s_tmin, s_tmax)
     rows = lp.sigma_rows(hats)
     for i in trange(len(lp), disable=disable):
-        _apply_churn(lp, i, gammas[i], hats[i], s_noise)
+        _apply_churn(lp, i, gammas[i], hats[i], s_noise, s_churn)
         den = lp.denoise(rows[i], next_row=rows[i + 1] if i + 1 < len(lp) else None)
         lp.report(i, den, hats[i])
         lp.update(nat.STEP_EULER, den, c0=hats[i], c1=sig[i + 1] - hats[i])
@@ -260,7 +279,7 @@ def sample_euler_ancestral(model, x, sigmas, extra_args=None, callback=None, dis
         lp.report(i, den)
         lp.update(nat.STEP_EULER, den, c0=sig[i], c1=sigma_down - sig[i])
         if sig[i + 1] > 0:
-            lp.add_noise(noise_sampler(sigmas[i], sigmas[i + 1]), s_noise, sigma_up)
+            lp.add_noise(noise_sampler(*lp.noise_args(noise_sampler, i)), s_noise, sigma_up)
     return lp.x
 
 
@@ -273,7 +292,7 @@ def sample_heun(model, x, sigmas, extra_args=None, callback=None, disable=None, 
     rows, rows_next = lp.sigma_rows(hats), lp.sigma_rows(sig[1:])
     d, x_2 = lp.fresh(), lp.fresh()
     for i in trange(len(lp), disable=disable):
-        _apply_churn(lp, i, gammas[i], hats[i], s_noise)
+        _apply_churn(lp, i, gammas[i], hats[i], s_noise, s_churn)
         last = sig[i + 1] == 0
         den = lp.denoise(rows[i], next_row=None if last else rows_next[i])
         lp.report(i, den, hats[i])
@@ -297,7 +316,7 @@ def sample_dpm_2(model, x, sigmas, extra_args=None, callback=None, disable=None,
     rows, rows_mid = lp.sigma_rows(hats), lp.sigma_rows(mids)
     d, x_2 = lp.fresh(), lp.fresh()
     for i in trange(len(lp), disable=disable):
-        _apply_churn(lp, i, gammas[i], hats[i], s_noise)
+        _apply_churn(lp, i, gammas[i], hats[i], s_noise, s_churn)
         den = lp.denoise(rows[i])
         lp.report(i, den, hats[i])
         if sig[i + 1] == 0:
@@ -329,7 +348,7 @@ def sample_dpm_2_ancestral(model, x, sigmas, extra_args=None, callback=None, dis
             ops.sampler_step(nat.STEP_HEUN_PRED, lp.x, den, out=x_2, aux=d, c0=_f(sig[i]), c1=_f(mids[i] - sig[i]))
             den_2 = lp.denoise(rows_mid[i], x_2)
             lp.update(nat.STEP_EULER_FROM, den_2, in2=x_2, c0=mids[i], c1=sigma_down - sig[i])
-            lp.add_noise(noise_sampler(sigmas[i], sigmas[i + 1]), s_noise, sigma_up)
+            lp.add_noise(noise_sampler(*lp.noise_args(noise_sampler, i)), s_noise, sigma_up)
     return lp.x
 
 
@@ -614,7 +633,7 @@ def sample_dpmpp_2s_ancestral(model, x, sigmas, extra_args=None, callback=None, 
             den_2 = lp.denoise(rows_s[i], x_2)
             lp.update(nat.STEP_DPMPP_2M1, den_2, c0=a2, c1=b2)
         if sig[i + 1] > 0:
-            lp.add_noise(noise_sampler(sigmas[i], sigmas[i + 1]), s_noise, sigma_up)
+            lp.add_noise(noise_sampler(*lp.noise_args(noise_sampler, i)), s_noise, sigma_up)
     return lp.x
 
 
@@ -712,7 +731,7 @@ def sample_dpmpp_2m_sde(model, x, sigmas, extra_args=None, callback=None, disabl
                     coef = 0.5 * (-h - eta_h).expm1().neg() * (1 / ratio)
                 lp.update(nat.STEP_ADD_DIFF, den, in2=old, c0=coef)
             if eta:
-                lp.add_noise(noise_sampler(sigmas[i], sigmas[i + 1]), sig[i + 1], (-2 * eta_h).expm1().neg().sqrt(), s_noise)
+                lp.add_noise(noise_sampler(*lp.noise_args(noise_sampler, i)), sig[i + 1], (-2 * eta_h).expm1().neg().sqrt(), s_noise)
             h_last = h
         old = den
         if sig[i + 1] == 0:
@@ -754,7 +773,7 @@ def sample_dpmpp_3m_sde(model, x, sigmas, extra_args=None, callback=None, disabl
                 phi_2 = h_eta.neg().expm1() / h_eta + 1
                 lp.update(nat.STEP_ADD_DIFF, den, in2=den_1, c0=phi_2 / r)
             if eta:
-                lp.add_noise(noise_sampler(sigmas[i], sigmas[i + 1]), sig[i + 1], (-2 * h * eta).expm1().neg().sqrt(), s_noise)
+                lp.add_noise(noise_sampler(*lp.noise_args(noise_sampler, i)), sig[i + 1], (-2 * h * eta).expm1().neg().sqrt(), s_noise)
         den_1, den_2 = den, den_1
         h_1, h_2 = h, h_1
     return lp.x

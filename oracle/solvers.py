@@ -122,6 +122,68 @@ def sample_heun(model, x, sigmas, extra_args=None, callback=None, s_churn=0.0, s
     return x
 
 
+def sample_dpm_2(model, x, sigmas, extra_args=None, callback=None, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0):
+    """sampling.py:187-215: Euler half step to the log-midpoint sigma, second slope taken there."""
+    extra = extra_args or {}
+    ones = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        x, sigma_hat = _churn(x, sigmas, i, s_churn, s_tmin, s_tmax, s_noise)
+        den = model(x, sigma_hat * ones, **extra)
+        d = to_d(x, sigma_hat, den)
+        _report(callback, x, i, sigmas[i], sigma_hat, den)
+        if sigmas[i + 1] == 0:
+            x = x + d * (sigmas[i + 1] - sigma_hat)
+        else:
+            sigma_mid = sigma_hat.log().lerp(sigmas[i + 1].log(), 0.5).exp()
+            x_2 = x + d * (sigma_mid - sigma_hat)
+            d_2 = to_d(x_2, sigma_mid, model(x_2, sigma_mid * ones, **extra))
+            x = x + d_2 * (sigmas[i + 1] - sigma_hat)
+    return x
+
+
+def sample_dpm_2_ancestral(model, x, sigmas, noise_sampler, extra_args=None, callback=None, eta=1.0, s_noise=1.0):
+    """sampling.py:218-245."""
+    extra = extra_args or {}
+    ones = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        den = model(x, sigmas[i] * ones, **extra)
+        sigma_down, sigma_up = ancestral_step(sigmas[i], sigmas[i + 1], eta)
+        _report(callback, x, i, sigmas[i], sigmas[i], den)
+        d = to_d(x, sigmas[i], den)
+        if sigma_down == 0:
+            x = x + d * (sigma_down - sigmas[i])
+        else:
+            sigma_mid = sigmas[i].log().lerp(sigma_down.log(), 0.5).exp()
+            x_2 = x + d * (sigma_mid - sigmas[i])
+            d_2 = to_d(x_2, sigma_mid, model(x_2, sigma_mid * ones, **extra))
+            x = x + d_2 * (sigma_down - sigmas[i])
+            x = x + noise_sampler(sigmas[i], sigmas[i + 1]) * s_noise * sigma_up
+    return x
+
+
+def sample_dpmpp_2s_ancestral(model, x, sigmas, noise_sampler, extra_args=None, callback=None, eta=1.0, s_noise=1.0):
+    """sampling.py:508-539."""
+    extra = extra_args or {}
+    ones = x.new_ones([x.shape[0]])
+    sigma_fn, t_fn = (lambda t: t.neg().exp()), (lambda s: s.log().neg())
+    for i in range(len(sigmas) - 1):
+        den = model(x, sigmas[i] * ones, **extra)
+        sigma_down, sigma_up = ancestral_step(sigmas[i], sigmas[i + 1], eta)
+        _report(callback, x, i, sigmas[i], sigmas[i], den)
+        if sigma_down == 0:
+            x = x + to_d(x, sigmas[i], den) * (sigma_down - sigmas[i])
+        else:
+            t, t_next = t_fn(sigmas[i]), t_fn(sigma_down)
+            h = t_next - t
+            s = t + 0.5 * h
+            x_2 = (sigma_fn(s) / sigma_fn(t)) * x - (-h * 0.5).expm1() * den
+            den_2 = model(x_2, sigma_fn(s) * ones, **extra)
+            x = (sigma_fn(t_next) / sigma_fn(t)) * x - (-h).expm1() * den_2
+        if sigmas[i + 1] > 0:
+            x = x + noise_sampler(sigmas[i], sigmas[i + 1]) * s_noise * sigma_up
+    return x
+
+
 def sample_dpmpp_2m(model, x, sigmas, extra_args=None, callback=None):
     """sampling.py:584-607."""
     extra = extra_args or {}

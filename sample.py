@@ -10,13 +10,12 @@ all-gather of the finished images, k_diffusion/evaluation.py:87).
 Additive flags (the reference hard-codes sample_lms, an unseeded rank-local randn and no class conditioning,
 sample.py:59-60, and therefore cannot run its own class-conditional configs):
   --sampler NAME       any K.sampling.sample_* (default: lms, like the reference)
-  --seed S             per-image noise from (seed, global image index): identical images for any GPU count
+  --seed S             per-image noise from (seed, global image index): image i is the same for any batch size / GPU count
   --class-cond C       class id for every image (-1: image index mod num_classes) for class-conditional configs
   --random-weights     no checkpoint: synthetic weights (K.synth), for smoke runs and benchmarking
   --no-png             skip PNG encoding (timing runs)
 """
 import argparse
-import math
 import sys
 import time
 from pathlib import Path
@@ -56,15 +55,17 @@ def resolve_sampler(name):
     return fn
 
 
-def class_ids(args, num_classes, lo, n, device):
-    """class_cond for global image indices [lo, lo+n) or None for unconditional models."""
+def class_ids(args, num_classes, indices, device):
+    """class_cond for the given global image indices, or None for unconditional models."""
     if not num_classes:
         return None
     if args.class_cond is None:
         raise SystemExit(f'this config is class-conditional ({num_classes} classes): pass --class-cond C (or -1)')
+    if args.class_cond >= num_classes:
+        raise SystemExit(f'--class-cond {args.class_cond} is out of range: this config has {num_classes} classes (0..{num_classes - 1})')
     if args.class_cond < 0:
-        return (torch.arange(lo, lo + n) % num_classes).to(device)
-    return torch.full([n], args.class_cond, dtype=torch.int64, device=device)
+        return (indices % num_classes).to(device)
+    return torch.full([len(indices)], args.class_cond, dtype=torch.int64, device=device)
 
 
 def main(argv=None):
@@ -95,8 +96,6 @@ def main(argv=None):
     sampler = resolve_sampler(args.sampler)
     num_classes = config['dataset']['num_classes']
     shape = (model_config['input_channels'], size[0], size[1])
-    per_rank = math.ceil(args.n / accelerator.num_processes)
-    cursor = [accelerator.process_index * per_rank]          # global index of this rank's next image
 
     @torch.no_grad()
     @K.utils.eval_mode(model)
@@ -105,15 +104,17 @@ def main(argv=None):
             tqdm.write('Sampling...')
         sigmas = K.sampling.get_sigmas_karras(args.steps, sigma_min, sigma_max, rho=7., device=device)
 
-        def sample_fn(n):
-            lo = cursor[0]
-            cursor[0] += n
+        def sample_fn(indices):
+            """Images of the given GLOBAL indices (this rank's share of one round; may be empty)."""
+            n = len(indices)
+            if n == 0:
+                return torch.empty([0, *shape], device=device)
             if args.seed is None:
                 x = torch.randn([n, *shape], device=device) * sigma_max
             else:
-                x = torch.stack([K.synth.synth_noise(shape, args.seed, lo + g, sigma_max) for g in range(n)]).to(device)
+                x = torch.stack([K.synth.synth_noise(shape, args.seed, int(g), sigma_max) for g in indices]).to(device)
             extra = {}
-            cc = class_ids(args, num_classes, lo, n, device)
+            cc = class_ids(args, num_classes, indices, device)
             if cc is not None:
                 extra['class_cond'] = cc
             quiet = not accelerator.is_local_main_process
@@ -124,7 +125,9 @@ def main(argv=None):
             return sampler(model, x, sigmas, extra_args=extra, disable=quiet)
 
         t0 = time.perf_counter()
-        x_0 = K.evaluation.compute_features(accelerator, sample_fn, lambda x: x, args.n, args.batch_size)
+        # the reference's compute_features (evaluation.py:80-90) with images addressed by global index: out[i] is image i for
+        # any batch size / GPU count (see compute_features_indexed)
+        x_0 = K.evaluation.compute_features_indexed(accelerator, sample_fn, args.n, args.batch_size)
         torch.cuda.synchronize()
         accelerator.print(f'{args.n} images in {time.perf_counter() - t0:.2f} s')
         if accelerator.is_main_process and not args.no_png:

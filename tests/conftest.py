@@ -19,7 +19,8 @@ def golden():
     from tests.golden import cases
     gd = cases.GOLDEN_DIR
     out = {"kat": json.load(open(os.path.join(gd, "kat.json")))}
-    for name in ("ops", "forward", "samples"):
+    out["kat2"] = json.load(open(os.path.join(gd, "kat2.json")))
+    for name in ("ops", "forward", "samples", "forward_b32", "forward_bf16", "samples_bf16"):
         out[name] = load_file(os.path.join(gd, name + ".safetensors"))
     return out
 

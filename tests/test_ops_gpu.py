@@ -493,3 +493,144 @@ def test_to_uint8(ops):
     x = torch.linspace(-1.5, 1.5, 1001)
     ref = (((x.clamp(-1, 1) + 1) / 2) * 255).to(torch.uint8)
     assert torch.equal(ops.to_uint8(g(x)).cpu(), ref)
+
+
+def test_brownian_multi_scale_statistics(ops):
+    """The virtual tree behaves like Brownian motion at every scale: Var[W(t1) - W(t0)] = t1 - t0 across four decades of
+    interval length (short intervals deep in the tree, long ones near its root), increments over disjoint intervals are
+    uncorrelated (also when they are siblings under one tree node), and a coarse increment is the sum of its parts."""
+    seeds = g(torch.arange(8, dtype=torch.int64) * 7919 + 5)
+    n = 1 << 15
+    inc = lambda a, b: ops.brownian(torch.empty(8, n, device=DEV), seeds, 0.01, 160.0, a, b, 1.0)
+    for a, b in ((0.0100, 0.0101), (0.02, 0.03), (0.5, 0.9), (3.0, 11.0), (20.0, 150.0), (0.01, 160.0)):
+        w = inc(a, b)
+        assert abs(w.var().item() / (b - a) - 1.0) < 0.03, (a, b)
+        assert abs(w.mean().item()) < 0.02 * (b - a) ** 0.5, (a, b)
+    pairs = (((0.5, 0.9), (0.9, 1.7)), ((0.02, 0.03), (40.0, 41.0)), ((79.99, 80.0), (80.0, 80.02)), ((1.0, 2.0), (2.0, 2.0001)))
+    for (a, b), (c, d) in pairs:
+        x, y = inc(a, b).flatten(), inc(c, d).flatten()
+        assert abs(torch.corrcoef(torch.stack([x, y]))[0, 1].item()) < 0.01, ((a, b), (c, d))
+    parts = inc(1.0, 1.5) + inc(1.5, 4.0) + inc(4.0, 32.0)
+    assert (parts - inc(1.0, 32.0)).abs().max() < 1e-4
+    # different samples (seeds) and different elements are independent streams
+    w = inc(0.3, 7.0)
+    assert abs(torch.corrcoef(w[:4])[0, 1:].abs().max().item()) < 0.03
+    assert abs(torch.corrcoef(torch.stack([w[0, :-1], w[0, 1:]]))[0, 1].item()) < 0.03
+
+
+# ---- bf16 arithmetic mode (KD_PREC_BF16): the same ops on bf16 activations ------------------------------------------------
+BF = torch.bfloat16
+
+
+def _bf(t):
+    return t.to(BF).to(DEV).contiguous()
+
+
+def _rt(t):
+    """what a bf16 kernel sees of an fp32 tensor"""
+    return t.to(BF).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 128, 128), (4100, 256, 384), (2048, 256, 256), (1000, 96, 192), (300, 160, 64), (8192, 512, 1536), (70, 32, 12)])
+def test_bf16_gemm_plain_and_residual(ops, M, N, K):
+    """kd_gemm_bf16 through the W-stationary, tiled and generic kernels (the shape picks the kernel): bf16 in / out, fp32 accumulate."""
+    a, w, r = rn(M, K, seed=1), rn(N, K, seed=2, scale=K ** -0.5), rn(M, N, seed=3)
+    ref = _rt(a) @ _rt(w).T
+    y = ops.linear(_bf(a), g(w))
+    assert y.dtype == BF and relerr(y, ref) < 8e-3
+    y = ops.linear(_bf(a), g(w), residual=_bf(r))
+    assert relerr(y, ref + _rt(r)) < 8e-3
+    x = _bf(r)
+    ops.linear(_bf(a), g(w), residual=x, out=x)                   # in place (how the model uses it)
+    assert relerr(x, ref + _rt(r)) < 8e-3
+
+
+@pytest.mark.parametrize("B,T,K,d_ff", [(2, 4096, 128, 384), (3, 1024, 256, 768), (32, 64, 512, 1536), (4, 49, 256, 768), (2, 50, 100, 96)])
+def test_bf16_norm_linear_and_geglu(ops, B, T, K, d_ff):
+    """AdaRMSNorm -> Linear / LinearGEGLU in bf16 mode (W-stationary at K = 128, A-stationary ring at K = 256 / 512, generic otherwise)
+    against the fp32 oracle on the bf16-rounded input."""
+    x, scale = rn(B, T, K, seed=4), 1 + 0.2 * rn(B, K, seed=5)
+    w, wg = rn(d_ff, K, seed=6, scale=K ** -0.5), rn(2 * d_ff, K, seed=7, scale=K ** -0.5)
+    xn = hdit.rms_norm(_rt(x), scale[:, None, :])
+    y = ops.norm_linear(_bf(x), g(scale), g(w), rows_per_sample=T)
+    assert y.dtype == BF and relerr(y, xn @ _rt(w).T) < 1.2e-2
+    from k_diffusion_amd import _native as nat
+    y = ops.norm_linear(_bf(x), g(scale), g(wg), rows_per_sample=T, epi=nat.EPI_GEGLU)
+    assert relerr(y, hdit.linear_geglu(xn, _rt(wg))) < 1.5e-2
+
+
+@pytest.mark.parametrize("H,W,nh,B,K", [(64, 64, 2, 2, 128), (32, 32, 4, 2, 256), (16, 16, 8, 4, 512), (7, 7, 4, 3, 256)])
+def test_bf16_qkv_epilogue(ops, H, W, nh, B, K):
+    """The bf16 qkv epilogue (cosine-sim scale + RoPE with hardware sin / cos from the position / frequency tables) against
+    the oracle's scale_for_cosine_sim + apply_rotary_emb on the fp32 projection."""
+    from k_diffusion_amd import _native as nat
+    T, d = H * W, nh * 64
+    x, scale = rn(B, T, K, seed=8), 1 + 0.2 * rn(B, K, seed=9)
+    w = rn(3 * d, K, seed=10, scale=K ** -0.5)
+    qs = torch.linspace(5.0, 12.0, nh)
+    pos, freqs = hdit.axial_pos(H, W).reshape(T, 2), hdit.rope_freqs(nh)
+    qkv = ops.norm_linear(_bf(x), g(scale), g(w), rows_per_sample=T, epi=nat.EPI_QKV,
+                          qk=(g(qs), g(pos.contiguous()), g((freqs / (2 * np.pi)).contiguous()), nh)).float().cpu().view(B, H, W, 3, nh, 64)
+    ref = (hdit.rms_norm(_rt(x), scale[:, None, :]) @ _rt(w).T).view(B, H, W, 3, nh, 64)
+    theta = hdit.rope_theta(hdit.axial_pos(H, W), freqs)
+    q_ref, k_ref = hdit.cosine_sim_scale(ref[..., 0, :, :], ref[..., 1, :, :], qs)
+    assert relerr(qkv[..., 0, :, :], hdit.apply_rope(q_ref, theta)) < 1.2e-2
+    assert relerr(qkv[..., 1, :, :], hdit.apply_rope(k_ref, theta)) < 1.2e-2
+    assert relerr(qkv[..., 2, :, :], ref[..., 2, :, :]) < 1.2e-2
+
+
+def test_bf16_attention_cores(ops, golden):
+    """bf16 global / window / neighbourhood cores against the reference's op goldens (prepared q, k) and the oracle."""
+    o = golden["ops"]
+    qkv = _bf(_pack(o["qk.q_out"], o["qk.k_out"], o["qk.v"]))
+    y = ops.attn_global(qkv.view(2, 256, -1), 2).float().cpu().view(2, 16, 16, 2, 64)
+    assert relerr(y, o["attn_global.o"]) < 1.2e-2
+    for shift in (0, 4):
+        y = ops.attn_window(qkv, 2, 8, shift).float().cpu().view(2, 16, 16, 2, 64)
+        assert relerr(y, o[f"attn_window{shift}.o"]) < 1.2e-2
+    for tag, ws, shift in (("w4s0", 4, 0), ("w4s2", 4, 2), ("w16s8", 16, 8), ("w16s0", 16, 0)):
+        q, k, v = o[f"attn_{tag}.q"], o[f"attn_{tag}.k"], o[f"attn_{tag}.v"]
+        y = ops.attn_window(_bf(_pack(q, k, v)), q.shape[3], ws, shift).float().cpu().view(q.shape)
+        assert relerr(y, o[f"attn_{tag}.o"]) < 1.2e-2, tag
+    for ks, (B, H, W, nh) in ((3, (2, 9, 12, 2)), (5, (2, 20, 13, 1)), (7, (1, 32, 32, 4)), (7, (2, 7, 7, 1)), (9, (2, 20, 33, 2)), (9, (1, 9, 9, 1))):
+        q, k, v = (rn(B, H, W, nh, 64, seed=s, scale=sc) for s, sc in ((1, 0.5), (2, 0.5), (3, 1.0)))
+        y = ops.attn_na2d(_bf(_pack(q, k, v)), nh, ks).float().cpu().view(B, H, W, nh, 64)
+        assert relerr(y, hdit.na2d(_rt(q), _rt(k), _rt(v), ks, 1.0)) < 1.2e-2, (ks, H, W)
+    for T, nh, B in ((49, 4, 2), (100, 2, 3), (960, 2, 1), (1024, 1, 2)):                # whole-in-LDS and streamed forms
+        q, k, v = (rn(B, T, 1, nh, 64, seed=s, scale=sc) for s, sc in ((1, 0.4), (2, 0.4), (3, 1.0)))
+        y = ops.attn_global(_bf(_pack(q, k, v)).view(B, T, -1), nh).float().cpu().view(B, T, nh, 64)
+        ref = hdit.attn_global(_rt(q), _rt(k), _rt(v)).view(B, T, nh, 64)
+        assert relerr(y, ref) < 1.2e-2, T
+    with pytest.raises(ValueError, match="prepared"):
+        ops.attn_global(qkv.view(2, 256, -1), 2, prep=(g(o["qk.scale"]), None, None))
+    with pytest.raises(RuntimeError, match="kernel_size"):
+        ops.attn_na2d(qkv, 2, 11)
+
+
+def test_bf16_merge_split_patch(ops, golden):
+    from k_diffusion_amd import _native as nat
+    o = golden["ops"]
+    x = o["rms_norm.x"]                                                      # [2, 8, 8, 128]
+    assert relerr(ops.token_merge(_bf(x), g(o["merge.w"])), hdit.token_merge(_rt(x), _rt(o["merge.w"]), 2, 2)) < 1e-2
+    y = ops.token_split_lerp(_bf(x), g(o["split.w"]), _bf(o["split.skip"]), g(torch.tensor([0.37])))
+    ref = torch.lerp(_rt(o["split.skip"]), hdit.token_split(_rt(x), _rt(o["split.w"]), 2, 2), 0.37)
+    assert relerr(y, ref) < 1e-2
+    # big enough for the tiled kernel (merge gather / split scatter through global_load_lds addressing)
+    xb, wm = rn(2, 32, 32, 128, seed=11), rn(256, 512, seed=12, scale=512 ** -0.5)
+    assert relerr(ops.token_merge(_bf(xb), g(wm)), hdit.token_merge(_rt(xb), _rt(wm), 2, 2)) < 1e-2
+    xs, ws_, skip = rn(2, 16, 16, 256, seed=13), rn(512, 256, seed=14, scale=1 / 16), rn(2, 32, 32, 128, seed=15)
+    y = ops.token_split_lerp(_bf(xs), g(ws_), _bf(skip), g(torch.tensor([0.37])))
+    assert relerr(y, torch.lerp(_rt(skip), hdit.token_split(_rt(xs), _rt(ws_), 2, 2), 0.37)) < 1e-2
+    # patch in (fp32 image -> bf16 tokens) / patch out (bf16 tokens -> fp32 image) with the Karras scalings
+    img, sigma = rn(2, 3, 32, 32, seed=16, scale=3.0), torch.tensor([0.3, 9.0])
+    w_in, w_out, gain = rn(128, 48, seed=17, scale=48 ** -0.5), rn(48, 128, seed=18, scale=128 ** -0.5), 1 + 0.1 * rn(128, seed=19)
+    c_skip, c_out, c_in = solvers.karras_scalings(sigma, 0.5)
+    t = ops.patch_in(g(img), g(w_in), (4, 4), sigma=g(sigma), sigma_data=0.5, precision=nat.PREC_BF16)
+    assert t.dtype == BF
+    ref_t = hdit.token_merge((img * c_in.view(-1, 1, 1, 1)).movedim(1, -1).contiguous(), w_in, 4, 4)
+    assert relerr(t, ref_t) < 1.5e-2
+    tok = rn(2, 8, 8, 128, seed=20)
+    out = ops.patch_out(_bf(tok), g(gain), g(w_out), (4, 4), 3, x_in=g(img), sigma=g(sigma), sigma_data=0.5)
+    assert out.dtype == torch.float32
+    f = hdit.token_split(hdit.rms_norm(_rt(tok), gain), _rt(w_out), 4, 4).movedim(-1, 1)
+    assert relerr(out, f * c_out.view(-1, 1, 1, 1) + img * c_skip.view(-1, 1, 1, 1)) < 5e-3

@@ -98,6 +98,31 @@ def test_solver_known_answers_bit_exact(golden):
     assert torch.equal(bits(got.reshape(-1)), bits(unhex(kat["solver_toy_sde_recorded"])))
 
 
+def test_second_order_ancestral_samplers_bit_exact(golden):
+    """sample_dpm_2 / sample_dpm_2_ancestral / sample_dpmpp_2s_ancestral (sampling.py:187-245, 508-539) against runs recorded
+    from the real reference (oracle/make_golden_r2.py), noise injected through ``noise_sampler=``; and the churn noise is drawn
+    on EVERY step like the reference's (the generator ends up where the reference's does)."""
+    kat = golden["kat2"]
+    toy = lambda x, sigma, **kw: torch.tanh(x) / (1 + sigma.view(-1, 1, 1, 1))
+    xt = torch.randn(2, 3, 4, 4, generator=torch.Generator().manual_seed(3)) * 80
+    sig20 = solvers.sigmas_karras(20, 1e-2, 80)
+    noise = cases.recorded_noise(tuple(xt.shape), 64, seed=77)
+    assert torch.equal(bits(solvers.sample_dpm_2(toy, xt, sig20).reshape(-1)), bits(unhex(kat["solver_toy_dpm_2"])))
+    for fn, key, kw in ((solvers.sample_dpm_2_ancestral, "solver_toy_dpm_2_ancestral_recorded", {}),
+                        (solvers.sample_dpm_2_ancestral, "solver_toy_dpm_2_ancestral_eta0.4_recorded", dict(eta=0.4, s_noise=0.9)),
+                        (solvers.sample_dpmpp_2s_ancestral, "solver_toy_dpmpp_2s_ancestral_recorded", {}),
+                        (solvers.sample_dpmpp_2s_ancestral, "solver_toy_dpmpp_2s_ancestral_eta0.4_recorded", dict(eta=0.4, s_noise=0.9))):
+        it = iter(noise)
+        got = fn(toy, xt, sig20, noise_sampler=lambda a, b: next(it), **kw)
+        assert torch.equal(bits(got.reshape(-1)), bits(unhex(kat[key]))), key
+    torch.manual_seed(321)
+    assert torch.equal(bits(solvers.sample_dpm_2(toy, xt, sig20, s_churn=8.0).reshape(-1)), bits(unhex(kat["solver_toy_dpm_2_churn"])))
+    torch.manual_seed(321)
+    got = solvers.sample_heun(toy, xt, sig20, s_churn=8.0, s_tmin=0.5, s_tmax=20.0)
+    assert torch.equal(bits(got.reshape(-1)), bits(unhex(kat["solver_toy_heun_churn_window"])))
+    assert torch.equal(bits(torch.randn(4)), bits(unhex(kat["rng_after_heun_churn_window"])))
+
+
 def test_dpm_solver_family_bit_exact(golden):
     """sample_dpm_fast (order patterns 3..3,2,1 / 3..3,1 / 3..3,2 / single step, and ancestral noise) and
     sample_dpm_adaptive (orders 3 and 2, ancestral) -- the oracle against runs recorded from the real reference,
@@ -149,6 +174,30 @@ def test_ops_vs_reference(golden):
     assert relerr(hdit.token_merge(x, o["merge.w"], 2, 2), o["merge.y"]) < 2e-6
     up = hdit.token_split(x, o["split.w"], 2, 2)
     assert relerr(torch.lerp(o["split.skip"], up, torch.tensor([0.37])), o["split.y"]) < 2e-6
+
+
+def test_na2d_window_starts_literal():
+    """NATTEN's neighbourhood rule written out as literals (its documentation: a query keeps exactly kernel_size keys per
+    axis; the window is centred where it fits and pulled inside at the borders): for kernel 7 the start is i - 3 clamped to
+    [0, L - 7].  NATTEN itself is absent here (parity unpinned); these are the worked corner / edge cases the survey asked for,
+    so a change of the oracle's (and therefore the HIP core's) rule cannot pass unnoticed."""
+    lit = {(7, 7): [0, 0, 0, 0, 0, 0, 0],
+           (8, 7): [0, 0, 0, 0, 1, 1, 1, 1],
+           (9, 7): [0, 0, 0, 0, 1, 2, 2, 2, 2],
+           (12, 7): [0, 0, 0, 0, 1, 2, 3, 4, 5, 5, 5, 5],
+           (6, 3): [0, 0, 1, 2, 3, 3],
+           (6, 5): [0, 0, 0, 1, 1, 1],
+           (11, 9): [0, 0, 0, 0, 0, 1, 2, 2, 2, 2, 2]}
+    for (length, ks), want in lit.items():
+        assert hdit.na2d_window_start(length, ks).tolist() == want, (length, ks)
+    # the 2-D op on an 8 x 9 grid: the corner query (0, 0) attends rows 0..6 x cols 0..6, the far corner (7, 8) rows 1..7 x cols 2..8
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(1, 8, 9, 1, 64, generator=g) * 0.3 for _ in range(3))
+    out = hdit.na2d(q, k, v, 7)
+    for (qi, qj), (r0, c0) in (((0, 0), (0, 0)), ((7, 8), (1, 2)), ((3, 4), (0, 1)), ((4, 8), (1, 2))):
+        kk, vv = k[0, r0:r0 + 7, c0:c0 + 7, 0].reshape(49, 64), v[0, r0:r0 + 7, c0:c0 + 7, 0].reshape(49, 64)
+        want = torch.softmax(kk @ q[0, qi, qj, 0], dim=0) @ vv
+        assert torch.allclose(out[0, qi, qj, 0], want, atol=1e-5), (qi, qj)
 
 
 def test_na2d_properties():
