@@ -583,6 +583,9 @@ int main(int argc, char** argv) {
         {"generic out+res", 8192, 128, 128, KD_EPI_RESIDUAL, 0, 4096, 0},
         {"generic down+res mnist", 196, 256, 768, KD_EPI_RESIDUAL, 0, 49, 0},
         {"generic store norm", 300, 96, 100, KD_EPI_STORE, 1, 50, 0},
+        {"generic geglu N=400", 2880, 400, 192, KD_EPI_GEGLU, 1, 960, 0},
+        {"generic down K=400", 2880, 192, 400, KD_EPI_RESIDUAL, 0, 960, 0},
+        {"generic store N=72", 500, 72, 64, KD_EPI_STORE, 0, 500, 0},
         {"generic store K=52", 260, 64, 52, KD_EPI_STORE, 0, 260, 0},
         {"generic merge", 2048, 256, 512, KD_EPI_STORE, 0, 256, 0, KD_A_MERGE2x2, 16, 16},
         {"generic merge small", 72, 64, 48, KD_EPI_STORE, 0, 36, 0, KD_A_MERGE2x2, 6, 6},

@@ -60,7 +60,8 @@ __device__ __forceinline__ void half_swap(unsigned& x, unsigned& y) {
 
 // One 32-feature block of a lane's row, fp32 in MFMA C-layout order (v[r], r < 16) -> bf16, paired with the other half-wave
 // into 2 x 16-byte stores.  `crow` = &C[row][first feature of the block]; lh = lane >> 5.
-__device__ __forceinline__ void store_block_bf16(u16* crow, const float (&v)[16], int lh, bool ok) {
+// `nvalid` (multiple of 8): features of the block that exist (ragged last block of a row): pieces past it are not stored.
+__device__ __forceinline__ void store_block_bf16(u16* crow, const float (&v)[16], int lh, bool ok, int nvalid = 32) {
   unsigned p[4][2];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -72,15 +73,15 @@ __device__ __forceinline__ void store_block_bf16(u16* crow, const float (&v)[16]
     half_swap(p[gp][0], p[gp + 1][0]);
     half_swap(p[gp][1], p[gp + 1][1]);
     // lanes 0-31: features 8gp .. 8gp+7; lanes 32-63: features 8(gp+1) .. +7
-    if (ok) *reinterpret_cast<u32x4*>(crow + 8 * (gp + lh)) = u32x4{p[gp][0], p[gp][1], p[gp + 1][0], p[gp + 1][1]};
+    if (ok && 8 * (gp + lh) < nvalid) *reinterpret_cast<u32x4*>(crow + 8 * (gp + lh)) = u32x4{p[gp][0], p[gp][1], p[gp + 1][0], p[gp + 1][1]};
   }
 }
 
 // the same block of a bf16 row-major operand (residual / skip) brought INTO the C-layout as fp32: r[i] pairs with v[i]
-__device__ __forceinline__ void load_block_bf16(const u16* rrow, float (&r)[16], int lh) {
+__device__ __forceinline__ void load_block_bf16(const u16* rrow, float (&r)[16], int lh, int nvalid = 32) {
 #pragma unroll
   for (int gp = 0; gp < 4; gp += 2) {
-    const u32x4 q = *reinterpret_cast<const u32x4*>(rrow + 8 * (gp + lh));
+    const u32x4 q = *reinterpret_cast<const u32x4*>(rrow + (8 * (gp + lh) < nvalid ? 8 * (gp + lh) : 0));   // pieces past the row end: re-read piece 0 (unused)
     unsigned q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     half_swap(q0, q2);
     half_swap(q1, q3);

@@ -864,7 +864,7 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_bf16_kernel(const KdGemm 
         v[r + 1] = o.y;
       }
       const int nb = n0 + 32 * wc;
-      store_block_bf16(C16 + (size_t)gmc * N + min(nb, N - 32), v, lh, ok && nb < N);
+      store_block_bf16(C16 + (size_t)gmc * N + min(nb, N - 8), v, lh, ok && nb < N, N - nb);
     } else if (EPI == KD_EPI_QKV) {
       const int vec = (n0 >> 6) + wc;
       if (vec * 64 < N) {
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_bf16_kernel(const KdGemm 
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int nb = n0 + wc * 64 + 32 * i, nbc = min(nb, N - 32);
+        const int nb = n0 + wc * 64 + 32 * i, nbc = min(nb, N - 8), nv = N - nb;
         size_t off;
         if (EPI == KD_EPI_SPLIT_LERP) {
           const int hw = p.gh * p.gw, cout = N >> 2;
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_bf16_kernel(const KdGemm 
         for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] * rs;
         if (EPI == KD_EPI_RESIDUAL || EPI == KD_EPI_SPLIT_LERP) {
           float rr_[16];
-          load_block_bf16(R16 + off, rr_, lh);
+          load_block_bf16(R16 + off, rr_, lh, nv);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             if (EPI == KD_EPI_RESIDUAL) {
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_bf16_kernel(const KdGemm 
             }
           }
         }
-        store_block_bf16(C16 + off, v, lh, ok && nb < N);
+        store_block_bf16(C16 + off, v, lh, ok && nb < N, nv);
       }
     }
   }
@@ -968,7 +968,8 @@ static int launch_generic(const KdGemm& d, hipStream_t s) {
 }
 
 int gemm_generic_try(const KdGemm& d, hipStream_t s, int* rc) {
-  if (d.epi != KD_EPI_UNPATCH_NCHW && (d.N & 31)) return 1;
+  if (d.epi != KD_EPI_UNPATCH_NCHW && (d.N & 7)) return 1;                 // 16-byte stores: 8 bf16
+  if (d.epi == KD_EPI_SPLIT_LERP && ((d.N >> 2) & 31)) return 1;            // a 32-feature block lies inside one quadrant
   if (d.epi == KD_EPI_STORE && d.out_add != 0.f) return 1;
   if (d.a_mode == KD_A_MERGE2x2 && ((d.K >> 2) & 3)) return 1;
 #define KD_GN(AM, EP) if (d.a_mode == AM && d.epi == EP) { *rc = launch_generic<AM, EP>(d, s); return 0; }
