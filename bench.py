@@ -10,6 +10,12 @@ One "step" = one pass of the hot path over one batch: a complete 50-step ``sampl
 ``--batch`` images per GPU, followed -- for N > 1 -- by the path's one exchange step, the RCCL
 all-gather of the finished images (k_diffusion/evaluation.py:87).  Initial noise, weights and the
 sigma table are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+Arithmetic mode (``--mode``, default bf16): ``value`` / ``dtype`` belong to that mode; at N = 1 the other two modes are measured
+right after it on the same box (1 warm-up + 2 passes each) and reported under ``modes`` in the same line:
+  bf16    bf16 activations, one bf16 MFMA per product, fp32 accumulate / statistics (the reference under autocast(bfloat16))
+  split3  fp32 activations, 3 split-bf16 MFMA terms per product: the fp32-PARITY mode (inside north_star's 1e-3)
+  exact   fp32 activations, fp32-input MFMA, bit-for-bit an fmaf chain
 """
 import argparse
 import json
@@ -42,6 +48,8 @@ def parse():
     p.add_argument("--sampler", default="sample_dpmpp_2m")
     p.add_argument("--sampler-steps", type=int, default=50)
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--mode", default=os.environ.get("KDIFF_GEMM", "bf16"), choices=["bf16", "split3", "exact"], help="arithmetic mode of `value`")
+    p.add_argument("--no-other-modes", action="store_true", help="skip the short measurement of the other two arithmetic modes")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time for the baseline sample")
     p.add_argument("--no-kernel-events", action="store_true", help="do not record per-launch HIP events in the timed region")
@@ -74,40 +82,49 @@ def kernel_table():
     return groups
 
 
-def family_roofline(name, g, split3, total_ms):
-    """Roofline entry of one kernel family from its summed algorithmic work and HIP-event time.  A family is bound by
-    whichever of (algorithmic bytes / HBM peak, executed MFMA flops / MFMA peak) needs longer."""
+SIDE_STREAM = ("gemm_skinny", "fourier", "cond_sum", "rmsnorm")     # the conditioning chain: runs on the side stream, overlapped
+
+
+def family_roofline(name, g, mode, total_ms):
+    """Roofline entry of one kernel family from its summed ALGORITHMIC work (flops = 2 M N K of the products, bytes = every
+    operand once at its storage width) and HIP-event time.  `bound` is decided on the algorithmic work; `frac` is the useful
+    fraction (algorithmic / peak).  The split-bf16x3 kernels execute 3 bf16 MFMA products per algorithmic product: their
+    `executed_frac` (matrix-pipe occupancy) is reported beside it."""
     sec = g["ms"] * 1e-3
     gbs = g["bytes"] / sec / 1e9
-    is_gemm, is_attn = name.startswith("gemm"), name.startswith("attn")
-    # executed matrix flops per algorithmic flop: 3 bf16 products per fp32 product in the split kernels; the dense
-    # attention cores (global / window) run on the exact fp32 MFMA; the neighbourhood core is a split-bf16 kernel too
-    if is_gemm:
-        mult, peak = (3.0, BF16_MFMA_PEAK_TFLOPS) if split3 and not name.startswith("gemm_f32") else (1.0, FP32_MFMA_PEAK_TFLOPS)
-    elif name.startswith("attn_na2d") or "bf16x3" in name:
-        mult, peak = 3.0, BF16_MFMA_PEAK_TFLOPS
-    elif is_attn:
-        mult, peak = 1.0, FP32_MFMA_PEAK_TFLOPS
+    is_bf16 = "bf16" in name and "bf16x3" not in name
+    is_x3 = "bf16x3" in name or name in ("gemm_astat", "attn_na2d") or (mode == "split3" and name.startswith("gemm_bf16x3"))
+    has_mfma = name.startswith("gemm") or name.startswith("attn")
+    if is_bf16 or is_x3:
+        mult, peak = (3.0 if is_x3 else 1.0), BF16_MFMA_PEAK_TFLOPS
+    elif has_mfma and not name.startswith("gemm_skinny"):
+        mult, peak = 1.0, FP32_MFMA_PEAK_TFLOPS          # exact fp32-input MFMA kernels
     else:
         mult, peak = 0.0, BF16_MFMA_PEAK_TFLOPS
     tfl_alg = g["flops"] / sec / 1e12
-    t_hbm, t_mfma = g["bytes"] / (HBM_PEAK_GBS * 1e9), g["flops"] * mult / (peak * 1e12)
+    # time the algorithmic work needs at the roof of each resource (matrix flops priced at the instruction the kernel issues)
+    t_hbm, t_mfma = g["bytes"] / (HBM_PEAK_GBS * 1e9), (g["flops"] * mult / (peak * 1e12) if mult else 0.0)
     common = {"kernel": name, "launches": g["launches"], "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 5),
-              "share_of_kernel_time": round(g["ms"] / total_ms, 4) if total_ms else None,
+              "share_of_kernel_time": None if name.startswith(SIDE_STREAM) or not total_ms else round(g["ms"] / total_ms, 4),
               "algorithmic_gbs": round(gbs, 1), "algorithmic_tflops": round(tfl_alg, 2)}
+    if name.startswith(SIDE_STREAM):
+        common["overlapped"] = "conditioning chain on the side stream: not part of the main chain's time"
+    if mult:
+        common["mfma_useful_frac"] = round(tfl_alg / peak, 4)
+        common["mfma_executed_frac"] = round(tfl_alg * mult / peak, 4)
     if t_hbm >= t_mfma:
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), **common,
-                "note": "algorithmic bytes (inputs once + outputs once, DESIGN.md section 4) of every launch of this family in the "
-                        "profiled pass / sum of their HIP-event durations"}
-    return {"bound": "mfma", "achieved": round(tfl_alg * mult, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tfl_alg * mult / peak, 4), **common,
-            "note": f"executed matrix flops = {mult:g} x algorithmic 2*M*N*K (split-bf16x3: three bf16 MFMA products per fp32 product) "
-                    "/ sum of HIP-event durations; dense MFMA peak of the executing instruction"}
+                "note": "algorithmic bytes (inputs once + outputs once at their storage width, DESIGN.md section 4) of every launch of this "
+                        "family in the profiled pass / sum of their HIP-event durations"}
+    return {"bound": "mfma", "achieved": round(tfl_alg, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tfl_alg / peak, 4), **common,
+            "note": "algorithmic matrix flops 2*M*N*K / sum of HIP-event durations against the dense MFMA peak of the instruction issued"
+                    + (f"; the kernel executes {mult:g} MFMA products per algorithmic product (mfma_executed_frac)" if mult > 1 else "")}
 
 
 def pmc_traffic(kernel_family):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE
     passes, gfx950 FETCH x2 correction: profiles/summarize_pmc.py); None when the summary has no matching entry."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
     if not kernel_family or not os.path.exists(path):
         return None
     try:
@@ -122,6 +139,14 @@ def cpu_baseline(cfg, seed, sampler_steps, target_seconds):
     """The CPU oracle (a port of the reference's algorithm: oracle/hdit.py + oracle/solvers.py) timed on
     this host's cores for a bounded sample of the same workload (same weights / noise recipe)."""
     from oracle import hdit, solvers
+    na2d_recorded, hdit.na2d = hdit.na2d, hdit.na2d_shifted     # same op, one window offset at a time (no 49x gather): ~5x faster on the CPU
+    try:
+        return _cpu_baseline(hdit, solvers, cfg, seed, sampler_steps, target_seconds)
+    finally:
+        hdit.na2d = na2d_recorded
+
+
+def _cpu_baseline(hdit, solvers, cfg, seed, sampler_steps, target_seconds):
     mc = cfg["model"]
     cores = min(os.cpu_count(), 32)      # torch's intra-op pool stops scaling (and thrashes) far below 256 threads on these op sizes
     torch.set_num_threads(cores)
@@ -141,8 +166,10 @@ def cpu_baseline(cfg, seed, sampler_steps, target_seconds):
     dt = time.perf_counter() - t0
     per_image = dt / n * sampler_steps
     return {"value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 image, {n} of {sampler_steps} DPM++2M steps with the oracle (torch CPU fp32, {cores} threads), "
-                      f"{dt:.1f} s measured, scaled to {sampler_steps} steps"}
+            "sample": f"1 image, {n} of {sampler_steps} DPM++2M steps of THIS workload with the oracle (oracle/hdit.py + solvers.py: the reference's "
+                      f"algorithm in torch CPU fp32, neighbourhood attention as the restated na2d evaluated per window offset; {cores} threads), "
+                      f"{dt:.1f} s measured, scaled to {sampler_steps} steps.  The reference itself cannot travel to this box; the survey "
+                      "measured it at 0.29 images/s on 8 cores for the shifted-window config (BASELINE.md section 3)"}
 
 
 def secondary_config(path, dev, args, sampler):
@@ -151,7 +178,7 @@ def secondary_config(path, dev, args, sampler):
     model = build_model(cfg, dev, args.seed)
     den = K.Denoiser(model, sigma_data=mc["sigma_data"])
     shape = (mc["input_channels"], *mc["input_size"])
-    x0 = torch.stack([K.synth.synth_noise(shape, args.seed, g, mc["sigma_max"]) for g in range(args.batch)]).to(dev)
+    x0 = K.synth.synth_noise_batch(shape, args.seed, 0, args.batch, mc["sigma_max"]).to(dev)
     sigmas = K.sampling.get_sigmas_karras(args.sampler_steps, mc["sigma_min"], mc["sigma_max"], rho=7., device=dev)
     sampler(den, x0, sigmas, disable=True)
     torch.cuda.synchronize()
@@ -165,11 +192,38 @@ def secondary_config(path, dev, args, sampler):
             "workload": f"{os.path.basename(path)} {mc['input_size'][0]}x{mc['input_size'][1]}, {args.sampler} {args.sampler_steps} steps"}
 
 
+def measure_mode(mode, den, x0, sigmas, extra, sampler, passes=2):
+    """Short measurement of another arithmetic mode on the same box (same model object: plans / packed weights are per mode)."""
+    os.environ["KDIFF_GEMM"] = mode
+    sampler(den, x0, sigmas, extra_args=extra, disable=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        out = sampler(den, x0, sigmas, extra_args=extra, disable=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    return {"value": round(passes * x0.shape[0] / dt, 3), "unit": "images/sec", "steps": passes, "warmup": 1, "dtype": MODE_DTYPE[mode][0], "dtype_note": MODE_DTYPE[mode][1]}, out
+
+
+MODE_DTYPE = {
+    "bf16": ("bf16", "bf16 activations in HBM (residual stream, qkv, attention out, FF hidden), one bf16 MFMA per product, fp32 accumulation, fp32 RMS "
+                     "statistics / softmax / GELU / RoPE; fp32 image, solver state and conditioning chain -- the arithmetic of the reference under "
+                     "torch.autocast(bfloat16); parity gates 2e-2 per forward / 1.5e-2 end to end against the fp32 reference (tests/test_model_gpu.py)"),
+    "split3": ("f32", "fp32-parity mode: fp32 in HBM, fp32 accumulation everywhere; matrix products as 3 split-bf16 MFMA terms per fp32 product "
+                      "(hi*hi + hi*lo + lo*hi, per-product error <= ~2^-15): inside north_star's 1e-3 against the fp32 reference"),
+    "exact": ("f32", "exact fp32-input MFMA (bit-for-bit an fmaf chain)"),
+}
+
+
 def main():
     args = parse()
+    os.environ["KDIFF_GEMM"] = args.mode
     ctx = K.distributed.RankContext()
     if ctx.num_processes != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.num_processes}")
+    if args.gpus > 1:
+        assert torch.distributed.get_world_size() == args.gpus and torch.distributed.get_backend() == "nccl", "one rank per GPU over RCCL"
     if ctx.device.type != "cuda":
         raise SystemExit("bench.py needs an MI355X: no ROCm device visible (there is no CPU fallback for the hot path)")
     dev = ctx.device
@@ -180,7 +234,7 @@ def main():
     B = args.batch
     shape = (mc["input_channels"], *mc["input_size"])
     lo = ctx.process_index * B
-    x0 = torch.stack([K.synth.synth_noise(shape, args.seed, lo + g, mc["sigma_max"]) for g in range(B)]).to(dev)
+    x0 = K.synth.synth_noise_batch(shape, args.seed, lo, B, mc["sigma_max"]).to(dev)
     extra = {}
     if cfg["dataset"]["num_classes"]:
         extra["class_cond"] = (torch.arange(lo, lo + B) % cfg["dataset"]["num_classes"]).to(dev)
@@ -226,14 +280,24 @@ def main():
                 f[k] += g[k]
         if not fam:
             fam = {"(no kernel events recorded)": {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}}
-        split3 = K._native.default_precision() == K._native.PREC_SPLIT3
-        rooflines = {name: family_roofline(name, g, split3, total_ms) for name, g in fam.items() if g["ms"] > 0}
-        dom_name = max(rooflines, key=lambda n: fam[n]["ms"]) if rooflines else None
+        main_ms = sum(g["ms"] for n, g in fam.items() if not n.startswith(SIDE_STREAM))
+        rooflines = {name: family_roofline(name, g, args.mode, main_ms) for name, g in fam.items() if g["ms"] > 0}
+        main_fams = [n for n in rooflines if not n.startswith(SIDE_STREAM)]
+        dom_name = max(main_fams, key=lambda n: fam[n]["ms"]) if main_fams else None
         roofline = dict(rooflines[dom_name]) if dom_name else {"bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0}
         roofline["traffic"] = pmc_traffic(dom_name)
         roofline["measured_on"] = "one extra identical pass right after the timed region, a HIP event pair on the launch stream around every launch"
-        roofline["other_kernels"] = {n: {k: r[k] for k in ("bound", "achieved", "unit", "frac", "share_of_kernel_time", "avg_launch_ms")}
-                                     for n, r in sorted(rooflines.items(), key=lambda kv: -fam[kv[0]]["ms"])[1:6]}
+        keys = ("bound", "achieved", "unit", "frac", "share_of_kernel_time", "avg_launch_ms", "mfma_useful_frac", "mfma_executed_frac", "overlapped")
+        roofline["other_kernels"] = {n: {k: r[k] for k in keys if k in r}
+                                     for n, r in sorted(rooflines.items(), key=lambda kv: -fam[kv[0]]["ms"]) if n != dom_name}
+        # whole path against its own rooflines: the algorithmic bytes / flops of every main-chain launch of the profiled pass
+        tot_b = sum(g["bytes"] for n, g in fam.items() if not n.startswith(SIDE_STREAM))
+        tot_f = sum(g["flops"] for n, g in fam.items() if not n.startswith(SIDE_STREAM))
+        pass_s = dt / args.steps
+        roofline["whole_path"] = {"algorithmic_gb_per_pass": round(tot_b / 1e9, 2), "algorithmic_tflop_per_pass": round(tot_f / 1e12, 3),
+                                  "hbm_frac_of_8TBs": round(tot_b / pass_s / (HBM_PEAK_GBS * 1e9), 4),
+                                  "mfma_useful_frac_of_bf16_peak": round(tot_f / pass_s / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
+                                  "kernel_time_share_of_pass": round(main_ms * 1e-3 / pass_s, 4)}
         if args.kernel_table:
             with open(args.kernel_table, "w") as f:
                 json.dump({"families": fam, "kernels": groups, "timed_seconds": dt}, f, indent=1)
@@ -244,18 +308,25 @@ def main():
             "metric": "images/sec, 256x256 image_transformer_v2, 50-step DPM++2M (whole job)",
             "value": round(n_img / dt, 3), "unit": "images/sec", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32",
-            "dtype_note": ("fp32 in HBM, fp32 accumulation everywhere; matrix products as 3 split-bf16 MFMA terms per fp32 product "
-                           "(hi*hi + hi*lo + lo*hi, per-product error <= ~2^-15; KDIFF_GEMM=exact selects the fp32-input MFMA)") if split3
-                          else "exact fp32-input MFMA (KDIFF_GEMM=exact)",
+            "dtype": MODE_DTYPE[args.mode][0], "mode": args.mode, "dtype_note": MODE_DTYPE[args.mode][1],
             "data": "synthetic (seeded noise, random-init weights incl. re-randomised zero-init projections)",
             "per_gpu": round(n_img / dt / args.gpus, 3),
             "config": {"workload": f"{os.path.basename(args.config)} {mc['input_size'][0]}x{mc['input_size'][1]}, {args.sampler} "
                                    f"{args.sampler_steps} steps, batch {B}/GPU, all-gather of finished images",
-                       "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus} (independent images, one final all-gather)"},
+                       "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus} (independent images, one final all-gather)",
+                       "rccl_nranks": torch.distributed.get_world_size() if args.gpus > 1 else 1},
             "algorithmic_tflops": round(n_img * 2 * mac * (nfe or 0) / dt / 1e12, 2) if nfe else None,
             "roofline": roofline,
         }
+        if args.gpus == 1 and not args.no_other_modes:
+            # the other arithmetic modes of the same build, on the same box, right after the timed region
+            result["modes"] = {args.mode: {"value": result["value"], "unit": "images/sec", "steps": args.steps, "warmup": args.warmup,
+                                           "dtype": result["dtype"]}}
+            for m in ("bf16", "split3", "exact"):
+                if m != args.mode:
+                    result["modes"][m], other = measure_mode(m, den, x0, sigmas, extra, sampler)
+                    result["modes"][m]["max_rel_diff_vs_" + args.mode] = round(float((other - out[:B]).abs().max() / out[:B].abs().max()), 6)
+            os.environ["KDIFF_GEMM"] = args.mode
         if args.gpus == 1 and not args.no_other_configs and os.path.basename(args.config) == "config_oxford_flowers.json":
             # BASELINE configs[2] (the single-GPU 256x256 DPM++2M case with shifted-window attention): same sampler, same
             # batch, 1 warm-up + 2 timed passes.  Reported beside the headline (configs[3] at 32 images / GPU), not as `value`.

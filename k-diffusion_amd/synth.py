@@ -64,3 +64,14 @@ def synth_noise(shape_chw, seed, global_index, sigma_max):
     g = torch.Generator(device="cpu")
     g.manual_seed(((seed << 32) + global_index) & 0x7FFFFFFFFFFFFFFF)
     return torch.randn(shape_chw, generator=g, dtype=torch.float32) * sigma_max
+
+
+def synth_noise_batch(shape_chw, seed, first_index, count, sigma_max):
+    """[count, C, H, W]: ``synth_noise`` of the global indices first_index .. first_index + count - 1 (one generator per image, so
+    a sample's noise does not depend on the batch / rank it is drawn in), written into one pinned-size buffer."""
+    out = torch.empty((count, *shape_chw), dtype=torch.float32)
+    g = torch.Generator(device="cpu")
+    for i in range(count):
+        g.manual_seed(((seed << 32) + first_index + i) & 0x7FFFFFFFFFFFFFFF)
+        torch.randn(shape_chw, generator=g, dtype=torch.float32, out=out[i])
+    return out.mul_(sigma_max)

@@ -200,6 +200,13 @@ def test_na2d_window_starts_literal():
         assert torch.allclose(out[0, qi, qj, 0], want, atol=1e-5), (qi, qj)
 
 
+def test_na2d_shifted_matches():
+    g = torch.Generator().manual_seed(1)
+    for (n, h, w, nh), ks in (((2, 9, 12, 2), 7), ((1, 16, 16, 1), 5), ((1, 7, 7, 1), 7), ((1, 12, 10, 2), 9)):
+        q, k, v = (torch.randn(n, h, w, nh, 64, generator=g) * s for s in (0.4, 0.4, 1.0))
+        assert torch.allclose(hdit.na2d_shifted(q, k, v, ks), hdit.na2d(q, k, v, ks), atol=2e-6)
+
+
 def test_na2d_properties():
     """na2d is parity-unpinned; check the defining properties instead."""
     g = torch.Generator().manual_seed(0)
