@@ -554,6 +554,21 @@ int main(int argc, char** argv) {
     kd_set_option("tiled_bm", 0);
     kd_set_option("wstat", 1);
   }
+  if (want("prefetch")) {
+    for (int pf : {0, 1}) {
+      kd_set_option("wstat_prefetch", pf);
+      printf("-- wstat_prefetch = %d\n", pf);
+      const GemmCase cw[] = {
+          {"prefetch L0 qkv", 131072, 384, 128, KD_EPI_QKV, 1, 4096, 2},
+          {"prefetch L0 geglu", 131072, 384, 128, KD_EPI_GEGLU, 1, 4096, 0},
+          {"prefetch L0 out+res", 131072, 128, 128, KD_EPI_RESIDUAL, 0, 4096, 0},
+          {"prefetch L0 down+res", 131072, 128, 384, KD_EPI_RESIDUAL, 0, 4096, 0},
+          {"prefetch ragged qkv", 4128, 384, 128, KD_EPI_QKV, 1, 96, 2},
+      };
+      for (const auto& c : cw) run_gemm_case(c);
+    }
+    kd_set_option("wstat_prefetch", 1);
+  }
   if (want("waves")) {
     for (int w : {4, 12}) {
       kd_set_option("wstat_waves", w);

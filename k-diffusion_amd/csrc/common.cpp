@@ -1,6 +1,6 @@
 // Error reporting + per-launch event timing shared by all entry points of libkdiff_hip.so.
 #include "kd_common.h"
-#include <map>
+#include <atomic>
 #include <mutex>
 
 namespace kd {
@@ -37,23 +37,38 @@ void prof_end(hipStream_t s) { (void)hipEventRecord(g_recs.back().e1, s); }
 using namespace kd;
 
 // ---- library options (explicit switches instead of environment variables read inside the library) -------------------------
+// A fixed table of named integers; reads on the launch path are one relaxed atomic load (option names are string literals in
+// the callers: the index is resolved once per call site through a function-local static).
 namespace kd {
-static std::mutex g_opt_mu;
-static std::map<std::string, int> g_opts;
-int option(const char* name, int dflt) {
-  std::lock_guard<std::mutex> lk(g_opt_mu);
-  auto it = g_opts.find(name);
-  return it == g_opts.end() ? dflt : it->second;
+namespace {
+struct Opt { const char* name; std::atomic<int> value; std::atomic<bool> set; };
+Opt g_opts[] = {{"skinny", {0}, {false}}, {"astat", {0}, {false}}, {"ksplit", {0}, {false}}, {"astat_max_k", {0}, {false}}, {"astat_waves", {0}, {false}},
+                {"astat_storewait", {0}, {false}}, {"gemm_debug", {0}, {false}}, {"bf16_fast", {0}, {false}}, {"wstat", {0}, {false}},
+                {"wstat_waves", {0}, {false}}, {"wstat_max_slices", {0}, {false}}, {"wstat_prefetch", {0}, {false}}, {"astat_bf16", {0}, {false}},
+                {"astat_splits", {0}, {false}}, {"astat_stages", {0}, {false}}, {"tiled_bm", {0}, {false}}, {"attn_global_qw", {0}, {false}},
+                {"attn_na_variant", {0}, {false}}, {"x0", {0}, {false}}, {"x1", {0}, {false}}, {"x2", {0}, {false}}, {"x3", {0}, {false}}};
+constexpr int N_OPTS = sizeof(g_opts) / sizeof(g_opts[0]);
+}  // namespace
+int option_index(const char* name) {
+  for (int i = 0; i < N_OPTS; ++i)
+    if (!strcmp(g_opts[i].name, name)) return i;
+  return -1;
+}
+int option_at(int idx, int dflt) {
+  if (idx < 0) return dflt;
+  return g_opts[idx].set.load(std::memory_order_relaxed) ? g_opts[idx].value.load(std::memory_order_relaxed) : dflt;
 }
 }  // namespace kd
 
 extern "C" int kd_set_option(const char* name, int value) {
   if (!name) return fail(KD_EINVAL, "kd_set_option: null name");
-  std::lock_guard<std::mutex> lk(g_opt_mu);
-  g_opts[name] = value;
+  const int i = option_index(name);
+  if (i < 0) return fail(KD_EINVAL, "kd_set_option: unknown option '%s'", name);
+  g_opts[i].value.store(value, std::memory_order_relaxed);
+  g_opts[i].set.store(true, std::memory_order_relaxed);
   return KD_OK;
 }
-extern "C" int kd_get_option(const char* name, int dflt) { return name ? option(name, dflt) : dflt; }
+extern "C" int kd_get_option(const char* name, int dflt) { return name ? option_at(option_index(name), dflt) : dflt; }
 
 extern "C" int kd_version(void) { return 200; }
 extern "C" const char* kd_last_error(void) { return err_buf(); }

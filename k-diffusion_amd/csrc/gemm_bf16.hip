@@ -27,7 +27,10 @@ struct GArgs {
 
 // ------------------------------------------------------------------------------------------------------------------
 // wstat
-template <int NC /* K / 16 */, int EPI, bool NORM, int NW>
+// PF: the NEXT chunk's rows are requested before the current chunk is processed (one extra set of raw fragments in registers):
+// with 2 waves per SIMD the other wave alone does not cover a chunk's HBM latency.  Every wave walks a CONTIGUOUS range of
+// chunks (same sample for most consecutive chunks: the scale vector stays in L1).
+template <int NC /* K / 16 */, int EPI, bool NORM, int NW, bool PF>
 __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
   constexpr int K = NC * 16, NK = NC / 4;
   constexpr bool GEGLU = EPI == KD_EPI_GEGLU;
@@ -56,7 +59,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
   for (int cc = 0; cc < 4; ++cc) off4[cc] = swz128(l31, 2 * cc + lh);
 
   const int chunks = (p.M + 31) >> 5;
-  for (int ch = grp * NW + wid; ch < chunks; ch += ngrp * NW) {
+  const int nwaves = ngrp * NW, cpw = (chunks + nwaves - 1) / nwaves;
+  const int ch0 = (grp * NW + wid) * cpw, ch1 = min(ch0 + cpw, chunks);
+  auto load_raw = [&](int ch, u32x4 (&raw)[NC]) {
+    const u32x4* ap = reinterpret_cast<const u32x4*>(p.A + (size_t)min(ch * 32 + l31, p.M - 1) * K + 8 * lh);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) raw[c] = ap[2 * c];
+  };
+  u32x4 nxt[PF ? NC : 1];
+  if (PF && ch0 < ch1) load_raw(ch0, reinterpret_cast<u32x4(&)[NC]>(nxt));
+  for (int ch = ch0; ch < ch1; ++ch) {
     const int row = ch * 32 + l31;
     const bool ok = row < p.M;
     const int rowc = ok ? row : p.M - 1;
@@ -65,26 +77,42 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
     bf16x8 a[NC];
     float rs = 1.0f;
     {
-      const u32x4* ap = reinterpret_cast<const u32x4*>(p.A + (size_t)rowc * K + 8 * lh);
       u32x4 raw[NC];
+      if (PF) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) raw[c] = ap[2 * c];
+        for (int c = 0; c < NC; ++c) raw[c] = nxt[PF ? c : 0];
+        if (ch + 1 < ch1) load_raw(ch + 1, reinterpret_cast<u32x4(&)[NC]>(nxt));
+      } else {
+        load_raw(ch, raw);
+      }
       if (NORM) {
         const int b = rowc / p.rows_per_sample;
         const float* sp = p.scale + (size_t)b * p.scale_stride + 8 * lh;
         float ssq = 0.f;
+        // the scale vector in groups of 8 chunks, every load of a group requested before the first is used (one L2 round trip
+        // per group instead of one per chunk)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp + 16 * c), s1 = *reinterpret_cast<const f32x4*>(sp + 16 * c + 4);
-          float x[8];
+        for (int c0 = 0; c0 < NC; c0 += 8) {
+          f32x4 s0[8], s1[8];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { x[2 * u] = bf_lo(raw[c][u]); x[2 * u + 1] = bf_hi(raw[c][u]); }
+          for (int u = 0; u < 8; ++u) {
+            s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
+            s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int u = 0; u < 8; ++u) ssq = fmaf(x[u], x[u], ssq);
-          u32x4 o = {pack_bf16(x[0] * s0[0], x[1] * s0[1]), pack_bf16(x[2] * s0[2], x[3] * s0[3]),
-                     pack_bf16(x[4] * s1[0], x[5] * s1[1]), pack_bf16(x[6] * s1[2], x[7] * s1[3])};
-          asm volatile("" : "+v"(o));    // materialise the fragment here (see the astat kernel)
-          a[c] = __builtin_bit_cast(bf16x8, o);
+          for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[2 * e] = bf_lo(raw[c][e]); x[2 * e + 1] = bf_hi(raw[c][e]); }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ssq = fmaf(x[e], x[e], ssq);
+            u32x4 o = {pack_bf16(x[0] * s0[u][0], x[1] * s0[u][1]), pack_bf16(x[2] * s0[u][2], x[3] * s0[u][3]),
+                       pack_bf16(x[4] * s1[u][0], x[5] * s1[u][1]), pack_bf16(x[6] * s1[u][2], x[7] * s1[u][3])};
+            asm volatile("" : "+v"(o));    // materialise the fragment here (see the astat kernel)
+            a[c] = __builtin_bit_cast(bf16x8, o);
+          }
         }
         ssq += __shfl_xor(ssq, 32, 64);
         rs = rsqrtf(ssq / (float)K + p.eps);
@@ -114,17 +142,31 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
       const char* wt = smem + (size_t)t * NK * WBLK;
+      // weight fragments of chunk c + 1 are requested before the 4 MFMAs of chunk c (explicit double buffer: left alone hipcc
+      // reads two fragments, waits, issues two MFMAs -- the LDS latency shows on every pair)
+      bf16x8 wf[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[0][j] = *reinterpret_cast<const bf16x8*>(wt + off4[0] + j * 32 * 128);
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const char* wk = wt + (c >> 2) * WBLK + off4[c & 3];
+        if (c + 1 < NC) {
+          const char* wk = wt + ((c + 1) >> 2) * WBLK + off4[(c + 1) & 3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wk + j * 32 * 128);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, a[c], acc[j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) wf[(c + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(wk + j * 32 * 128);
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c & 1][j], a[c], acc[j], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int c = 0; c + 1 < NC; ++c) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       // ---- epilogue, in the lane that owns the row ---------------------------------------------------------------------------
       u16* crow = p.C + (size_t)rowc * p.N;
+      const bool st_ok = ok;
       if (GEGLU) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
@@ -137,7 +179,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
             v[r + 1] = o.y;
           }
           const int nb = n0 + 32 * jj;
-          store_block_bf16(crow + min(nb, p.N - 32), v, lh, ok && nb < p.N);
+          store_block_bf16(crow + min(nb, p.N - 32), v, lh, st_ok && nb < p.N);
         }
       } else if (EPI == KD_EPI_QKV) {
 #pragma unroll
@@ -158,7 +200,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = acc[2 * vv + jj][r];
-            store_block_bf16(crow + n0 + 64 * vv + 32 * jj, v, lh, ok);
+            store_block_bf16(crow + n0 + 64 * vv + 32 * jj, v, lh, st_ok);
           }
         }
       } else {
@@ -174,7 +216,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] += rr[r];
           }
-          store_block_bf16(crow + min(nb, p.N - 32), v, lh, ok && nb < p.N);
+          store_block_bf16(crow + min(nb, p.N - 32), v, lh, st_ok && nb < p.N);
         }
       }
     }
@@ -193,9 +235,9 @@ static int cu_count() {
 
 constexpr int WSTAT_LDS_MAX = 144 * 1024;
 
-template <int NC, int EPI, bool NORM, int NW>
+template <int NC, int EPI, bool NORM, int NW, bool PF>
 static int launch_wstat(const GArgs& a, int lds, const char* nm, double flops, double bytes, hipStream_t s) {
-  auto kern = gemm_wstat_kernel<NC, EPI, NORM, NW>;
+  auto kern = gemm_wstat_kernel<NC, EPI, NORM, NW, PF>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WSTAT_LDS_MAX);
@@ -244,7 +286,13 @@ int gemm_wstat_try(const KdGemm& d, hipStream_t s, int* rc) {
   const double bytes = 2.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N) + (d.epi == KD_EPI_RESIDUAL ? 2.0 * d.M * d.N : 0.0);
   char nm[96] = "gemm_wstat";
   if (prof_on()) snprintf(nm, sizeof(nm), "gemm_bf16_wstat<e%d,n%d> M=%d N=%d K=%d", d.epi, d.norm, d.M, d.N, d.K);
-#define KD_WS(NCV, EP, NO, NWV) { *rc = launch_wstat<NCV, EP, NO, NWV>(a, lds, nm, flops, bytes, s); return 0; }
+  const bool pf = option("wstat_prefetch", 1) != 0;
+#define KD_WS(NCV, EP, NO, NWV)                                                                   \
+  {                                                                                               \
+    *rc = (pf && NCV <= 16) ? launch_wstat<NCV, EP, NO, NWV, (NCV <= 16)>(a, lds, nm, flops, bytes, s)  \
+                            : launch_wstat<NCV, EP, NO, NWV, false>(a, lds, nm, flops, bytes, s); \
+    return 0;                                                                                     \
+  }
 #define KD_WS_ALL(NCV, NWV)                                                       \
   {                                                                               \
     if (d.epi == KD_EPI_QKV) KD_WS(NCV, KD_EPI_QKV, true, NWV)                    \

@@ -25,7 +25,10 @@ struct GemmP : KdGemm {
 // ---- error reporting (thread-local message, C ABI returns a code) -------------------------------
 char* err_buf();
 int fail(int code, const char* fmt, ...);
-int option(const char* name, int dflt);   // kd_set_option() values (tuning / A-B switches), thread-safe
+// kd_set_option() values (tuning / A-B switches), thread-safe; `option("name", dflt)` with a string LITERAL costs one atomic load
+int option_index(const char* name);
+int option_at(int idx, int dflt);
+#define option(name, dflt) ::kd::option_at([]() -> int { static const int idx_ = ::kd::option_index(name); return idx_; }(), (dflt))
 
 // ---- per-launch profiling (bench.py): hipEvent pairs around launches when enabled ---------------
 struct ProfRec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
