@@ -200,10 +200,22 @@ static void run_gemm_case(const GemmCase& c) {
     }
   }
   const float us = time_us([&] { kd_gemm_bf16(&d, nullptr); });
+  char clk_note[64] = "";
+  if (strstr(c.name, "wstat") || strstr(c.name, "clock")) {       // shader clock under this kernel's load (s_memtime vs the 100 MHz s_memrealtime)
+    DevBuf<unsigned long long> dClk(4);
+    HIPCHK(hipMemset(dClk.p, 0, 32));
+    kd_prof_clock_buffer(dClk.p);
+    for (int i = 0; i < 20; ++i) kd_gemm_bf16(&d, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    kd_prof_clock_buffer(nullptr);
+    auto ck = dClk.down();
+    if (ck[3] > ck[1]) snprintf(clk_note, sizeof(clk_note), "  clk %.2f GHz", (double)(ck[2] - ck[0]) / (double)(ck[3] - ck[1]) * 0.1);
+  }
   const double flops = 2.0 * M * (double)NW * K;
   const double bytes = 2.0 * ((double)M * K + (double)M * N + ((c.epi == KD_EPI_RESIDUAL || split) ? (double)M * N : 0.0));
   printf("%-28s M=%6d N=%4d K=%4d  max|err|=%.4g (max|ref|=%.3g) bad=%ld  %8.1f us  %7.1f TF/s  %6.0f GB/s  %s\n", c.name, M, N, K, max_err, max_ref, bad,
          us, flops / us * 1e-6, bytes / us * 1e-3, bad ? "FAIL" : "ok");
+  if (clk_note[0]) printf("%s\n", clk_note);
   if (bad) ++g_fail;
 }
 
@@ -555,8 +567,9 @@ int main(int argc, char** argv) {
     kd_set_option("wstat", 1);
   }
   if (want("prefetch")) {
-    for (int pf : {0, 1}) {
-      kd_set_option("wstat_prefetch", pf);
+    for (int pf : {0, 1, 2, 6}) {
+      kd_set_option("wstat_prefetch", pf & 3);
+      kd_set_option("wstat_waves", pf == 6 ? 4 : 0);
       printf("-- wstat_prefetch = %d\n", pf);
       const GemmCase cw[] = {
           {"prefetch L0 qkv", 131072, 384, 128, KD_EPI_QKV, 1, 4096, 2},
@@ -567,7 +580,8 @@ int main(int argc, char** argv) {
       };
       for (const auto& c : cw) run_gemm_case(c);
     }
-    kd_set_option("wstat_prefetch", 1);
+    kd_set_option("wstat_prefetch", 0);
+    kd_set_option("wstat_waves", 0);
   }
   if (want("waves")) {
     for (int w : {4, 12}) {

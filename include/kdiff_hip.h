@@ -237,6 +237,9 @@ int kd_prof_enable(int on);
 int kd_prof_count(void);
 int kd_prof_get(int i, char* name, int name_cap, float* ms, double* flops, double* bytes);
 int kd_prof_reset(void);
+/* Shader-clock probe (benchmarks/): while `dev_ptr` (4 x uint64 of device memory) is set, workgroup 0 of the W-stationary bf16 GEMM
+ * writes {s_memtime, s_memrealtime} at entry and at exit: clock under load = d(memtime) / d(realtime) x 100 MHz.  NULL switches it off. */
+int kd_prof_clock_buffer(void* dev_ptr);
 
 #ifdef __cplusplus
 }

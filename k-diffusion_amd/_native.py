@@ -92,6 +92,7 @@ SIGNATURES = {
     "kd_prof_count": [],
     "kd_prof_get": [_i, C.c_char_p, _i, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "kd_prof_reset": [],
+    "kd_prof_clock_buffer": [_vp],
 }
 
 _lib = None

@@ -23,6 +23,7 @@ struct GArgs {
   int n_tiles;              // packed n-tiles in total
   int tiles_per_slice, n_slices;
   int n_heads; const float* qk_scale; const float* pos; const float* freq;
+  unsigned long long* clk;  // kd_prof_clock_buffer: {s_memtime, s_memrealtime} at entry and exit of workgroup 0 (shader clock under load)
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -30,7 +31,7 @@ struct GArgs {
 // PF: the NEXT chunk's rows are requested before the current chunk is processed (one extra set of raw fragments in registers):
 // with 2 waves per SIMD the other wave alone does not cover a chunk's HBM latency.  Every wave walks a CONTIGUOUS range of
 // chunks (same sample for most consecutive chunks: the scale vector stays in L1).
-template <int NC /* K / 16 */, int EPI, bool NORM, int NW, bool PF>
+template <int NC /* K / 16 */, int EPI, bool NORM, int NW, bool PF, bool PIPE>
 __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
   constexpr int K = NC * 16, NK = NC / 4;
   constexpr bool GEGLU = EPI == KD_EPI_GEGLU;
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
   const int slice = blockIdx.x % p.n_slices, grp = blockIdx.x / p.n_slices, ngrp = gridDim.x / p.n_slices;
   const int nt0 = slice * p.tiles_per_slice;
   const int ntn = min(p.tiles_per_slice, p.n_tiles - nt0);
+  if (p.clk && blockIdx.x == 0 && tid == 0) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
 
   // ---- park this slice of the packed weight in LDS (lane-linear copy, 1 KiB per wave-instruction) --------------------------
   {
@@ -128,22 +130,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
       px = p.pos[2 * tok + 1];
     }
 
-    for (int t = 0; t < ntn; ++t) {
-      const int n0 = (nt0 + t) * NCOL;
-      // residual operand of this tile, requested before the products
-      u32x4 rraw[4][2];
-      if (EPI == KD_EPI_RESIDUAL) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) load_block_raw(p.R + (size_t)rowc * p.N + min(n0 + 32 * j, p.N - 32), rraw[j], lh);
-      }
-      f32x16 acc[4];
+    // ---- the tiles of this slice.  mma(t): products of tile t into an accumulator set; epi(t): its epilogue, in the lane
+    // that owns the row.  PIPE: two accumulator sets -- the epilogue of tile t is issued BETWEEN the MFMAs of tile t + 1 (one
+    // MFMA, then ~10 VALU instructions of the epilogue, one fragment read, ...): the matrix pipe works through a 32-clock MFMA
+    // while the same wave's VALU instructions issue, instead of the two phases taking turns (they add up otherwise: measured).
+    u16* crow = p.C + (size_t)rowc * p.N;
+    auto mma = [&](int t, f32x16 (&acc)[4], bool pin) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
       const char* wt = smem + (size_t)t * NK * WBLK;
-      // weight fragments of chunk c + 1 are requested before the 4 MFMAs of chunk c (explicit double buffer: left alone hipcc
-      // reads two fragments, waits, issues two MFMAs -- the LDS latency shows on every pair)
+      // weight fragments of chunk c + 1 are requested before the 4 MFMAs of chunk c (explicit double buffer)
       bf16x8 wf[2][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) wf[0][j] = *reinterpret_cast<const bf16x8*>(wt + off4[0] + j * 32 * 128);
@@ -157,15 +155,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c & 1][j], a[c], acc[j], 0, 0, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-      for (int c = 0; c + 1 < NC; ++c) {
+      if (pin) {
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int c = 0; c + 1 < NC; ++c) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      // ---- epilogue, in the lane that owns the row ---------------------------------------------------------------------------
-      u16* crow = p.C + (size_t)rowc * p.N;
+    };
+    auto epi = [&](int t, f32x16 (&acc)[4], u32x4 (&rraw)[4][2]) {
+      const int n0 = (nt0 + t) * NCOL;
       const bool st_ok = ok;
       if (GEGLU) {
 #pragma unroll
@@ -219,9 +220,53 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
           store_block_bf16(crow + min(nb, p.N - 32), v, lh, st_ok && nb < p.N);
         }
       }
+    };
+    u32x4 rraw[4][2];
+    if (PIPE) {
+      // issue pattern of one "MFMAs of the next tile + epilogue of this tile" region
+      auto interleave = [&]() {
+        constexpr int VPM = 10;                                // VALU instructions between two MFMAs (epilogue ~ 10 per MFMA)
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int i = 0; i < 4 * NC; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+          if (i < 4 * NC - 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      };
+      f32x16 accA[4], accB[4];
+      mma(0, accA, true);
+      int t = 0;
+      for (; t + 1 < ntn; t += 2) {
+        mma(t + 1, accB, false);
+        epi(t, accA, rraw);
+        interleave();
+        if (t + 2 < ntn) {
+          mma(t + 2, accA, false);
+          epi(t + 1, accB, rraw);
+          interleave();
+        } else {
+          epi(t + 1, accB, rraw);
+        }
+      }
+      if (t < ntn) epi(t, accA, rraw);
+    } else {
+      for (int t = 0; t < ntn; ++t) {
+        if (EPI == KD_EPI_RESIDUAL) {      // residual operand of this tile, requested before the products
+          const int n0 = (nt0 + t) * NCOL;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) load_block_raw(p.R + (size_t)rowc * p.N + min(n0 + 32 * j, p.N - 32), rraw[j], lh);
+        }
+        f32x16 acc[4];
+        mma(t, acc, true);
+        epi(t, acc, rraw);
+      }
     }
   }
+  if (p.clk && blockIdx.x == 0 && tid == 0) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
 }
+
+unsigned long long* g_clk = nullptr;
 
 static int cu_count() {
   static int n = 0;
@@ -235,9 +280,9 @@ static int cu_count() {
 
 constexpr int WSTAT_LDS_MAX = 144 * 1024;
 
-template <int NC, int EPI, bool NORM, int NW, bool PF>
+template <int NC, int EPI, bool NORM, int NW, bool PF, bool PIPE>
 static int launch_wstat(const GArgs& a, int lds, const char* nm, double flops, double bytes, hipStream_t s) {
-  auto kern = gemm_wstat_kernel<NC, EPI, NORM, NW, PF>;
+  auto kern = gemm_wstat_kernel<NC, EPI, NORM, NW, PF, PIPE>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WSTAT_LDS_MAX);
@@ -280,18 +325,24 @@ int gemm_wstat_try(const KdGemm& d, hipStream_t s, int* rc) {
   a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample > 0 ? d.rows_per_sample : d.M; a.eps = d.eps;
   a.M = d.M; a.N = d.N; a.n_tiles = n_tiles; a.tiles_per_slice = tps; a.n_slices = n_slices;
   a.n_heads = d.n_heads; a.qk_scale = d.qk_scale; a.pos = d.rope_pos; a.freq = d.rope_freq;
+  a.clk = g_clk;
   const int lds = tps * nk * WBLK;
   const double n_eff = geglu ? 2.0 * d.N : (double)d.N;
   const double flops = 2.0 * d.M * n_eff * d.K;
   const double bytes = 2.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N) + (d.epi == KD_EPI_RESIDUAL ? 2.0 * d.M * d.N : 0.0);
   char nm[96] = "gemm_wstat";
   if (prof_on()) snprintf(nm, sizeof(nm), "gemm_bf16_wstat<e%d,n%d> M=%d N=%d K=%d", d.epi, d.norm, d.M, d.N, d.K);
-  const bool pf = option("wstat_prefetch", 1) != 0;
-#define KD_WS(NCV, EP, NO, NWV)                                                                   \
-  {                                                                                               \
-    *rc = (pf && NCV <= 16) ? launch_wstat<NCV, EP, NO, NWV, (NCV <= 16)>(a, lds, nm, flops, bytes, s)  \
-                            : launch_wstat<NCV, EP, NO, NWV, false>(a, lds, nm, flops, bytes, s); \
-    return 0;                                                                                     \
+  // 0 plain (default), 1 next-chunk prefetch, 2 software-pipelined tiles (qkv / GEGLU at K = 128).  All three measure the same
+  // within noise (profiles/r02_wstat_ablation.md): under these kernels the chip runs at 1.6-2.2 GHz (s_memtime / s_memrealtime),
+  // i.e. against its power limit, where re-arranging the same work buys nothing
+  const int pf = option("wstat_prefetch", 0);
+#define KD_WS(NCV, EP, NO, NWV)                                                                                        \
+  {                                                                                                                    \
+    constexpr bool can_pipe = NCV == 8 && (EP == KD_EPI_QKV || EP == KD_EPI_GEGLU);                                    \
+    if (pf == 2 && can_pipe) *rc = launch_wstat<NCV, EP, NO, NWV, false, can_pipe>(a, lds, nm, flops, bytes, s);       \
+    else if (pf >= 1 && NCV <= 16) *rc = launch_wstat<NCV, EP, NO, NWV, (NCV <= 16), false>(a, lds, nm, flops, bytes, s); \
+    else *rc = launch_wstat<NCV, EP, NO, NWV, false, false>(a, lds, nm, flops, bytes, s);                              \
+    return 0;                                                                                                          \
   }
 #define KD_WS_ALL(NCV, NWV)                                                       \
   {                                                                               \
@@ -1053,6 +1104,11 @@ __global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* __re
 }  // namespace kd
 
 using namespace kd;
+
+extern "C" int kd_prof_clock_buffer(void* dev_ptr) {
+  b16::g_clk = reinterpret_cast<unsigned long long*>(dev_ptr);
+  return KD_OK;
+}
 
 extern "C" long long kd_packed_weight_bytes_bf16(int N, int K, int geglu) {
   if (N <= 0 || K <= 0) return 0;
