@@ -36,7 +36,8 @@ const char* kd_last_error(void);
  *   fp32 kernels : "skinny" (1) "astat" (1) "ksplit" (1) "astat_max_k" (512) "astat_waves" (4) "astat_storewait" (0)
  *                  "gemm_debug" (0; profiling ablations of benchmarks/: 1 no C stores, 2 no MFMA, 8 GEGLU without erf)
  *   bf16 kernels : "bf16_fast" (1; 0 = generic kernel only) "wstat" (1) "wstat_waves" (0 = per shape) "wstat_max_slices" (24)
- *                  "astat_bf16" (1) "astat_splits" (0 = auto) "tiled_bm" (0 = auto, 128, 256) "attn_global_qw" (8) */
+ *                  "wstat_prefetch" (0; 1 next-chunk prefetch, 2 software-pipelined tiles) "astat_bf16" (1) "astat_splits" (0 = auto)
+ *                  "tiled_bm" (0 = auto, 128, 256) "attn_global_qw" (8) "patch_fast" (1; 0 = patch-in / patch-out through the generic kernel) */
 int kd_set_option(const char* name, int value);
 int kd_get_option(const char* name, int dflt);
 

@@ -8,7 +8,7 @@
 // qkv is the bf16 output of the qkv GEMM [tokens, 3, nh, 64] with q, k ALREADY prepared (cosine-sim scale + RoPE in that GEMM's
 // epilogue); out is bf16 [tokens, nh * 64].  One scheme for all three cores:
 //   * K rows and V rows go HBM -> LDS by global_load_lds, 8 rows x 128 bytes per wave-instruction, as row-major [key][64] images
-//     whose 16-byte chunks are XOR-swizzled on the source side (bf16_common.h swz128): no staging VALU work, no ds_write pass;
+//     whose 16-byte chunks are XOR-swizzled on the source side (asw() below): no staging VALU work, no ds_write pass;
 //   * S^T = K Q^T : K rows are the MFMA A operand (conflict-free ds_read_b128), Q the B operand straight from HBM registers; a
 //     lane owns ONE query (column) and 16 keys per 32-key tile, so the softmax reductions are in-lane plus one half-wave shuffle;
 //   * O^T = V^T P^T : P (fp32 -> bf16 in registers) is the B operand as it sits in the accumulators; the V^T fragments come out
@@ -54,30 +54,76 @@ __device__ __forceinline__ void glds16(const void* src, void* dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
 
-// V^T fragment of one MFMA: 8 k-slots = image rows key0 .. key0+3 and key0+8 .. key0+11, feature 32 * eb + (lane & 31)
+// 16-byte chunk swizzle of the K / V images (rows of 128 bytes): chunk q of row r sits at q ^ asw(r).  Bit 2 of the XOR word comes
+// from r bit 1, so the four rows r .. r + 3 of a ds_read_b64_tr_b16 group land in four different 64-byte quarters of the 256-byte
+// bank row (the GEMM images' (r >> 1) & 7 puts rows r, r + 2 into the same quarter: two-way conflicts on every V^T read), while
+// 16 consecutive rows still take 16 different (half, slot) positions for the ds_read_b128 of the K fragments.
+// asw(r + 8) = asw(r) ^ 2, asw(r + 16) = asw(r).
+__device__ __forceinline__ int asw(int row) { return ((row & 2) << 1) | ((row >> 2) & 3); }
+
+// V^T fragments of one k-step (8 k-slots = image rows key0 .. key0+3 and key0+8 .. key0+11; features 32 e + (lane & 31), e = 0, 1)
+// through ds_read_b64_tr_b16.  `va` = vt_addr(row key0 + ((lane & 15) >> 2), lane): the e = 1 chunk is `^ 64`, the +8 row is
+// `^ 32` and 1024 bytes further.
 using s16x4 = short __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 vt_frag(const char* vimg, int key0, int eb, int lane) {
-  const int r0 = key0 + ((lane & 15) >> 2);
-  const int chunk = 4 * eb + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1), sub = (lane & 1) * 8;
-  const int r1 = r0 + 8;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (s16x4 __attribute__((address_space(3)))*)(vimg + r0 * 128 + ((chunk ^ ((r0 >> 1) & 7)) << 4) + sub));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (s16x4 __attribute__((address_space(3)))*)(vimg + r1 * 128 + ((chunk ^ ((r1 >> 1) & 7)) << 4) + sub));
+__device__ __forceinline__ int vt_lane_row(int lane) { return (lane & 15) >> 2; }
+__device__ __forceinline__ int vt_addr(int r0, int lane) {
+  const int c = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+  return r0 * 128 + ((c ^ asw(r0)) << 4) + (lane & 1) * 8;
+}
+__device__ __forceinline__ bf16x8 vt_read(const char* vimg, int a_lo) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vimg + a_lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(vimg + (a_lo ^ 32) + 1024));
   const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
   return __builtin_bit_cast(bf16x8, u32x4{l2[0], l2[1], h2[0], h2[1]});
+}
+// O^T (two feature blocks) += V^T P^T for one k-step
+__device__ __forceinline__ void pv_step(f32x16 (&O)[2], const char* vimg, int va, const bf16x8 pf) {
+  O[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt_read(vimg, va), pf, O[0], 0, 0, 0);
+  O[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt_read(vimg, va ^ 64), pf, O[1], 0, 0, 0);
 }
 // 8 probabilities (accumulator registers 8u .. 8u+7 of a score tile) -> B-operand fragment
 __device__ __forceinline__ bf16x8 p_frag(const f32x16& S, int u) {
   return __builtin_bit_cast(bf16x8, u32x4{pack_bf16(S[8 * u], S[8 * u + 1]), pack_bf16(S[8 * u + 2], S[8 * u + 3]),
                                           pack_bf16(S[8 * u + 4], S[8 * u + 5]), pack_bf16(S[8 * u + 6], S[8 * u + 7])});
 }
-__device__ __forceinline__ void store_o(u16* orow, f32x16 (&O)[2][2], float inv, int lh, bool ok) {
+// v_max3_f32 / v_min3_f32 through the compiler's own pattern (NOT inline asm: the hazard recogniser does not look inside asm
+// operands, and an asm VALU read of a just-written MFMA result misses its wait states -- seen as wrong scores on hardware)
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float min3f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+// row maximum of a lane's (masked) scores over NT tiles, both half-waves
+template <int NT>
+__device__ __forceinline__ float score_max(const f32x16 (&S)[NT]) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) m = max3f(m, S[t][i], S[t][i + 1]);
+  return fmaxf(m, __shfl_xor(m, 32, 64));
+}
+// S <- exp(S - m) in place (v_exp_f32 on a packed fma), returns this lane's partial row sum
+template <int NT>
+__device__ __forceinline__ float score_exp(f32x16 (&S)[NT], float m) {
+  constexpr float LOG2E = 1.4426950408889634f;
+  const f32x2 mb = {-m * LOG2E, -m * LOG2E};
+  f32x2 l2 = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const f32x2 x = __builtin_elementwise_fma(f32x2{S[t][i], S[t][i + 1]}, f32x2{LOG2E, LOG2E}, mb);
+      const f32x2 pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+      S[t][i] = pv.x;
+      S[t][i + 1] = pv.y;
+      l2 += pv;
+    }
+  return l2.x + l2.y;
+}
+__device__ __forceinline__ void store_o(u16* orow, const f32x16 (&O)[2], float inv, int lh, bool ok) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     float v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = (O[e][0][r] + O[e][1][r]) * inv;
+    for (int r = 0; r < 16; ++r) v[r] = O[e][r] * inv;
     store_block_bf16(orow + 32 * e, v, lh, ok);
   }
 }
@@ -110,7 +156,7 @@ __global__ __launch_bounds__(QW * 64, (QW <= 4 && MODE != MODE_WINDOW16) ? 2 : 1
   for (int pc = wid; pc < TP / 8; pc += QW) {
     const int row = 8 * pc + (lane >> 3);
     const int tok = slot_token<MODE>(a, min(row, T - 1), wi, wj);
-    const int q = (lane & 7) ^ ((row >> 1) & 7);
+    const int q = (lane & 7) ^ asw(row);
     const char* src = base + (size_t)tok * row_bytes + q * 16;
     glds16(src + a.nh * DH * 2, Kimg + pc * 1024);
     glds16(src + 2 * a.nh * DH * 2, Vimg + pc * 1024);
@@ -135,60 +181,46 @@ __global__ __launch_bounds__(QW * 64, (QW <= 4 && MODE != MODE_WINDOW16) ? 2 : 1
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
+  const int ka = l31 * 128 + ((h2 ^ asw(l31)) << 4);          // K fragment of tile t, k-step st: (ka ^ 32 st) + 4096 t
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kimg + swz128(32 * t + l31, 2 * st + h2));
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kimg + (ka ^ (32 * st)) + 4096 * t);
       S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], S[t], 0, 0, 0);
     }
   }
   // ---- masks + softmax over keys -----------------------------------------------------------------------------------------------
   const int q_region = (MODE != MODE_GLOBAL) ? slot_region<MODE>(min(q_slot, T - 1), wi, wj, a.shift) : 0;
-  float m = -INFINITY;
+  if (MODE != MODE_GLOBAL || (T & 31)) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int ks = t * 32 + mfma32_row(i, lane);
-      if (MODE == MODE_GLOBAL) {
-        if (t * 32 + 32 > T) S[t][i] += (ks < T) ? 0.f : -INFINITY;
-      } else {
-        if ((1 << (2 * WinLog2<MODE>::v)) < TP) S[t][i] += (ks < T) ? 0.f : -INFINITY;
-        if (a.shift) S[t][i] += (slot_region<MODE>(min(ks, T - 1), wi, wj, a.shift) == q_region) ? 0.f : -INFINITY;
+      for (int i = 0; i < 16; ++i) {
+        const int ks = t * 32 + mfma32_row(i, lane);
+        if (MODE == MODE_GLOBAL) {
+          if (t * 32 + 32 > T) S[t][i] += (ks < T) ? 0.f : -INFINITY;
+        } else {
+          if ((1 << (2 * WinLog2<MODE>::v)) < TP) S[t][i] += (ks < T) ? 0.f : -INFINITY;
+          if (a.shift) S[t][i] += (slot_region<MODE>(min(ks, T - 1), wi, wj, a.shift) == q_region) ? 0.f : -INFINITY;
+        }
       }
-      m = fmaxf(m, S[t][i]);
-    }
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
-  float l = 0.f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float pv = __expf(S[t][i] - m);
-      S[t][i] = pv;
-      l += pv;
-    }
+  }
+  const float m = score_max<NT>(S);
+  float l = score_exp<NT>(S, m);
   l += __shfl_xor(l, 32, 64);
 
   // ---- O^T = V^T P^T ---------------------------------------------------------------------------------------------------------------
-  f32x16 O[2][2];
+  f32x16 O[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int i = 0; i < 16; ++i) O[e][i] = 0.f;
+  const int va = vt_addr(4 * h2 + vt_lane_row(lane), lane);      // k-step (t, u): rows + 32 t + 16 u, same swizzle word
 #pragma unroll
-      for (int i = 0; i < 16; ++i) O[e][u][i] = 0.f;
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const bf16x8 pf = p_frag(S[t], u);
-      const int key0 = t * 32 + 16 * u + 4 * h2;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) O[e][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt_frag(Vimg, key0, e, lane), pf, O[e][u], 0, 0, 0);
-    }
-  }
+    for (int u = 0; u < 2; ++u) pv_step(O, Vimg + (32 * t + 16 * u) * 128, va, p_frag(S[t], u));
   store_o(a.out + ((size_t)b * a.T + q_tok) * (a.nh * DH) + head * DH, O, 1.0f / l, h2, q_ok);
 }
 
@@ -215,7 +247,7 @@ __global__ __launch_bounds__(GL_QW * 64) void attn_long_bf16_kernel(const DArgs 
     for (int j = 0; j < 2; ++j) {
       const int pc = 2 * wid + j, row = 8 * pc + (lane >> 3);
       const int tok = min(kb * GL_KB + row, T - 1);
-      const int q = (lane & 7) ^ ((row >> 1) & 7);
+      const int q = (lane & 7) ^ asw(row);
       const char* src = base + (size_t)tok * row_bytes + q * 16;
       glds16(src + a.nh * DH * 2, buf + pc * 1024);
       glds16(src + 2 * a.nh * DH * 2, buf + GL_IMG + pc * 1024);
@@ -229,14 +261,14 @@ __global__ __launch_bounds__(GL_QW * 64) void attn_long_bf16_kernel(const DArgs 
   }
   KD_WAIT_VM(0);                                   // q in registers before any block is in flight (counted waits below see only blocks)
   issue(0);
-  f32x16 O[2][2];
+  f32x16 O[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) O[e][u][i] = 0.f;
+    for (int i = 0; i < 16; ++i) O[e][i] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  const int ka = l31 * 128 + ((h2 ^ asw(l31)) << 4);
+  const int va = vt_addr(4 * h2 + vt_lane_row(lane), lane);
   const int nkb = (T + GL_KB - 1) / GL_KB;
   for (int kb = 0; kb < nkb; ++kb) {
     if (kb + 1 < nkb) { issue(kb + 1); KD_WAIT_VM(4); } else { KD_WAIT_VM(0); }
@@ -253,46 +285,27 @@ __global__ __launch_bounds__(GL_QW * 64) void attn_long_bf16_kernel(const DArgs 
     for (int st = 0; st < 4; ++st)
 #pragma unroll
       for (int t = 0; t < GL_NTK; ++t) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kimg + swz128(32 * t + l31, 2 * st + h2));
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kimg + (ka ^ (32 * st)) + 4096 * t);
         S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], S[t], 0, 0, 0);
       }
-    float m_blk = -INFINITY;
+    if (k0 + GL_KB > T) {
 #pragma unroll
-    for (int t = 0; t < GL_NTK; ++t)
+      for (int t = 0; t < GL_NTK; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (k0 + GL_KB > T) S[t][i] += (k0 + t * 32 + mfma32_row(i, lane) < T) ? 0.f : -INFINITY;
-        m_blk = fmaxf(m_blk, S[t][i]);
-      }
-    m_blk = fmaxf(m_blk, __shfl_xor(m_blk, 32, 64));
-    const float m_new = fmaxf(m_run, m_blk);
+        for (int i = 0; i < 16; ++i) S[t][i] += (k0 + t * 32 + mfma32_row(i, lane) < T) ? 0.f : -INFINITY;
+    }
+    const float m_new = fmaxf(m_run, score_max<GL_NTK>(S));
     const float alpha = __expf(m_run - m_new);       // first block: exp(-inf) = 0
     m_run = m_new;
-    float l_blk = 0.f;
-#pragma unroll
-    for (int t = 0; t < GL_NTK; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float pv = __expf(S[t][i] - m_new);
-        S[t][i] = pv;
-        l_blk += pv;
-      }
-    l_run = l_run * alpha + l_blk;
+    l_run = l_run * alpha + score_exp<GL_NTK>(S, m_new);
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) O[e][u][i] *= alpha;
+      for (int i = 0; i < 16; ++i) O[e][i] *= alpha;
 #pragma unroll
     for (int t = 0; t < GL_NTK; ++t)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const bf16x8 pf = p_frag(S[t], u);
-        const int key0 = t * 32 + 16 * u + 4 * h2;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) O[e][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt_frag(Vimg, key0, e, lane), pf, O[e][u], 0, 0, 0);
-      }
+      for (int u = 0; u < 2; ++u) pv_step(O, Vimg + (32 * t + 16 * u) * 128, va, p_frag(S[t], u));
     KD_BARRIER();                                  // every wave is done with buffer kb & 1 before block kb + 2 overwrites it
   }
   const float l = l_run + __shfl_xor(l_run, 32, 64);
@@ -318,7 +331,9 @@ struct NaGeo {
   static constexpr int PR = 4 + KS - 1;                                      // patch rows of a wave
   static constexpr int PW = (8 + KS - 1 <= 16) ? 16 : 32;                    // patch width (keys per patch row)
   static constexpr int NKT = (PR * PW + 31) / 32;                            // key tiles per wave
-  static constexpr int ROWS = ((HR * HC + PW + 7) / 8) * 8;                  // image rows (a patch may poke past the halo's last key)
+  // image rows: a wave's patch may poke past the halo's last key -- the highest row any fragment read touches is
+  // (HR - 1) HC + (HC - (8 + KS - 1)) + 15 = HR HC - KS + 8.  Kept tight: at KS = 7 the two images take 78 KiB, TWO workgroups per CU
+  static constexpr int ROWS = ((HR * HC - KS + 9 + 7) / 8) * 8;
   static constexpr int LDS = 2 * ROWS * 128;
 };
 
@@ -347,15 +362,21 @@ __global__ __launch_bounds__(256, (NaGeo<KS>::LDS <= 80 * 1024) ? 2 : 1) void at
   const int ty0 = ty * NA_TH, tx0 = tx * NA_TW;
   const int hy0 = max(0, min(ty0 - KS / 2, a.H - HR)), hx0 = max(0, min(tx0 - KS / 2, a.W - HC));
 
-  // ---- halo rows -> K / V images -----------------------------------------------------------------------------------------------
-  for (int pc = wid; pc < ROWS / 8; pc += 4) {
-    const int row = 8 * pc + (lane >> 3);
-    const int hr = min(row, HR * HC - 1);
-    const int ky = min(hy0 + hr / HC, a.H - 1), kx = min(hx0 + hr % HC, a.W - 1);
-    const int q = (lane & 7) ^ ((row >> 1) & 7);
-    const char* src = base + (size_t)(ky * a.W + kx) * row_bytes + q * 16;
-    glds16(src + a.nh * DH * 2, Kimg + pc * 1024);
-    glds16(src + 2 * a.nh * DH * 2, Vimg + pc * 1024);
+  // ---- halo rows -> K / V images: image row 8 pc + (lane >> 3) = halo position (y, x), walked 32 rows at a time ----------------
+  static_assert(PW == 16, "kernel sizes up to 9: 16-key patch rows");
+  {
+    int row = 8 * wid + (lane >> 3);
+    int y = row / HC, x = row % HC;
+    constexpr int DY = 32 / HC, DX = 32 % HC;
+    for (int pc = wid; pc < ROWS / 8; pc += 4) {
+      // rows past the halo's last key (a patch may poke there) take any real token: they are outside every window
+      const int ky = min(hy0 + y, a.H - 1), kx = min(hx0 + x, a.W - 1);
+      const char* src = base + (size_t)(unsigned)((ky * a.W + kx) * (int)row_bytes + (((lane & 7) ^ asw(row)) << 4));
+      glds16(src + a.nh * DH * 2, Kimg + pc * 1024);
+      glds16(src + 2 * a.nh * DH * 2, Vimg + pc * 1024);
+      row += 32; x += DX; y += DY;
+      if (x >= HC) { x -= HC; ++y; }
+    }
   }
   // ---- this lane's query ------------------------------------------------------------------------------------------------------------
   const int qy_raw = ty0 + 4 * wy_ + (l31 >> 3), qx_raw = tx0 + 8 * wx_ + (l31 & 7);
@@ -372,81 +393,64 @@ __global__ __launch_bounds__(256, (NaGeo<KS>::LDS <= 80 * 1024) ? 2 : 1) void at
   const int wy = max(0, min(qy - KS / 2, a.H - KS)) - hy0, wx = max(0, min(qx - KS / 2, a.W - KS)) - hx0;
   const int row_lo = min(max(0, min(min(ty0 + 4 * wy_, a.H - 1) - KS / 2, a.H - KS)) - hy0, HR - PR);
   const int col_lo = min(max(0, min(min(tx0 + 8 * wx_, a.W - 1) - KS / 2, a.W - KS)) - hx0, HC - (8 + KS - 1));
-  const int korg = row_lo * HC + col_lo;          // halo index of patch key (0, 0); local key PW * r + c is korg + HC * r + c
+  const int korg = row_lo * HC + col_lo;          // halo index of patch key (0, 0); local key 16 r + c is image row korg + HC r + c
+  // validity of patch column / patch row for THIS lane's query as +inf (inside the window) / -inf: v_min3 applies both at once.
+  // Accumulator register i of a tile holds local key (i & 3) + 8 (i >> 2) + 4 h2: column (i & 3) + 8 ((i >> 2) & 1) + 4 h2 of patch
+  // row 2 t + (i >> 3).
+  float colv[8], rowv[2 * NKT];
+  {
+    const int r0 = wy - row_lo, c0 = wx - col_lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) colv[j] = ((unsigned)((j & 3) + 8 * (j >> 2) + 4 * h2 - c0) < (unsigned)KS) ? INFINITY : -INFINITY;
+#pragma unroll
+    for (int p = 0; p < 2 * NKT; ++p) rowv[p] = ((unsigned)(p - r0) < (unsigned)KS) ? INFINITY : -INFINITY;
+  }
   KD_WAIT_VM(0);
   KD_BARRIER();
 
-  // ---- S^T = K Q^T over the wave's key tiles ------------------------------------------------------------------------------------
-  // tile t, local key 32 t + i: patch row (32 t + i) / PW, column (32 t + i) % PW
+  // ---- S^T = K Q^T over the wave's key tiles: tile t, local key 32 t + i = patch row 2 t + (i >> 4), column i & 15 -------------
   f32x16 S[NKT];
 #pragma unroll
   for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
-  auto halo_row = [&](int kl) -> int { return korg + (kl / PW) * HC + (kl % PW); };
+  int ka[NKT];
+  {
+    const int kr0 = korg + (l31 >> 4) * HC + (l31 & 15);
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      const int kr = kr0 + 2 * t * HC;
+      ka[t] = kr * 128 + ((h2 ^ asw(kr)) << 4);
+    }
+  }
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kimg + swz128(halo_row(32 * t + l31), 2 * st + h2));
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kimg + (ka[t] ^ (32 * st)));
       S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], S[t], 0, 0, 0);
     }
   }
   // ---- window mask + softmax -------------------------------------------------------------------------------------------------------
-  // validity of local key kl for THIS lane's query: patch row in [r0, r0 + KS) and column in [c0, c0 + KS)
-  {
-    const int r0 = wy - row_lo, c0 = wx - col_lo;
-    const unsigned run = ((1u << KS) - 1u) << c0;                     // valid columns of a patch row (c0 + KS <= PW <= 32)
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      unsigned word = 0u;                                             // bit i: local key 32 t + i valid
-      if (PW == 16) {
-        const int pr0 = 2 * t, pr1 = 2 * t + 1;
-        word = ((pr0 >= r0 && pr0 < r0 + KS) ? run : 0u) | ((pr1 >= r0 && pr1 < r0 + KS) ? (run << 16) : 0u);
-      } else {
-        word = (t >= r0 && t < r0 + KS) ? run : 0u;
-      }
-      word >>= 4 * h2;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) S[t][i] += (word & (1u << ((i & 3) + 8 * (i >> 2)))) ? 0.f : -INFINITY;
-    }
-  }
-  float m = -INFINITY;
 #pragma unroll
   for (int t = 0; t < NKT; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) m = fmaxf(m, S[t][i]);
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
-  float l = 0.f;
-#pragma unroll
-  for (int t = 0; t < NKT; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float pv = __expf(S[t][i] - m);
-      S[t][i] = pv;
-      l += pv;
-    }
+    for (int i = 0; i < 16; ++i) S[t][i] = min3f(S[t][i], colv[i & 7], rowv[2 * t + (i >> 3)]);
+  const float m = score_max<NKT>(S);
+  float l = score_exp<NKT>(S, m);
   l += __shfl_xor(l, 32, 64);
 
-  // ---- O^T = V^T P^T -------------------------------------------------------------------------------------------------------------------
-  f32x16 O[2][2];
+  // ---- O^T = V^T P^T: k-slots of lane-half h2 at step (t, u) are patch row 2 t + u, columns 4 h2 + {0..3} and + 8 ----------------
+  f32x16 O[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int i = 0; i < 16; ++i) O[e][i] = 0.f;
+  const int vr0 = korg + 4 * h2 + vt_lane_row(lane);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) O[e][u][i] = 0.f;
+  for (int t = 0; t < NKT; ++t)
 #pragma unroll
-  for (int t = 0; t < NKT; ++t) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const bf16x8 pf = p_frag(S[t], u);
-      // k-slots of lane-half h2: local keys 32 t + 16 u + 4 h2 + {0..3} and + 8: two runs of 4 consecutive keys inside one patch row
-      const int key0 = halo_row(32 * t + 16 * u + 4 * h2);
-#pragma unroll
-      for (int e = 0; e < 2; ++e) O[e][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt_frag(Vimg, key0, e, lane), pf, O[e][u], 0, 0, 0);
-    }
-  }
+    for (int u = 0; u < 2; ++u) pv_step(O, Vimg, vt_addr(vr0 + (2 * t + u) * HC, lane), p_frag(S[t], u));
   store_o(a.out + ((size_t)b * T + q_tok) * (a.nh * DH) + head * DH, O, 1.0f / l, h2, q_ok);
 }
 

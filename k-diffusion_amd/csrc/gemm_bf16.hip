@@ -1100,6 +1100,8 @@ __global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* __re
       u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
 }
 
+int gemm_patch_try(const KdGemm& d, hipStream_t s, int* rc);      // patch_bf16.hip
+
 }  // namespace b16
 }  // namespace kd
 
@@ -1145,6 +1147,7 @@ extern "C" int kd_gemm_bf16(const KdGemm* dp, void* stream) {
     if (!b16::gemm_generic_try(d, s, &rc)) return rc;
     return fail(KD_EINVAL, "kd_gemm_bf16: no generic kernel for a_mode=%d epi=%d N=%d", d.a_mode, d.epi, d.N);
   }
+  if ((d.a_mode == KD_A_PATCH_NCHW || d.epi == KD_EPI_UNPATCH_NCHW) && !b16::gemm_patch_try(d, s, &rc)) return rc;
   const bool small_k = d.K == 128 || (d.K == 384 && d.N <= 128);
   if (small_k && !b16::gemm_wstat_try(d, s, &rc)) return rc;
   if (!b16::gemm_astat_try(d, s, &rc)) return rc;
