@@ -220,6 +220,77 @@ static void run_gemm_case(const GemmCase& c) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// fused feed-forward block (kd_ffn_bf16) against an fp64 restatement; the two-kernel form (GEGLU GEMM + residual GEMM) timed beside it
+static void run_ffn_case(const char* name, int M, int K, int dff, int rps) {
+  if (!want(name)) return;
+  const int B = (M + rps - 1) / rps;
+  auto X_h = to_bf(randn((size_t)M * K));
+  auto Wu_f = randn((size_t)2 * dff * K, 1.0f / sqrtf((float)K)), Wd_f = randn((size_t)K * dff, 1.0f / sqrtf((float)dff));
+  std::vector<float> scale_h((size_t)B * K);
+  for (auto& x : scale_h) x = 1.0f + 0.3f * std::normal_distribution<float>(0, 1)(rng);
+  DevBuf<uint16_t> dX(X_h.size()), dY(X_h.size()), dH((size_t)M * dff);
+  DevBuf<float> dWu(Wu_f.size()), dWd(Wd_f.size()), dS(scale_h.size());
+  dX.up(X_h); dWu.up(Wu_f); dWd.up(Wd_f); dS.up(scale_h);
+  DevBuf<char> dPu((size_t)kd_packed_weight_bytes_bf16(dff, K, 1)), dPd((size_t)kd_packed_weight_bytes_bf16(K, dff, 2)), dPd0((size_t)kd_packed_weight_bytes_bf16(K, dff, 0));
+  if (kd_pack_weight_bf16(dWu.p, dPu.p, dff, K, 1, nullptr) || kd_pack_weight_bf16(dWd.p, dPd.p, K, dff, 2, nullptr) ||
+      kd_pack_weight_bf16(dWd.p, dPd0.p, K, dff, 0, nullptr)) { printf("%s: pack failed: %s\n", name, kd_last_error()); ++g_fail; return; }
+  HIPCHK(hipMemset(dY.p, 0xFF, dY.n * 2));
+  KdFfn f;
+  memset(&f, 0, sizeof(f));
+  f.x = dX.p; f.out = dY.p; f.scale = dS.p; f.scale_stride = K; f.rows_per_sample = rps; f.eps = 1e-6f;
+  f.Wp_up = dPu.p; f.Wp_down = dPd.p; f.M = M; f.K = K; f.d_ff = dff;
+  if (K != 128) { printf("%-28s not supported by kd_ffn_bf16\n", name); return; }     // (kd_ffn_bf16_supported also asks for M >= 16384: a speed rule)
+  if (int rc = kd_ffn_bf16(&f, nullptr)) { printf("%-28s REJECTED (%d): %s\n", name, rc, kd_last_error()); ++g_fail; return; }
+  HIPCHK(hipDeviceSynchronize());
+  auto Y_h = dY.down();
+  std::vector<int> rows;
+  for (int i = 0; i < 40 && i < M; ++i) { rows.push_back(i); rows.push_back(M - 1 - i); }
+  std::uniform_int_distribution<int> rd(0, M - 1);
+  for (int i = 0; i < 200; ++i) rows.push_back(rd(rng));
+  double max_err = 0, max_ref = 0;
+  long bad = 0;
+  std::vector<double> a(K), hid(dff);
+  for (int m : rows) {
+    const int b = m / rps;
+    double ssq = 0;
+    for (int k = 0; k < K; ++k) { a[k] = bf2f(X_h[(size_t)m * K + k]); ssq += a[k] * a[k]; }
+    const double rs = 1.0 / sqrt(ssq / K + 1e-6);
+    for (int k = 0; k < K; ++k) a[k] = bf2f(f2bf((float)(a[k] * scale_h[(size_t)b * K + k])));
+    for (int n = 0; n < dff; ++n) {
+      double v = 0, g = 0;
+      for (int k = 0; k < K; ++k) {
+        v += a[k] * (double)bf2f(f2bf(Wu_f[(size_t)n * K + k]));
+        g += a[k] * (double)bf2f(f2bf(Wu_f[(size_t)(dff + n) * K + k]));
+      }
+      hid[n] = bf2f(f2bf((float)(v * rs * gelu(g * rs))));            // the hidden activation is bf16 in both forms
+    }
+    for (int n = 0; n < K; ++n) {
+      double o = 0;
+      for (int j = 0; j < dff; ++j) o += hid[j] * (double)bf2f(f2bf(Wd_f[(size_t)n * dff + j]));
+      o += bf2f(X_h[(size_t)m * K + n]);
+      const double got = bf2f(Y_h[(size_t)m * K + n]);
+      const double err = fabs(got - o);
+      max_ref = std::max(max_ref, fabs(o));
+      if (!(err <= 0.01 * fabs(o) + 0.03)) ++bad;
+      if (err == err) max_err = std::max(max_err, err); else max_err = 1e30;
+    }
+  }
+  const float us = time_us([&] { kd_ffn_bf16(&f, nullptr); });
+  // the two-kernel form on the same data
+  KdGemm u, d;
+  memset(&u, 0, sizeof(u)); memset(&d, 0, sizeof(d));
+  u.M = M; u.N = dff; u.K = K; u.epi = KD_EPI_GEGLU; u.norm = 1; u.rows_per_sample = rps; u.scale_stride = K; u.eps = 1e-6f; u.precision = KD_PREC_BF16;
+  u.A = reinterpret_cast<const float*>(dX.p); u.C = reinterpret_cast<float*>(dH.p); u.Wp = dPu.p; u.scale = dS.p; u.W = dWu.p;
+  d.M = M; d.N = K; d.K = dff; d.epi = KD_EPI_RESIDUAL; d.rows_per_sample = rps; d.eps = 1e-6f; d.precision = KD_PREC_BF16;
+  d.A = reinterpret_cast<const float*>(dH.p); d.C = reinterpret_cast<float*>(dY.p); d.R = reinterpret_cast<const float*>(dX.p); d.Wp = dPd0.p; d.W = dWd.p;
+  float us2 = 0;
+  if (!kd_gemm_bf16(&u, nullptr) && !kd_gemm_bf16(&d, nullptr)) us2 = time_us([&] { kd_gemm_bf16(&u, nullptr); kd_gemm_bf16(&d, nullptr); });
+  const double flops = 2.0 * M * (double)K * 3.0 * dff;
+  printf("%-28s M=%6d K=%4d dff=%4d  max|err|=%.4g (max|ref|=%.3g) bad=%ld  %8.1f us  %7.1f TF/s  %6.0f GB/s   (two kernels: %.1f us)  %s\n", name, M, K, dff,
+         max_err, max_ref, bad, us, flops / us * 1e-6, 4.0 * M * K / us * 1e-3, us2, bad ? "FAIL" : "ok");
+  if (bad) ++g_fail;
+}
+
 // patch-in (fp32 NCHW image -> bf16 tokens, * c_in) and patch-out (RMSNorm -> projection -> fp32 NCHW image, Karras c_out / c_skip)
 static void run_patch_case(const char* name, int B, int C, int gh, int gw, int ps, int width) {
   if (!want(name)) return;
@@ -602,6 +673,16 @@ int main(int argc, char** argv) {
     }
     kd_set_option("wstat_waves", 0);
   }
+  for (int v : {1, 3}) {
+    kd_set_option("ffn_variant", v);
+    if (want("ffn")) printf("-- ffn_variant = %d\n", v);
+    run_ffn_case("ffn L0", 131072, 128, 384, 4096);
+    run_ffn_case("ffn ragged", 4128 + 77, 128, 448, 96);
+    run_ffn_case("ffn tiny", 37, 128, 64, 37);
+    run_ffn_case("ffn one tile", 300, 128, 64, 100);
+    run_ffn_case("ffn two tiles", 300, 128, 128, 100);
+  }
+  kd_set_option("ffn_variant", 1);
   run_patch_case("patch flowers", 32, 3, 64, 64, 4, 128);
   run_patch_case("patch mnist", 4, 1, 7, 7, 4, 256);
   run_patch_case("patch cifar (generic)", 8, 3, 16, 16, 2, 256);

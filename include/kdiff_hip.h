@@ -37,7 +37,8 @@ const char* kd_last_error(void);
  *                  "gemm_debug" (0; profiling ablations of benchmarks/: 1 no C stores, 2 no MFMA, 8 GEGLU without erf)
  *   bf16 kernels : "bf16_fast" (1; 0 = generic kernel only) "wstat" (1) "wstat_waves" (0 = per shape) "wstat_max_slices" (24)
  *                  "wstat_prefetch" (0; 1 next-chunk prefetch, 2 software-pipelined tiles) "astat_bf16" (1) "astat_splits" (0 = auto)
- *                  "tiled_bm" (0 = auto, 128, 256) "attn_global_qw" (8) "patch_fast" (1; 0 = patch-in / patch-out through the generic kernel) */
+ *                  "tiled_bm" (0 = auto, 128, 256) "attn_global_qw" (8) "patch_fast" (1; 0 = patch-in / patch-out through the generic kernel)
+ *                  "ffn_fused" (1; 0 = kd_ffn_bf16_supported answers no) */
 int kd_set_option(const char* name, int value);
 int kd_get_option(const char* name, int dflt);
 
@@ -101,8 +102,30 @@ int kd_gemm_f32(const KdGemm* desc, void* stream);
  * lerp and the Karras scalings in fp32 registers; one rounding to bf16 at the store. */
 int kd_gemm_bf16(const KdGemm* desc, void* stream);
 long long kd_packed_weight_bytes_bf16(int N, int K, int geglu);
-/* W [N or 2N (geglu), K] fp32 -> blocks [n-tile][k-step][128 rows][64 k] bf16 (16 KiB each, the kernels' swizzled LDS image) */
+/* W [N or 2N (geglu), K] fp32 -> blocks [n-tile][k-step][128 rows][64 k] bf16 (16 KiB each, the kernels' swizzled LDS image).
+ * `geglu` selects the layout: 0 plain, 1 GEGLU (value / gate rows interleaved per 32 outputs), 2 plain rows with the k order
+ * of kd_ffn_bf16's down projection (inside every group of 16 k: 0-3, 8-11, 4-7, 12-15). */
 int kd_pack_weight_bf16(const float* W, void* out, int N, int K, int geglu, void* stream);
+
+/* Fused feed-forward block in bf16 arithmetic:  out = x + down_proj(GEGLU(up_proj(AdaRMSNorm(x)))).
+ * Replaces FeedForwardBlock.forward, image_transformer_v2.py:487-493 (norm :155-166, LinearGEGLU :132-139, dropout = identity at
+ * inference, Linear :126-129, residual :493) -- the pair kd_gemm_bf16(KD_EPI_GEGLU) + kd_gemm_bf16(KD_EPI_RESIDUAL) without the
+ * d_ff-wide hidden activation ever leaving the chip.  x, out: bf16 [M, K] (out may be x); scale: fp32 norm scales, row m uses
+ * scale + (m / rows_per_sample) * scale_stride; Wp_up = kd_pack_weight_bf16(up_proj.weight [2 d_ff, K], N = d_ff, geglu = 1);
+ * Wp_down = kd_pack_weight_bf16(down_proj.weight [K, d_ff], N = K, K = d_ff, geglu = 2).
+ * Shapes: K == 128, d_ff % 64 == 0 (kd_ffn_bf16_supported); anything else returns KD_EINVAL and the caller uses the pair. */
+typedef struct KdFfn {
+  const void* x;
+  void* out;
+  const float* scale;
+  int scale_stride, rows_per_sample;
+  float eps;
+  const void* Wp_up;
+  const void* Wp_down;
+  int M, K, d_ff;
+} KdFfn;
+int kd_ffn_bf16_supported(int M, int K, int d_ff);
+int kd_ffn_bf16(const KdFfn* desc, void* stream);
 
 /* One-off packing of a weight for KD_PREC_SPLIT3 (weights are static during sampling): W [N or 2N (geglu), K]
  * fp32 -> `out`, kd_packed_weight_bytes(N, K, geglu) bytes: [n-tile][k-step][hi|lo][128 rows][32 bf16] in the

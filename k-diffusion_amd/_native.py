@@ -50,6 +50,16 @@ class KdGemm(C.Structure):
     ]
 
 
+class KdFfn(C.Structure):
+    """include/kdiff_hip.h KdFfn: the fused feed-forward block (FeedForwardBlock.forward, image_transformer_v2.py:487-493)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("out", C.c_void_p), ("scale", C.c_void_p),
+        ("scale_stride", C.c_int), ("rows_per_sample", C.c_int), ("eps", C.c_float),
+        ("Wp_up", C.c_void_p), ("Wp_down", C.c_void_p),
+        ("M", C.c_int), ("K", C.c_int), ("d_ff", C.c_int),
+    ]
+
+
 _vp, _i, _f, _ll, _d = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_double
 
 # name -> argtypes; every symbol declared in include/kdiff_hip.h
@@ -62,6 +72,8 @@ SIGNATURES = {
     "kd_gemm_bf16": [C.POINTER(KdGemm), _vp],
     "kd_packed_weight_bytes_bf16": [_i, _i, _i],
     "kd_pack_weight_bf16": [_vp, _vp, _i, _i, _i, _vp],
+    "kd_ffn_bf16_supported": [_i, _i, _i],
+    "kd_ffn_bf16": [_vp, _vp],
     "kd_attn_global_bf16": [_vp, _vp, _i, _i, _i, _vp],
     "kd_attn_window_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "kd_attn_na2d_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -1,0 +1,231 @@
+// Fused feed-forward block of the HDiT denoiser in bf16 mode, gfx950:
+//     y = x + down_proj( GEGLU( up_proj( AdaRMSNorm(x, cond) ) ) )                      (image_transformer_v2.py:479-493, :95 GEGLU)
+// in ONE kernel: the d_ff-wide hidden activation never goes to HBM.  At the level-0 shape of the headline config (131 072 tokens,
+// width 128, d_ff 384) the two-kernel form moves 33 + 100 MB (up) and 100 + 33 + 33 MB (down) per layer and both kernels sit
+// at the HBM rate; fused, the block reads x once and writes it once (67 MB) and is bound by its matrix / VALU work instead.
+//
+// Structure ("A-stationary", lane-owns-row like every bf16 GEMM here, see bf16_common.h):
+//   * a workgroup of 8 waves owns a panel of 256 rows; wave w keeps the normalised rows 32 w .. 32 w + 31 as MFMA B-operand
+//     fragments in registers for the whole kernel (K / 16 fragments) and the K-wide fp32 output accumulators beside them;
+//   * d_ff is walked in tiles of 64 hidden features.  The weights of a tile -- the GEGLU-interleaved up-projection tile
+//     [128 rows: 32 value | 32 gate | 32 value | 32 gate][K] and the down-projection k-step [K rows][64 hidden] -- form one
+//     48 KiB unit (K = 128) that all waves copy HBM/L2 -> LDS with global_load_lds into a 3-slot ring: one barrier per tile,
+//     counted vmcnt, the copy of tile t + 2 in flight while tile t is multiplied;
+//   * per tile: 4 K/16 MFMAs give value / gate accumulators, the GEGLU runs in the lane that owns the row, and its 64 outputs
+//     are ALREADY the B operand of the down-projection: accumulator registers 8u .. 8u+7 of a 32-feature block are the 8 k-slots
+//     of lane-half lh for the hidden features {16u + 4 lh + 0..3, 16u + 8 + 4 lh + 0..3}.  The down-projection weight is packed
+//     with that k order inside every group of 16 (kd_pack_weight_bf16 layout 2), so its fragments stay one ds_read_b128;
+//   * epilogue: + x (re-read: the panel's rows are still in L2), bf16, 16-byte stores.
+#include "bf16_common.h"
+
+namespace kd {
+namespace b16 {
+
+struct FArgs {
+  const u16* X; u16* Y; const char* Wu; const char* Wd;
+  const float* scale; int scale_stride, rows_per_sample; float eps;
+  int M, n_tiles;            // n_tiles = d_ff / 64
+};
+
+#define KD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define KD_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+constexpr int FF_NW = 8;
+
+// SKEW: waves 4..7 (the second wave of every SIMD) run half a tile behind waves 0..3 -- in interval t they finish tile t - 1
+// (GEGLU, down projection) and then start tile t (up projection), while their SIMD partner does up(t), GEGLU(t), down(t).  The
+// barrier per tile otherwise keeps both waves of a SIMD in the SAME phase (both want the matrix pipe, then both want the VALU,
+// and the per-tile costs add up); skewed, one wave's MFMAs run beside the other's GEGLU.  The down-projection k-step of tile t - 1
+// has to stay one interval longer: its ring gets a fourth slot (3 x 32 KiB + 4 x 16 KiB = all 160 KiB of LDS).
+template <int NC /* K / 16 */, bool SKEW>
+__global__ __launch_bounds__(FF_NW * 64) void ffn_kernel(const FArgs p) {
+  constexpr int K = NC * 16, NKU = NC / 4, KB = K / 32, NTD = K / 128;
+  constexpr int UP_BYTES = NKU * WBLK, DN_BYTES = NTD * WBLK, UNIT = UP_BYTES + DN_BYTES;
+  constexpr int NDS = SKEW ? 4 : 3;                   // slots of the down-projection ring
+  constexpr int PCS = UNIT / 1024 / FF_NW;            // 1 KiB pieces per wave per tile
+  static_assert(K % 128 == 0 && (UNIT / 1024) % FF_NW == 0, "unit = whole pieces per wave");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int row = blockIdx.x * (FF_NW * 32) + wid * 32 + l31;
+  const bool ok = row < p.M;
+  const int rowc = ok ? row : p.M - 1;
+  const int T = p.n_tiles;
+
+  const bool late = SKEW && wid >= FF_NW / 2;
+  auto up_slot = [&](int t) -> char* { return smem + (t % 3) * UP_BYTES; };
+  auto dn_slot = [&](int t) -> char* { return smem + 3 * UP_BYTES + (t % NDS) * DN_BYTES; };
+  auto issue = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < PCS; ++i) {
+      const int pi = wid + FF_NW * i;
+      const char* src;
+      char* dst;
+      if (pi < NKU * 16) {
+        src = p.Wu + ((size_t)t * NKU) * WBLK + pi * 1024;
+        dst = up_slot(t) + pi * 1024;
+      } else {
+        const int pd = pi - NKU * 16;
+        src = p.Wd + ((size_t)(pd >> 4) * T + t) * WBLK + (pd & 15) * 1024;
+        dst = dn_slot(t) + pd * 1024;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 16),
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  // ---- this lane's row: raw bf16 + the sample's scale vector requested first, then the first two weight units ----------------
+  u32x4 raw[NC];
+  f32x4 s0[NC], s1[NC];
+  {
+    const u32x4* ap = reinterpret_cast<const u32x4*>(p.X + (size_t)rowc * K + 8 * lh);
+    const float* sp = p.scale + (size_t)(rowc / p.rows_per_sample) * p.scale_stride + 8 * lh;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      raw[c] = ap[2 * c];
+      s0[c] = *reinterpret_cast<const f32x4*>(sp + 16 * c);
+      s1[c] = *reinterpret_cast<const f32x4*>(sp + 16 * c + 4);
+    }
+  }
+  issue(0);
+  if (T > 1) issue(1);
+  bf16x8 a[NC];
+  float rs;
+  {
+    float ssq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[2 * e] = bf_lo(raw[c][e]); x[2 * e + 1] = bf_hi(raw[c][e]); }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ssq = fmaf(x[e], x[e], ssq);
+      u32x4 o = {pack_bf16(x[0] * s0[c][0], x[1] * s0[c][1]), pack_bf16(x[2] * s0[c][2], x[3] * s0[c][3]),
+                 pack_bf16(x[4] * s1[c][0], x[5] * s1[c][1]), pack_bf16(x[6] * s1[c][2], x[7] * s1[c][3])};
+      asm volatile("" : "+v"(o));
+      a[c] = __builtin_bit_cast(bf16x8, o);
+    }
+    ssq += __shfl_xor(ssq, 32, 64);
+    rs = rsqrtf(ssq / (float)K + p.eps);
+  }
+  const float rsh = 0.5f * rs;
+
+  int off4[4];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) off4[cc] = swz128(l31, 2 * cc + lh);
+  f32x16 acc_o[KB];
+#pragma unroll
+  for (int ob = 0; ob < KB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[ob][r] = 0.f;
+
+  f32x16 acc[4];
+  bf16x8 hf[4];
+  auto up = [&](int t) {                              // value / gate accumulators of the 2 x 32 hidden features of tile t
+    const char* wu = up_slot(t);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const char* wk = wu + (c >> 2) * WBLK + off4[c & 3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wk + j * 32 * 128);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, a[c], acc[j], 0, 0, 0);
+      }
+    }
+  };
+  auto glu = [&]() {                                  // GEGLU in the lane that owns the row; the outputs are the down projection's B operand
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      unsigned pk[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 o = geglu_pair(f32x2{acc[2 * jj][r], acc[2 * jj][r + 1]} * rsh, f32x2{acc[2 * jj + 1][r], acc[2 * jj + 1][r + 1]} * rs);
+        pk[r >> 1] = pack_bf16(o.x, o.y);
+      }
+      hf[2 * jj] = __builtin_bit_cast(bf16x8, u32x4{pk[0], pk[1], pk[2], pk[3]});
+      hf[2 * jj + 1] = __builtin_bit_cast(bf16x8, u32x4{pk[4], pk[5], pk[6], pk[7]});
+    }
+  };
+  auto down = [&](int t) {                            // k-step t (64 hidden features) into the K output features
+    const char* wd = dn_slot(t);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int ob = 0; ob < KB; ++ob) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wd + (ob >> 2) * WBLK + (ob & 3) * 32 * 128 + off4[g]);
+        acc_o[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hf[g], acc_o[ob], 0, 0, 0);
+      }
+  };
+  static_assert(PCS == 6, "the counted waits below are written for 6 pieces per wave per tile");
+  const int n_int = SKEW ? T + 1 : T;                 // the late waves finish the last tile in one more interval
+  for (int t = 0; t < n_int; ++t) {
+    if (t + 1 < T) { KD_WAIT_VM(6); } else { KD_WAIT_VM(0); }
+    KD_BARRIER();                                      // unit t is in for every wave; every wave is done with interval t - 1
+    if (t + 2 < T) issue(t + 2);
+    if (!late) {
+      if (t < T) { up(t); glu(); down(t); }
+    } else {
+      if (t > 0) { glu(); down(t - 1); }
+      if (t < T) up(t);
+    }
+  }
+  // ---- + skip, store -------------------------------------------------------------------------------------------------------------
+  const u16* xrow = p.X + (size_t)rowc * K;
+  u16* yrow = p.Y + (size_t)rowc * K;
+#pragma unroll
+  for (int ob = 0; ob < KB; ++ob) {
+    float sk[16], v[16];
+    load_block_bf16(xrow + 32 * ob, sk, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc_o[ob][r] + sk[r];
+    store_block_bf16(yrow + 32 * ob, v, lh, ok);
+  }
+}
+
+}  // namespace b16
+}  // namespace kd
+
+using namespace kd;
+using namespace kd::b16;
+
+extern "C" int kd_ffn_bf16_supported(int M, int K, int d_ff) {
+  // below ~16k rows the panels do not fill the chip and the two-kernel form (row-parallel over more, smaller units) is faster
+  return (M >= 16384 && K == 128 && d_ff > 0 && d_ff % 64 == 0 && option("ffn_fused", 1)) ? 1 : 0;
+}
+
+extern "C" int kd_ffn_bf16(const KdFfn* dp, void* stream) {
+  if (!dp) return fail(KD_EINVAL, "kd_ffn_bf16: null descriptor");
+  const KdFfn& d = *dp;
+  if (!d.x || !d.out || !d.scale || !d.Wp_up || !d.Wp_down) return fail(KD_EINVAL, "kd_ffn_bf16: null x / out / scale / Wp_up / Wp_down");
+  if (d.M <= 0 || d.rows_per_sample <= 0 || (d.scale_stride & 3)) return fail(KD_EINVAL, "kd_ffn_bf16: needs M, rows_per_sample > 0, scale_stride %% 4 == 0");
+  if (d.K != 128 || d.d_ff <= 0 || d.d_ff % 64) return fail(KD_EINVAL, "kd_ffn_bf16: K = %d, d_ff = %d not supported (K == 128, d_ff %% 64 == 0)", d.K, d.d_ff);
+  hipStream_t s = (hipStream_t)stream;
+  FArgs a{};
+  a.X = reinterpret_cast<const u16*>(d.x); a.Y = reinterpret_cast<u16*>(d.out);
+  a.Wu = reinterpret_cast<const char*>(d.Wp_up); a.Wd = reinterpret_cast<const char*>(d.Wp_down);
+  a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample; a.eps = d.eps;
+  a.M = d.M; a.n_tiles = d.d_ff / 64;
+  // 1 (default) plain, 3 skewed wave pairs.  Measured equal within noise (64.5 / 68.6 us at the level-0 shape; a third form with
+  // one wave per SIMD and the two row blocks' MFMA / GEGLU streams interleaved instruction by instruction took 71 us):
+  // profiles/r02_ffn_fused.md -- under this kernel the chip runs against its power limit and re-arranging the same work buys nothing.
+  const int variant = option("ffn_variant", 1);
+  auto kern = variant == 3 ? ffn_kernel<8, true> : ffn_kernel<8, false>;
+  const int panel = FF_NW * 32, threads = FF_NW * 64;
+  const int LDS = (variant == 3 ? 10 : 9) * WBLK;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * WBLK);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 10 * WBLK);
+    attr_set = true;
+  }
+  char nm[96] = "ffn_bf16";
+  if (prof_on()) snprintf(nm, sizeof(nm), "ffn_bf16 M=%d K=%d dff=%d", d.M, d.K, d.d_ff);
+  const double flops = 2.0 * d.M * (double)d.K * (3.0 * d.d_ff);
+  const double bytes = 4.0 * d.M * (double)d.K + 6.0 * d.d_ff * (double)d.K;
+  LaunchScope prof(nm, flops, bytes, s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((d.M + panel - 1) / panel)), dim3(threads), LDS, s, a);
+  return check_launch("kd_ffn_bf16");
+}

@@ -315,9 +315,21 @@ class _Plan:
                 else:
                     call(prefix + "attn_window", lib.kd_attn_window_f32, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.window_size, shift, *prep)
                 gemm(prefix + "out_proj", att, sa.out_proj.weight, x, T, d, d, epi=nat.EPI_RESIDUAL, R=x)
-            gemm(prefix + "up_proj", x, mod.ff.up_proj.weight, hid, T, lv.d_ff, d, epi=nat.EPI_GEGLU,
-                 scale_ptr=scale_ptr(prefix + "ff.norm"), scale_stride=total, rows_per_sample=rps)
-            gemm(prefix + "down_proj", hid, mod.ff.down_proj.weight, x, T, d, lv.d_ff, epi=nat.EPI_RESIDUAL, R=x)
+            if bf and target is self.launches and lib.kd_ffn_bf16_supported(T, d, lv.d_ff):
+                # the whole FeedForwardBlock (:487-493) in one kernel: the d_ff-wide hidden activation stays on the chip
+                fd = nat.KdFfn()
+                fd.x = fd.out = x.data_ptr()
+                fd.scale_stride, fd.rows_per_sample, fd.eps = total, rps, 1e-6
+                fd.Wp_up = m._packed_image(mod.ff.up_proj.weight, lv.d_ff, d, 1, bf16=True).data_ptr()
+                fd.Wp_down = m._packed_image(mod.ff.down_proj.weight, d, lv.d_ff, 2, bf16=True).data_ptr()
+                fd.M, fd.K, fd.d_ff = T, d, lv.d_ff
+                self.norm_descs.append((fd, scale_ptr(prefix + "ff.norm")[1]))
+                self.keep.append(fd)
+                target.append(_Launch(lib.kd_ffn_bf16, (C.byref(fd),), prefix + "ff"))
+            else:
+                gemm(prefix + "up_proj", x, mod.ff.up_proj.weight, hid, T, lv.d_ff, d, epi=nat.EPI_GEGLU,
+                     scale_ptr=scale_ptr(prefix + "ff.norm"), scale_stride=total, rows_per_sample=rps)
+                gemm(prefix + "down_proj", hid, mod.ff.down_proj.weight, x, T, d, lv.d_ff, epi=nat.EPI_RESIDUAL, R=x)
 
         for li in range(n_lv - 1):
             for i, mod in enumerate(m.down_levels[li]):
@@ -450,7 +462,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         """Packed image of a weight (split-bf16, or plain bf16 for the bf16 mode), shared by all plans of this model.  The
         entry keeps the source tensor alive, so its address cannot be recycled under the cached image; the dict is dropped
         with the plans whenever the weights change (``_weights_fingerprint``)."""
-        key = (id(W), N, K, bool(geglu), bool(bf16))
+        key = (id(W), N, K, int(geglu), bool(bf16))
         ent = self._packed.get(key)
         if ent is None:
             ent = self._packed[key] = (W, ops.pack_weight(W, N, K, geglu, cache=False, bf16=bf16))

@@ -47,13 +47,17 @@ _packed = {}
 
 def pack_weight(W, N, K, geglu, cache=True, bf16=False):
     """Packed image of a weight (uint8 tensor): the split-bf16 image of KD_PREC_SPLIT3, or with ``bf16=True`` the plain bf16
-    image of KD_PREC_BF16.  Weights are static while sampling, so the image is cached per tensor OBJECT (weak reference +
+    image of KD_PREC_BF16.  ``geglu``: 0 / False plain, 1 / True GEGLU rows, 2 (bf16 only) the k order of the fused FF block's
+    down projection.  Weights are static while sampling, so the image is cached per tensor OBJECT (weak reference +
     version counter: a new tensor that happens to reuse the address of a freed one never hits a stale image)."""
-    key = (id(W), bool(bf16))
+    geglu = int(geglu)
+    if geglu == 2 and not bf16:
+        raise ValueError("pack layout 2 exists for the bf16 image only")
+    key = (id(W), bool(bf16), geglu)
     ent = _packed.get(key) if cache else None
     if ent is not None:
         ref, version, meta, img = ent
-        if ref() is W and version == W._version and meta == (tuple(W.shape), N, K, bool(geglu), W.data_ptr()):
+        if ref() is W and version == W._version and meta == (tuple(W.shape), N, K, geglu, W.data_ptr()):
             return img
     _chk(W, "W")
     lib = nat.lib()
@@ -69,7 +73,7 @@ def pack_weight(W, N, K, geglu, cache=True, bf16=False):
                 del _packed[k]
             if len(_packed) > 512:
                 _packed.clear()
-        _packed[key] = (weakref.ref(W), W._version, (tuple(W.shape), N, K, bool(geglu), W.data_ptr()), img)
+        _packed[key] = (weakref.ref(W), W._version, (tuple(W.shape), N, K, geglu, W.data_ptr()), img)
     return img
 
 
@@ -205,6 +209,33 @@ def patch_out(x, norm_scale, weight, patch, channels, x_in=None, sigma=None, sig
     return gemm(x, weight, out, M=B * h * w, N=channels * ph * pw, K=K, epi=nat.EPI_UNPATCH_NCHW, norm_scale=norm_scale,
                 scale_stride=0, rows_per_sample=h * w, grid=(h, w), patch=(ph, pw, channels), residual=x_in, sigma=sigma,
                 sigma_data=sigma_data, eps=eps, precision=_prec_of(x))
+
+
+def ffn_supported(M, K, d_ff):
+    """Does the fused feed-forward kernel take this shape (bf16 mode)?  Otherwise use the up / down pair of ``gemm`` calls."""
+    return bool(nat.lib().kd_ffn_bf16_supported(int(M), int(K), int(d_ff)))
+
+
+def ffn(x, norm_scale, w_up, w_down, out=None, scale_stride=None, rows_per_sample=None, eps=1e-6):
+    """FeedForwardBlock.forward (image_transformer_v2.py:487-493) in one kernel, bf16 mode:
+    out = x + down_proj(GEGLU(up_proj(rms_norm(x) * norm_scale))).  x: bf16 [..., K]; norm_scale: fp32 [B, K] (one row per
+    sample; ``rows_per_sample`` tokens each) ; w_up: fp32 [2 d_ff, K]; w_down: fp32 [K, d_ff].  ``out`` may be x."""
+    K = x.shape[-1]
+    M = x.numel() // K
+    d_ff = w_down.shape[1]
+    if x.dtype != torch.bfloat16:
+        raise TypeError("ffn: bf16 activations only (KDIFF_GEMM=bf16)")
+    out = torch.empty_like(x) if out is None else out
+    d = nat.KdFfn()
+    d.x, d.out, d.scale = _p(_chk(x, "x", torch.bfloat16)), _p(_chk(out, "out", torch.bfloat16)), _p(_chk(norm_scale, "norm_scale"))
+    d.scale_stride = norm_scale.shape[-1] if scale_stride is None else scale_stride
+    d.rows_per_sample = (M // max(norm_scale.numel() // norm_scale.shape[-1], 1)) if rows_per_sample is None else rows_per_sample
+    d.eps = eps
+    up_img, down_img = pack_weight(w_up, d_ff, K, 1, bf16=True), pack_weight(w_down, K, d_ff, 2, bf16=True)
+    d.Wp_up, d.Wp_down = _p(up_img), _p(down_img)
+    d.M, d.K, d.d_ff = M, K, d_ff
+    nat.check(nat.lib().kd_ffn_bf16(C.byref(d), _stream()), "kd_ffn_bf16")
+    return out
 
 
 def fourier_sigma(sigma, weight, out=None):

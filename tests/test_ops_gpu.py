@@ -128,6 +128,31 @@ def test_qkv_epilogue_prepares_q_and_k(ops, gtol):
         ops.norm_linear(g(x), g(scale), g(w[: 2 * d]), rows_per_sample=H * W, epi=5, qk=(g(sh), g(cos), g(sin), nh))
 
 
+@pytest.mark.parametrize("B,T,d_ff", [(8, 4096, 384), (5, 4096, 448), (1, 16500, 64), (2, 300, 128)])
+def test_bf16_fused_ffn(ops, B, T, d_ff):
+    """kd_ffn_bf16 (the whole FeedForwardBlock, image_transformer_v2.py:487-493, hidden activation on-chip) against the fp32
+    oracle on the bf16-rounded input and against the two-kernel form (GEGLU GEMM + residual GEMM) it replaces: same roundings
+    (bf16 normalised input, bf16 hidden, bf16 output), so the two agree to a couple of bf16 ulps."""
+    from k_diffusion_amd import _native as nat
+    K = 128
+    x, scale = rn(B, T, K, seed=14), 1 + 0.2 * rn(B, K, seed=15)
+    wu, wd = rn(2 * d_ff, K, seed=16, scale=K ** -0.5), rn(K, d_ff, seed=17, scale=d_ff ** -0.5)
+    xb = _bf(x)
+    ref = _rt(x) + hdit.linear_geglu(hdit.rms_norm(_rt(x), scale[:, None, :]), _rt(wu)) @ _rt(wd).T
+    y = ops.ffn(xb, g(scale), g(wu), g(wd), rows_per_sample=T)
+    assert y.dtype == BF and y.shape == xb.shape and relerr(y, ref) < 8e-3
+    hid = ops.norm_linear(xb, g(scale), g(wu), rows_per_sample=T, epi=nat.EPI_GEGLU)
+    y2 = ops.linear(hid, g(wd), residual=xb)
+    assert relerr(y, y2.float()) < 6e-3
+    z = xb.clone()
+    ops.ffn(z, g(scale), g(wu), g(wd), rows_per_sample=T, out=z)             # in place (how the model uses it)
+    assert torch.equal(z, y)
+    assert ops.ffn_supported(B * T, K, d_ff) == (B * T >= 16384)
+    assert not ops.ffn_supported(1 << 20, 256, 768) and not ops.ffn_supported(1 << 20, 128, 100)
+    with pytest.raises(RuntimeError):
+        ops.ffn(_bf(rn(B, 64, 256, seed=1)), g(1 + 0.2 * rn(B, 256, seed=2)), g(rn(2 * 64, 256, seed=3)), g(rn(256, 64, seed=4)), rows_per_sample=64)
+
+
 @pytest.mark.parametrize("H,W,nh,B,K", [(16, 16, 2, 2, 128), (32, 32, 2, 1, 128), (20, 24, 4, 1, 256), (8, 8, 8, 3, 512)])
 def test_split_stored_qkv_feeds_the_attention_cores(ops, monkeypatch, H, W, nh, B, K):
     """qkv_packed: the qkv GEMM stores q, k, v as split-bf16 chunks and the split cores (prep='packed') take them as stored.
