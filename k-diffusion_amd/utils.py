@@ -25,7 +25,9 @@ def to_pil_image(x):
     if x.ndim == 4:
         assert x.shape[0] == 1
         x = x[0]
-    if x.is_cuda:
+    if x.dtype == torch.uint8:                          # already converted on the device (sample.py --gather-uint8)
+        u8 = x.cpu()
+    elif x.is_cuda:
         from . import ops
         u8 = ops.to_uint8(x.to(torch.float32).contiguous()).cpu()
     else:

@@ -134,6 +134,50 @@ def test_checkpoint_tools_round_trip(KD, tmp_path):
         KD.checkpoint.write_inference_checkpoint(sd, None, tmp_path / "x.safetensors")
 
 
+def test_fp8_weight_checkpoint(KD, tmp_path):
+    """convert_for_inference.py --dtype fp8 (BASELINE configs[4]; no reference counterpart, convert_for_inference.py:23): projection
+    weights stored as e4m3 + one power-of-two scale per output channel, everything else fp32; the loader's expansion is bit for
+    bit ``fake_quantize_fp8`` of the original weight and EXACT in bf16 (so the bf16 arithmetic mode runs on the fp8 weights)."""
+    import json
+    import safetensors.torch as safetorch
+    sys.path.insert(0, REPO)
+    import convert_for_inference
+    ck = KD.checkpoint
+    raw = json.load(open(os.path.join(REPO, "configs", "config_mnist_transformer.json")))
+    model = KD.config.make_model(KD.config.load_config(raw))
+    sd = KD.synth.synth_state_dict(model.state_dict(), seed=5)
+    pth = tmp_path / "run.pth"
+    torch.save({"config": raw, "model_ema": sd}, pth)
+    convert_for_inference.main([str(pth), "--dtype", "fp8", "-o", str(tmp_path / "m8.safetensors")])
+    stored = safetorch.load_file(str(tmp_path / "m8.safetensors"))
+    q_names = [k for k, v in sd.items() if ck.is_fp8_weight(k, v)]
+    assert len(q_names) > 20 and "patch_in.proj.weight" in q_names and "class_emb.weight" not in q_names and "time_emb.weight" not in q_names
+    for k in q_names:
+        assert stored[k].dtype == torch.float8_e4m3fn and stored[k + ck.FP8_SCALE_SUFFIX].shape == (sd[k].shape[0],)
+        sc = stored[k + ck.FP8_SCALE_SUFFIX]
+        assert torch.equal(torch.log2(sc), torch.log2(sc).round())                       # powers of two
+        assert (sd[k].abs().amax(1) / sc <= ck.FP8_MAX).all() and (sd[k].abs().amax(1) / sc > ck.FP8_MAX / 2 - 1e-3).all()   # the tightest such scale
+    assert all(stored[k].dtype == torch.float32 for k, v in sd.items() if v.is_floating_point() and k not in q_names)
+    loaded = ck.load_inference_checkpoint(tmp_path / "m8.safetensors")
+    ref = ck.fp8_state_dict(sd)
+    assert set(loaded) == set(sd)
+    for k in sd:
+        assert torch.equal(loaded[k], ref[k]), k
+    for k in q_names:
+        w8 = loaded[k]
+        assert torch.equal(w8.to(torch.bfloat16).float(), w8)                            # exact in bf16: 4 significand bits x 2^k
+        rel = (w8 - sd[k]).abs() / sd[k].abs().amax(1, keepdim=True)
+        assert rel.max() <= 2.0 ** -4 + 1e-6                                             # half an e4m3 step at the top binade, relative to the row maximum
+    model.load_state_dict(loaded)
+    assert KD.config.load_config(tmp_path / "m8.safetensors")["model"]["widths"] == raw["model"]["widths"]
+    assert os.path.getsize(tmp_path / "m8.safetensors") < 0.4 * sum(v.numel() * 4 for v in sd.values())
+    # a scale tensor that lost its weight (or the reverse) is an error, not a silent fp8 -> fp32 cast
+    del stored[q_names[0] + ck.FP8_SCALE_SUFFIX]
+    safetorch.save_file(stored, str(tmp_path / "bad.safetensors"))
+    with pytest.raises(ValueError, match="fp8_scale"):
+        ck.load_inference_checkpoint(tmp_path / "bad.safetensors")
+
+
 def test_sample_cli_contract():
     sys.path.insert(0, REPO)
     import sample
@@ -177,6 +221,66 @@ if ctx.is_main_process:
     torch.save(out, {out!r})
 ctx.shutdown()
 """
+
+
+_WORKER_INDEXED = r"""
+import os, sys, torch
+sys.path.insert(0, {repo!r})
+import k_diffusion_amd as K
+import sample
+ctx = K.distributed.RankContext(device="cpu", backend="gloo")
+assert ctx.num_processes == {world}
+args = sample.parse(["--config", "c.json", "--random-weights", "--seed", "9", "--class-cond", "-1", "-n", "{n}", "--batch-size", "{bs}"])
+shape, calls = (1, 4, 4), []
+def sample_fn(idx):                     # stands in for model + sampler: a pure function of the GLOBAL image indices it is given
+    calls.append(len(idx))
+    if len(idx) == 0:
+        return torch.empty(0, 3, 4, 4)
+    x0 = torch.stack([K.synth.synth_noise(shape, args.seed, int(g), 1.0) for g in idx])
+    cc = sample.class_ids(args, 10, idx, "cpu")
+    bseed = torch.tensor(sample.brownian_seeds(args.seed, idx), dtype=torch.int64)
+    noise = sample.indexed_noise_sampler(args.seed, idx, shape, "cpu")
+    n1, n2 = noise(None, None), noise(None, None)
+    feat = torch.cat([x0, (cc.float() / 10)[:, None, None, None].expand_as(x0) + n1 * 1e-3, ((bseed % 1000).float() / 1000)[:, None, None, None] + n2 * 1e-3], dim=1)
+    return feat.clamp(-1, 1)
+lo, hi = K.distributed.shard_range({n}, ctx.num_processes, ctx.process_index)
+out = K.evaluation.compute_features_indexed(ctx, sample_fn, {n}, {bs})
+out8 = K.evaluation.compute_features_indexed(ctx, sample_fn, {n}, {bs}, post=lambda x: (((x + 1) / 2) * 255).to(torch.uint8))
+assert sum(calls) == 2 * (hi - lo), (calls, lo, hi)            # every rank sampled exactly its own shard, nothing else
+ctx.wait_for_everyone()
+if ctx.is_main_process:
+    torch.save((out, out8), {out!r})
+ctx.shutdown()
+"""
+
+
+@pytest.mark.parametrize("world,n,bs,port", [(8, 21, 2, 29641), (2, 7, 4, 29642), (8, 5, 3, 29643)])
+def test_indexed_gather_many_ranks_over_gloo(KD, tmp_path, world, n, bs, port):
+    """The data-parallel sampling schedule of sample.py on 8 (and 2) gloo ranks with an n the ranks do not divide (the last
+    ranks get short or EMPTY shards): out[i] is image i -- start noise, class id, Brownian-tree seed and ancestral noise stream
+    all functions of the global index -- identical to a single-process run, also through the uint8 gather."""
+    sys.path.insert(0, REPO)
+    import sample
+    out = str(tmp_path / "gathered.pt")
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER_INDEXED.format(repo=REPO, out=out, world=world, n=n, bs=bs))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got, got8 = torch.load(out)
+    shape = (1, 4, 4)
+    idx = torch.arange(n)
+    x0 = torch.stack([KD.synth.synth_noise(shape, 9, int(g), 1.0) for g in idx])
+    noise = sample.indexed_noise_sampler(9, idx, shape, "cpu")
+    n1, n2 = noise(None, None), noise(None, None)
+    bseed = torch.tensor(sample.brownian_seeds(9, idx), dtype=torch.int64)
+    assert len(set(bseed.tolist())) == n and (bseed >= 0).all()
+    expect = torch.cat([x0, ((idx % 10).float() / 10)[:, None, None, None].expand_as(x0) + n1 * 1e-3,
+                        ((bseed % 1000).float() / 1000)[:, None, None, None] + n2 * 1e-3], dim=1).clamp(-1, 1)
+    assert got.shape == (n, 3, 4, 4) and torch.equal(got, expect)
+    assert got8.dtype == torch.uint8 and torch.equal(got8, (((expect + 1) / 2) * 255).to(torch.uint8))
 
 
 def test_two_rank_gather_over_gloo(KD, tmp_path):
