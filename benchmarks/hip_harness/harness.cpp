@@ -609,6 +609,12 @@ int main(int argc, char** argv) {
         {"astat ragged geglu", 1000, 192, 256, KD_EPI_GEGLU, 1, 50, 0},
     };
     for (const auto& c : ca) run_gemm_case(c);
+    for (int rows : {128, 256, 128, 256}) {
+      kd_set_option("astat_rows", rows);
+      printf("-- astat_rows = %d\n", rows);
+      for (int i = 0; i < 5; ++i) run_gemm_case(ca[i]);
+    }
+    kd_set_option("astat_rows", 0);
     for (int sp : {1, 2, 3, 6}) {
       kd_set_option("astat_splits", sp);
       printf("-- astat_splits = %d\n", sp);

@@ -569,37 +569,52 @@ int gemm_tiled_try(const KdGemm& d, hipStream_t s, int* rc) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // astat: AdaRMSNorm -> wide projection (qkv, up-projection + GEGLU) at K = 256 / 512, where the weight is too large to park.
-// A workgroup (4 waves) owns a 128-row panel for a range of n-tiles: each wave keeps its 32 rows of the normalised, scaled
-// panel in registers as B-operand fragments (read and converted once), the packed weight streams through a 4-slot LDS ring
-// (one 16 KiB block = [128 features][64 k] per slot, global_load_lds three blocks ahead, counted vmcnt, one barrier per block),
-// the epilogue of an n-tile runs in the lanes that own the rows while the next blocks are in flight.  Two workgroups per CU.
-// vmcnt bookkeeping (loads and stores retire in issue order): the blocks needed right after an epilogue are confirmed BEFORE
-// its stores enter the queue; the first wait behind them allows exactly those stores to stay outstanding (full panels only).
-template <int NC, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const GArgs p) {
-  constexpr int K = NC * 16, NK = NC / 4, NSTG = 4;
+// A workgroup of NWV waves owns a panel of 32 NWV rows for a range of n-tiles: each wave keeps its 32 rows of the normalised,
+// scaled panel in registers as B-operand fragments (read and converted once), the packed weight streams through an LDS ring
+// (one 16 KiB block = [128 features][64 k] per slot, global_load_lds NSTG - 1 blocks ahead, counted vmcnt, one barrier per
+// block), the epilogue of an n-tile runs in the lanes that own the rows while the next blocks are in flight.
+//   NWV = 4: 128-row panels, 4-slot ring, two workgroups per CU (small M: more, smaller units);
+//   NWV = 8: 256-row panels, 8-slot ring, one workgroup per CU -- every block that crosses the L2 -> LDS path (39-52 bytes / clock /
+//            CU measured, profiles/r02_harness_*.log) now feeds 256 rows instead of 128: at two 128-row workgroups per CU the
+//            weight stream alone asked for ~50 bytes / clock / CU, i.e. that path, not the matrix pipe, set the pace.
+// vmcnt bookkeeping (loads and stores retire in issue order): the wait before block s allows the blocks requested after it AND the
+// epilogue stores issued after it to stay outstanding (full panels only; ragged panels wait for their stores).
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+  switch (n) {
+#define KD_C(v) case v: asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); break;
+    KD_C(0) KD_C(1) KD_C(2) KD_C(3) KD_C(4) KD_C(5) KD_C(6) KD_C(7) KD_C(8) KD_C(9) KD_C(10) KD_C(11) KD_C(12) KD_C(13) KD_C(14) KD_C(15)
+    KD_C(16) KD_C(17) KD_C(18) KD_C(19) KD_C(20) KD_C(21) KD_C(22) KD_C(23) KD_C(24) KD_C(25) KD_C(26) KD_C(27) KD_C(28) KD_C(29) KD_C(30) KD_C(31)
+    KD_C(32) KD_C(33) KD_C(34) KD_C(35) KD_C(36) KD_C(37) KD_C(38) KD_C(39) KD_C(40)
+#undef KD_C
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+template <int NC, int EPI, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_astat_kernel(const GArgs p) {
+  constexpr int K = NC * 16, NK = NC / 4, NSTG = NWV == 4 ? 4 : 8, PDIST = NSTG - 1;
+  constexpr int PB = 16 / NWV;                       // 1 KiB pieces of a block per wave
   constexpr bool GEGLU = EPI == KD_EPI_GEGLU;
   constexpr int NCOL = GEGLU ? 64 : 128;
   constexpr int NST = GEGLU ? 4 : 8;                 // 16-byte stores per lane per n-tile
-  static_assert(NK % NSTG == 0, "ring slot of a block must be a compile-time constant");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int nt_begin = (int)((long)p.n_tiles * blockIdx.y / gridDim.y), nt_end = (int)((long)p.n_tiles * (blockIdx.y + 1) / gridDim.y);
   const int n_tiles = nt_end - nt_begin, total = n_tiles * NK;
-  const int m0 = blockIdx.x * 128;
+  const int m0 = blockIdx.x * (32 * NWV);
 
-  const char* wp = p.Wp + (size_t)nt_begin * NK * WBLK + wid * 4096 + lane * 16;
+  const char* wp = p.Wp + (size_t)nt_begin * NK * WBLK + wid * (PB * 1024) + lane * 16;
   auto issue = [&](int s) {
     const char* src = wp + (size_t)s * WBLK;
-    char* dst = smem + (s % NSTG) * WBLK + wid * 4096;
+    char* dst = smem + (s % NSTG) * WBLK + wid * (PB * 1024);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < PB; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 1024),
                                        (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
   };
-  issue(0);
-  issue(1);
-  issue(2);
+#pragma unroll
+  for (int s = 0; s < PDIST; ++s)
+    if (s < total) issue(s);
 
   const int row = m0 + wid * 32 + l31;
   const bool ok = row < p.M;
@@ -647,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const GArgs p) {
     py = p.pos[2 * tok];
     px = p.pos[2 * tok + 1];
   }
-  const bool full_panel = m0 + 128 <= p.M;
+  const bool full_panel = m0 + 32 * NWV <= p.M;
   // every ordinary load above has been consumed (the compiler waited for them, which also drained the first ring blocks)
 
   int off4[4];
@@ -665,17 +680,19 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const GArgs p) {
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
       const int s = nt * NK + ks;
-      if (nt > 0 && ks == 2 && full_panel) {
-        // queue: [block s][NST epilogue stores][block s+1][block s+2]
-        if (s + 2 < total) { if (NST == 4) KD_WAIT_VM(12); else KD_WAIT_VM(16); }
-        else if (s + 1 < total) { if (NST == 4) KD_WAIT_VM(8); else KD_WAIT_VM(12); }
-        else { if (NST == 4) KD_WAIT_VM(4); else KD_WAIT_VM(8); }
-      } else if (nt == 0 || ks >= 2) {
-        if (s + 2 < total) KD_WAIT_VM(8); else if (s + 1 < total) KD_WAIT_VM(4); else KD_WAIT_VM(0);
+      {
+        // behind block s in the queue: the blocks requested after it, and the stores of the epilogues that ran since its request
+        // (block s was requested in step s - PDIST; the epilogue of a tile follows its last step, ks + 1 resp. ks + 1 + NK steps ago)
+        int allow = PB * min(PDIST - 1, total - 1 - s);
+        if (full_panel) {
+          if (nt > 0 && ks + 1 <= PDIST) allow += NST;
+          if (nt > 1 && ks + 1 + NK <= PDIST) allow += NST;
+        }
+        wait_vm_dyn(allow);
       }
-      KD_BARRIER();                      // every wave's quarter of block s is in; everyone is done reading slot (s-1) % NSTG
-      if (s + 3 < total) issue(s + 3);
-      const char* st = smem + (ks % NSTG) * WBLK;
+      KD_BARRIER();                      // every wave's share of block s is in; everyone is done reading slot (s-1) % NSTG
+      if (s + PDIST < total) issue(s + PDIST);
+      const char* st = smem + (s % NSTG) * WBLK;
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
 #pragma unroll
@@ -695,8 +712,6 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const GArgs p) {
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // blocks (nt+1, ks = 0, 1) were requested >= 2 blocks ago: confirm them before this epilogue's stores enter the queue
-    if (nt + 1 < n_tiles) KD_WAIT_VM(4);
     const int n0 = (nt_begin + nt) * NCOL;
     if (GEGLU) {
 #pragma unroll
@@ -749,29 +764,40 @@ __global__ __launch_bounds__(256, 2) void gemm_astat_kernel(const GArgs p) {
   }
 }
 
-template <int NC, int EPI>
-static int launch_astat(const GArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {
-  auto kern = gemm_astat_kernel<NC, EPI>;
-  constexpr int LDS = 4 * WBLK;
+template <int NC, int EPI, int NWV>
+static int launch_astat_w(const GArgs& a, int splits, const char* nm, double flops, double bytes, hipStream_t s) {
+  auto kern = gemm_astat_kernel<NC, EPI, NWV>;
+  constexpr int LDS = (NWV == 4 ? 4 : 8) * WBLK;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  // panels x n-splits: two workgroups fit a CU; split the n-tiles of a panel until the grid fills them
-  const int panels = (a.M + 127) / 128;
-  const int want = 2 * cu_count();
-  int splits = 1;
-  for (int sp = 1; sp <= a.n_tiles; ++sp) {
-    if (a.n_tiles % sp) continue;
-    splits = sp;
-    if (panels * sp >= want) break;
-  }
-  const int forced = option("astat_splits", 0);
-  if (forced > 0 && forced <= a.n_tiles) splits = forced;
+  const int panels = (a.M + 32 * NWV - 1) / (32 * NWV);
   LaunchScope prof(nm, flops, bytes, s);
-  hipLaunchKernelGGL(kern, dim3((unsigned)panels, (unsigned)splits), dim3(256), LDS, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)panels, (unsigned)splits), dim3(NWV * 64), LDS, s, a);
   return check_launch("kd_gemm_bf16(astat)");
+}
+
+template <int NC, int EPI>
+static int launch_astat(const GArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {
+  // panels x n-splits.  256-row panels (one workgroup per CU) whenever they still give every CU a workgroup; otherwise
+  // 128-row panels, two workgroups per CU, n-tiles split until the grid fills them.
+  auto pick = [&](int panels, int want) {
+    int splits = 1;
+    for (int sp = 1; sp <= a.n_tiles; ++sp) {
+      if (a.n_tiles % sp) continue;
+      splits = sp;
+      if (panels * sp >= want) break;
+    }
+    return splits;
+  };
+  const int forced = option("astat_splits", 0), rows = option("astat_rows", 0);
+  const int p256 = (a.M + 255) / 256, s256 = pick(p256, cu_count());
+  const bool wide = rows ? rows == 256 : (p256 * s256 >= cu_count() * 3 / 4);
+  if (wide) return launch_astat_w<NC, EPI, 8>(a, forced > 0 && forced <= a.n_tiles ? forced : s256, nm, flops, bytes, s);
+  const int s128 = pick((a.M + 127) / 128, 2 * cu_count());
+  return launch_astat_w<NC, EPI, 4>(a, forced > 0 && forced <= a.n_tiles ? forced : s128, nm, flops, bytes, s);
 }
 
 int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
