@@ -781,8 +781,8 @@ static int launch_astat_w(const GArgs& a, int splits, const char* nm, double flo
 
 template <int NC, int EPI>
 static int launch_astat(const GArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {
-  // panels x n-splits.  256-row panels (one workgroup per CU) whenever they still give every CU a workgroup; otherwise
-  // 128-row panels, two workgroups per CU, n-tiles split until the grid fills them.
+  // panels x n-splits: 128-row panels, two workgroups per CU, n-tiles split until the grid fills them ("astat_rows" = 256: the
+  // 256-row / one-workgroup-per-CU form).
   auto pick = [&](int panels, int want) {
     int splits = 1;
     for (int sp = 1; sp <= a.n_tiles; ++sp) {
@@ -794,7 +794,9 @@ static int launch_astat(const GArgs& a, const char* nm, double flops, double byt
   };
   const int forced = option("astat_splits", 0), rows = option("astat_rows", 0);
   const int p256 = (a.M + 255) / 256, s256 = pick(p256, cu_count());
-  const bool wide = rows ? rows == 256 : (p256 * s256 >= cu_count() * 3 / 4);
+  // measured (harness "astat", profiles/r02_harness_astat_rows.log): the 256-row form is never faster (L1 qkv 30.4 vs 28.2 us, L2 qkv
+  // 47.0 vs 38.6, the GEGLU shapes equal) -- the L2 -> LDS stream it halves is not what limits these kernels -- so it runs on request only
+  const bool wide = rows == 256;
   if (wide) return launch_astat_w<NC, EPI, 8>(a, forced > 0 && forced <= a.n_tiles ? forced : s256, nm, flops, bytes, s);
   const int s128 = pick((a.M + 127) / 128, 2 * cu_count());
   return launch_astat_w<NC, EPI, 4>(a, forced > 0 && forced <= a.n_tiles ? forced : s128, nm, flops, bytes, s);
