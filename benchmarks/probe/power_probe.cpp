@@ -76,6 +76,44 @@ __global__ __launch_bounds__(1024) void work_kernel(int iters, float* sink, unsi
   }
 }
 
+// MFMA whose A operand comes from LDS (one conflict-free ds_read_b128 per MFMA, requested 4 slots ahead), like the W fragments of
+// the GEMM kernels; DO_MFMA = 0 leaves only the reads (their values are consumed by a cheap xor so they are not dead).
+template <int DO_MFMA, int READS_PER_MFMA>
+__global__ __launch_bounds__(512) void lds_kernel(int iters, float* sink, unsigned long long* clk) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 16384; i += blockDim.x) reinterpret_cast<float*>(lds)[i] = 0.001f * i;
+  __syncthreads();
+  unsigned long long t0 = 0, r0 = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  bf16x8 b;
+  for (int i = 0; i < 8; ++i) b[i] = (__bf16)(0.002f * (lane - i));
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+  u32x4 keep = {0, 0, 0, 0};
+  const char* base = lds + lane * 16;
+  u32x4 frag[8];
+  for (int i = 0; i < 8; ++i) frag[i] = *reinterpret_cast<const u32x4*>(base + i * 1024);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (DO_MFMA) acc[s & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, frag[s & 7]), b, acc[s & 3], 0, 0, 0);
+      else keep ^= frag[s & 7];
+#pragma unroll
+      for (int u = 0; u < READS_PER_MFMA; ++u) frag[(s + 4 + u) & 7] = *reinterpret_cast<const u32x4*>(base + ((s * READS_PER_MFMA + u + it) & 31) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float sum = 0.f;
+  for (int j = 0; j < 4; ++j) sum += acc[j][0] + acc[j][7];
+  if (sum == 12345.678f || keep[0] == 0x12345678u) sink[threadIdx.x] = sum + keep[1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = __builtin_amdgcn_s_memtime() - t0;
+    clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+  }
+}
+
 __global__ __launch_bounds__(256) void stream_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     float4 x = src[i];
@@ -193,6 +231,16 @@ int main() {
   measure("mfma+valu (1:4), AGPR", smp, [&] { hipLaunchKernelGGL((work_kernel<1, 1, 4, 1>), dim3(cus), dim3(512), 0, 0, iters, sink, clk); }, mfma_flops * 1e-6, "TFLOP/s", clk);
   measure("mfma+valu (1:4), 4 waves", smp, [&] { hipLaunchKernelGGL((work_kernel<1, 1, 4>), dim3(cus), dim3(256), 0, 0, iters, sink, clk); }, mfma_flops * 0.5e-6, "TFLOP/s", clk);
   measure("mfma+valu (1:4), 16 waves", smp, [&] { hipLaunchKernelGGL((work_kernel<1, 1, 4>), dim3(cus), dim3(1024), 0, 0, iters, sink, clk); }, mfma_flops * 2e-6, "TFLOP/s", clk);
+  // MFMA fed from LDS, on 16 CUs (full clock): do the fragment reads hide behind the MFMAs?
+  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  const double lds_bytes16 = 16.0 * 8 * 64 * 16.0 * iters * 16;      // 16 CUs x 8 waves x 1 KiB per read
+  measure("lds reads only, 16 CUs", smp, [&] { hipLaunchKernelGGL((lds_kernel<0, 1>), dim3(16), dim3(512), 65536, 0, iters, sink, clk); }, lds_bytes16 * 1e-3, "GB/s", clk);
+  measure("mfma + 1 read, 16 CUs", smp, [&] { hipLaunchKernelGGL((lds_kernel<1, 1>), dim3(16), dim3(512), 65536, 0, iters, sink, clk); }, mfma_flops / cus * 16e-6, "TFLOP/s", clk);
+  measure("2 reads only, 16 CUs", smp, [&] { hipLaunchKernelGGL((lds_kernel<0, 2>), dim3(16), dim3(512), 65536, 0, iters, sink, clk); }, 2 * lds_bytes16 * 1e-3, "GB/s", clk);
+  measure("mfma + 2 reads, 16 CUs", smp, [&] { hipLaunchKernelGGL((lds_kernel<1, 2>), dim3(16), dim3(512), 65536, 0, iters, sink, clk); }, mfma_flops / cus * 16e-6, "TFLOP/s", clk);
   // a quarter of the CUs: far below any power limit -- does the sum rule survive?
   const int q = cus / 4;
   measure("mfma, 64 CUs", smp, [&] { hipLaunchKernelGGL((work_kernel<1, 0, 8>), dim3(q), dim3(512), 0, 0, iters, sink, clk); }, mfma_flops * 0.25e-6, "TFLOP/s", clk);

@@ -1,15 +1,16 @@
 // bf16-mode GEMMs of the HDiT denoiser for gfx950 (see bf16_common.h for the operand formats and the swapped product).
 //
-// Every kernel here is built around one measured fact of this chip: a CU takes ~10-13 bytes / clock through its vector-memory
-// path, L2 hits included, i.e. the bytes a workgroup pulls INTO the CU cost about as much as HBM bytes.  At the level-0 shapes
-// (131 072 rows, K = 128 / 384) the weight re-streamed per row panel was as much traffic as the activations themselves, so:
+// What shapes these kernels (measured: profiles/r02_pipe_overlap.md, r02_harness_*.log): a SIMD issues no vector instruction
+// while it runs an MFMA (time = MFMA passes + vector issue slots + unhidden waits, so the COUNT of vector instructions per MFMA
+// matters, not their placement); LDS fragment reads hide behind MFMAs; HBM gives 5.0-5.6 TB/s to a pure stream and the level-0
+// shapes (131 072 rows, K = 128 / 384) are bound by it; L2 -> LDS through global_load_lds sustains 39-52 bytes / clock / CU.
 //
 //   wstat  "W-stationary": a persistent workgroup per CU parks its slice of the packed weight (<= 144 KiB) in LDS ONCE; its waves
 //          then walk 32-row chunks of A independently: the chunk goes HBM -> registers as MFMA B-operand fragments (RMS statistics
 //          and the AdaRMSNorm scale applied on the way), every weight fragment comes from LDS, the epilogue runs in the lane that
 //          owns the row (no LDS, no cross-lane traffic but one half-wave exchange) and stores 16 bytes per lane.  After the
-//          initial weight copy there is NO barrier and no counted wait: 8-12 waves per CU sit in different phases, so one wave's
-//          loads, another's MFMAs and a third's epilogue overlap by construction.
+//          initial weight copy there is NO barrier and no counted wait: the 8 waves of a CU sit in different phases, so one wave's
+//          memory waits are covered by the others' MFMA / epilogue work.
 //   (astat / tiled forms for the deeper levels follow below.)
 #include "bf16_common.h"
 
