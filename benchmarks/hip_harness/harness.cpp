@@ -200,16 +200,19 @@ static void run_gemm_case(const GemmCase& c) {
     }
   }
   const float us = time_us([&] { kd_gemm_bf16(&d, nullptr); });
-  char clk_note[64] = "";
-  if (strstr(c.name, "wstat") || strstr(c.name, "clock")) {       // shader clock under this kernel's load (s_memtime vs the 100 MHz s_memrealtime)
-    DevBuf<unsigned long long> dClk(4);
-    HIPCHK(hipMemset(dClk.p, 0, 32));
+  char clk_note[256] = "";
+  if (strstr(c.name, "wstat") || strstr(c.name, "clock") || strstr(c.name, "astat")) {       // shader clock under this kernel's load (s_memtime vs the 100 MHz s_memrealtime)
+    DevBuf<unsigned long long> dClk(8);
+    HIPCHK(hipMemset(dClk.p, 0, 64));
     kd_prof_clock_buffer(dClk.p);
     for (int i = 0; i < 20; ++i) kd_gemm_bf16(&d, nullptr);
     HIPCHK(hipDeviceSynchronize());
     kd_prof_clock_buffer(nullptr);
     auto ck = dClk.down();
     if (ck[3] > ck[1]) snprintf(clk_note, sizeof(clk_note), "  clk %.2f GHz", (double)(ck[2] - ck[0]) / (double)(ck[3] - ck[1]) * 0.1);
+    if (ck[3] > ck[1] && ck[4])      // astat time line of workgroup 0 (shader clocks): whole / row prologue / first tile K loop / its epilogue; ring blocks
+      snprintf(clk_note + strlen(clk_note), sizeof(clk_note) - strlen(clk_note), "  wg0: %llu clk = prologue %llu + [K loop %llu + epilogue %llu] x tiles (%llu blocks)",
+               ck[2] - ck[0], ck[4] - ck[0], ck[5] - ck[4], ck[6] - ck[5], ck[7]);
   }
   const double flops = 2.0 * M * (double)NW * K;
   const double bytes = 2.0 * ((double)M * K + (double)M * N + ((c.epi == KD_EPI_RESIDUAL || split) ? (double)M * N : 0.0));

@@ -600,10 +600,25 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_astat_kernel(
   constexpr int NST = GEGLU ? 4 : 8;                 // 16-byte stores per lane per n-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int nt_begin = (int)((long)p.n_tiles * blockIdx.y / gridDim.y), nt_end = (int)((long)p.n_tiles * (blockIdx.y + 1) / gridDim.y);
+  // workgroup -> (row panel, n-split).  Workgroups go to the 8 XCDs round-robin by id: with the panel count a multiple of 8 the
+  // splits of ONE panel are given ids 8 apart, i.e. they run on one XCD at about the same time and its L2 fetches the panel's rows
+  // from HBM once instead of once per split (at level 2 the 8 splits otherwise read 67 MB for an 8 MB activation).
+  int panel, split;
+  const int n_splits = p.n_slices, n_panels = gridDim.x / n_splits;
+  if ((n_panels & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    panel = (j / n_splits) * 8 + xcd;
+    split = j % n_splits;
+  } else {
+    panel = blockIdx.x % n_panels;
+    split = blockIdx.x / n_panels;
+  }
+  const int nt_begin = (int)((long)p.n_tiles * split / n_splits), nt_end = (int)((long)p.n_tiles * (split + 1) / n_splits);
   const int n_tiles = nt_end - nt_begin, total = n_tiles * NK;
-  const int m0 = blockIdx.x * (32 * NWV);
+  const int m0 = panel * (32 * NWV);
 
+  const bool probe = p.clk && blockIdx.x == 0 && tid == 0;      // kd_prof_clock_buffer: workgroup 0's time line
+  if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
   const char* wp = p.Wp + (size_t)nt_begin * NK * WBLK + wid * (PB * 1024) + lane * 16;
   auto issue = [&](int s) {
     const char* src = wp + (size_t)s * WBLK;
@@ -613,9 +628,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_astat_kernel(
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 1024),
                                        (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
   };
-#pragma unroll
-  for (int s = 0; s < PDIST; ++s)
-    if (s < total) issue(s);
 
   const int row = m0 + wid * 32 + l31;
   const bool ok = row < p.M;
@@ -623,31 +635,80 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_astat_kernel(
   bf16x8 a[NC];
   float rs;
   {
-    const u32x4* ap = reinterpret_cast<const u32x4*>(p.A + (size_t)rowc * K + 8 * lh);
     const int b = rowc / p.rows_per_sample;
     const float* sp = p.scale + (size_t)b * p.scale_stride + 8 * lh;
     float ssq = 0.f;
-    // groups of 4 chunks, fenced: the loads of one group are in flight while the previous one is converted, and the live set
-    // stays at the fragments plus one group of raw rows / scales (all loads hoisted to the top would not fit the register file)
+    // The wave's 32 rows come in through LDS: global_load_lds reads them as WHOLE rows (1 KiB contiguous per instruction, fully
+    // coalesced) into the ring slot the wave borrows before the weight stream starts, and every lane then picks its own row's
+    // fragments out of LDS.  Reading them straight from HBM, one 16-byte chunk per lane per instruction (32 different rows per
+    // instruction, every 128-byte line touched by four instructions), cost 12 000 - 25 000 of the workgroup's 40 000 - 65 000
+    // clocks (kd_prof_clock_buffer time line, profiles/r02_astat_timeline.md).  Chunk q of row r sits at slot q ^ (r & 15) of its
+    // row image (source-side permutation), so the 16 lanes of a ds_read_b128 pass hit 16 different bank groups.
+    constexpr int RPR = WBLK / (2 * K);                // rows per staging round (one 16 KiB slot): 16 at K = 512, 32 at K = 256
+    constexpr int NR = 32 / RPR, CPR = K / 8;          // rounds; 16-byte chunks per row
+    static_assert(RPR >= 16 && NR * RPR == 32, "staging geometry");
+    u32x4 raw[NC];
+    char* stage = smem + wid * WBLK;
+    // the sample's scale vector (K floats) goes to a small LDS area of the wave as well when its 32 rows share one sample (every
+    // real shape): 32 lanes asking L2 for the same 32 bytes, chunk after chunk, was the other half of the prologue
+    char* scl = smem + NSTG * WBLK + wid * (K * 4);
+    const int r_first = min(m0 + wid * 32, p.M - 1), r_last = min(m0 + wid * 32 + 31, p.M - 1);
+    const bool uni = r_first / p.rows_per_sample == r_last / p.rows_per_sample;
+    if (uni) {
+      const char* ssrc = reinterpret_cast<const char*>(p.scale + (size_t)(r_first / p.rows_per_sample) * p.scale_stride) + lane * 16;
 #pragma unroll
-    for (int c0 = 0; c0 < NC; c0 += 4) {
-      u32x4 raw[4];
-      f32x4 s0[4], s1[4];
+      for (int i = 0; i < K * 4 / 1024; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc + i * 1024),
+                                         (__attribute__((address_space(3))) void*)(scl + i * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rr = (i * 64 + lane) / CPR, qs = (i * 64 + lane) % CPR;        // LDS row of this lane's piece, its slot in the row
+        const int grow = min(m0 + wid * 32 + r * RPR + rr, p.M - 1);
+        const char* src = reinterpret_cast<const char*>(p.A + (size_t)grow * K) + ((qs ^ (rr & 15)) << 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + i * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // wave-private slot: no barrier
+      if (NR == 1 || (l31 / RPR) == r) {
+        const int rr = l31 % RPR;
+        const char* rowp = stage + rr * (2 * K);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) raw[c] = *reinterpret_cast<const u32x4*>(rowp + (((2 * c + lh) ^ (rr & 15)) << 4));
+      }
+      if (NR > 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is overwritten by the next round
+    }
+    f32x4 s0[2][4], s1[2][4];
+    const float* spl = reinterpret_cast<const float*>(scl) + 8 * lh;
+    auto load_scales = [&](int c0, int g) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        raw[u] = ap[2 * (c0 + u)];
-        s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
-        s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
+        if (uni) {
+          s0[g][u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
+          s1[g][u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
+        } else {
+          s0[g][u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
+          s1[g][u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
+        }
       }
+    };
+    load_scales(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c0 = 0; c0 < NC; c0 += 4) {
+      const int g = (c0 >> 2) & 1;
+      if (c0 + 4 < NC) load_scales(c0 + 4, g ^ 1);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { x[2 * e] = bf_lo(raw[u][e]); x[2 * e + 1] = bf_hi(raw[u][e]); }
+        for (int e = 0; e < 4; ++e) { x[2 * e] = bf_lo(raw[c0 + u][e]); x[2 * e + 1] = bf_hi(raw[c0 + u][e]); }
 #pragma unroll
         for (int e = 0; e < 8; ++e) ssq = fmaf(x[e], x[e], ssq);
-        u32x4 o = {pack_bf16(x[0] * s0[u][0], x[1] * s0[u][1]), pack_bf16(x[2] * s0[u][2], x[3] * s0[u][3]),
-                   pack_bf16(x[4] * s1[u][0], x[5] * s1[u][1]), pack_bf16(x[6] * s1[u][2], x[7] * s1[u][3])};
+        u32x4 o = {pack_bf16(x[0] * s0[g][u][0], x[1] * s0[g][u][1]), pack_bf16(x[2] * s0[g][u][2], x[3] * s0[g][u][3]),
+                   pack_bf16(x[4] * s1[g][u][0], x[5] * s1[g][u][1]), pack_bf16(x[6] * s1[g][u][2], x[7] * s1[g][u][3])};
         asm volatile("" : "+v"(o));      // materialise the fragment HERE: hipcc otherwise sinks the multiply + pack down to the
                                          // first MFMA that uses it and keeps x and the scales (4x the registers) alive until then
         a[c0 + u] = __builtin_bit_cast(bf16x8, o);
@@ -663,7 +724,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_astat_kernel(
     py = p.pos[2 * tok];
     px = p.pos[2 * tok + 1];
   }
+  KD_BARRIER();                                        // every wave has taken its rows out of the slot it borrowed
+#pragma unroll
+  for (int s = 0; s < PDIST; ++s)
+    if (s < total) issue(s);
   const bool full_panel = m0 + 32 * NWV <= p.M;
+  if (probe) p.clk[4] = __builtin_amdgcn_s_memtime();          // end of the row prologue
   // every ordinary load above has been consumed (the compiler waited for them, which also drained the first ring blocks)
 
   int off4[4];
@@ -694,26 +760,27 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_astat_kernel(
       KD_BARRIER();                      // every wave's share of block s is in; everyone is done reading slot (s-1) % NSTG
       if (s + PDIST < total) issue(s + PDIST);
       const char* st = smem + (s % NSTG) * WBLK;
+      // explicit double buffer, one sched_barrier per chunk: the 4 fragment reads of chunk cc + 1 go out BEFORE the 4 MFMAs of
+      // chunk cc (left to itself the scheduler, short of registers at K = 512, emits read / wait / MFMA triples and every MFMA
+      // eats a full LDS latency)
+      bf16x8 wf[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[0][j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 128 + off4[0]);
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
+        if (cc + 1 < 4) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(st + j * 32 * 128 + off4[cc]);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, a[4 * ks + cc], acc[j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) wf[(cc + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 128 + off4[cc + 1]);
         }
-      }
-      // issue order: the 4 fragment reads of chunk cc+1 go out before the 4 MFMAs of chunk cc (two chunks of fragments live,
-      // not the whole block: with K = 512 the A fragments already hold half the register file)
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) {
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cc & 1][j], a[4 * ks + cc], acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
     const int n0 = (nt_begin + nt) * NCOL;
+    if (probe && nt == 0) p.clk[5] = __builtin_amdgcn_s_memtime();    // end of the first tile's K loop
     if (GEGLU) {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
@@ -758,25 +825,29 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_astat_kernel(
         store_block_bf16(crow + n0 + 32 * j, v, lh, ok);
       }
     }
+    if (probe && nt == 0) p.clk[6] = __builtin_amdgcn_s_memtime();    // end of the first tile's epilogue
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   }
+  if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)total; }
 }
 
 template <int NC, int EPI, int NWV>
 static int launch_astat_w(const GArgs& a, int splits, const char* nm, double flops, double bytes, hipStream_t s) {
   auto kern = gemm_astat_kernel<NC, EPI, NWV>;
-  constexpr int LDS = (NWV == 4 ? 4 : 8) * WBLK;
+  constexpr int LDS = (NWV == 4 ? 4 : 8) * WBLK + NWV * NC * 64;      // ring + one scale vector (K floats) per wave
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   const int panels = (a.M + 32 * NWV - 1) / (32 * NWV);
+  GArgs b = a;
+  b.n_slices = splits;                                // (the astat kernel's use of this field: n-splits per panel)
   LaunchScope prof(nm, flops, bytes, s);
-  hipLaunchKernelGGL(kern, dim3((unsigned)panels, (unsigned)splits), dim3(NWV * 64), LDS, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(panels * splits)), dim3(NWV * 64), LDS, s, b);
   return check_launch("kd_gemm_bf16(astat)");
 }
 
@@ -817,6 +888,7 @@ int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
   a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample; a.eps = d.eps;
   a.M = d.M; a.N = d.N; a.n_tiles = d.N / ncol;
   a.n_heads = d.n_heads; a.qk_scale = d.qk_scale; a.pos = d.rope_pos; a.freq = d.rope_freq;
+  a.clk = g_clk;
   const double n_eff = geglu ? 2.0 * d.N : (double)d.N;
   const double flops = 2.0 * d.M * n_eff * d.K;
   const double bytes = 2.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N);
