@@ -279,6 +279,18 @@ static void run_ffn_case(const char* name, int M, int K, int dff, int rps) {
     }
   }
   const float us = time_us([&] { kd_ffn_bf16(&f, nullptr); });
+  {   // time line of workgroup 0 (shader clocks)
+    DevBuf<unsigned long long> dClk(8);
+    HIPCHK(hipMemset(dClk.p, 0, 64));
+    kd_prof_clock_buffer(dClk.p);
+    for (int i = 0; i < 5; ++i) kd_ffn_bf16(&f, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    kd_prof_clock_buffer(nullptr);
+    auto ck = dClk.down();
+    if (ck[3] > ck[1])
+      printf("  clk %.2f GHz  wg0: %llu clk = rows in + norm %llu + %llu tiles %llu + skip / store %llu\n", (double)(ck[2] - ck[0]) / (double)(ck[3] - ck[1]) * 0.1,
+             ck[2] - ck[0], ck[4] - ck[0], ck[7], ck[5] - ck[4], ck[2] - ck[5]);
+  }
   // the two-kernel form on the same data
   KdGemm u, d;
   memset(&u, 0, sizeof(u)); memset(&d, 0, sizeof(d));
@@ -647,6 +659,19 @@ int main(int argc, char** argv) {
       for (const auto& c : ct) run_gemm_case(c);
     }
     kd_set_option("tiled_bm", 0);
+    for (int deep : {0, 1, 0, 1}) {
+      kd_set_option("tiled_deep", deep);
+      printf("-- tiled_deep = %d (4-slot ring for grids of at most one tile per CU)\n", deep);
+      const GemmCase cd[] = {
+          {"tiled L2 out+res", 8192, 512, 512, KD_EPI_RESIDUAL, 0, 256, 0},
+          {"tiled L2 down+res", 8192, 512, 1536, KD_EPI_RESIDUAL, 0, 256, 0},
+          {"tiled merge1", 8192, 512, 1024, KD_EPI_STORE, 0, 256, 0, KD_A_MERGE2x2, 16, 16},
+          {"tiled ragged res", 300, 160, 64, KD_EPI_RESIDUAL, 0, 300, 0},
+          {"tiled small K", 2000, 128, 64, KD_EPI_STORE, 0, 2000, 0},
+      };
+      for (const auto& c : cd) run_gemm_case(c);
+    }
+    kd_set_option("tiled_deep", 0);
     kd_set_option("wstat", 1);
   }
   if (want("prefetch")) {

@@ -25,11 +25,13 @@ struct FArgs {
   const u16* X; u16* Y; const char* Wu; const char* Wd;
   const float* scale; int scale_stride, rows_per_sample; float eps;
   int M, n_tiles;            // n_tiles = d_ff / 64
+  unsigned long long* clk;   // kd_prof_clock_buffer: time line of workgroup 0
 };
 
 #define KD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define KD_BARRIER() asm volatile("s_barrier" ::: "memory")
 
+extern unsigned long long* g_clk;                     // gemm_bf16.hip (kd_prof_clock_buffer)
 constexpr int FF_NW = 8;
 
 // SKEW: waves 4..7 (the second wave of every SIMD) run half a tile behind waves 0..3 -- in interval t they finish tile t - 1
@@ -50,6 +52,8 @@ __global__ __launch_bounds__(FF_NW * 64) void ffn_kernel(const FArgs p) {
   const bool ok = row < p.M;
   const int rowc = ok ? row : p.M - 1;
   const int T = p.n_tiles;
+  const bool probe = p.clk && blockIdx.x == 0 && tid == 0;
+  if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
 
   const bool late = SKEW && wid >= FF_NW / 2;
   auto up_slot = [&](int t) -> char* { return smem + (t % 3) * UP_BYTES; };
@@ -108,6 +112,7 @@ __global__ __launch_bounds__(FF_NW * 64) void ffn_kernel(const FArgs p) {
     rs = rsqrtf(ssq / (float)K + p.eps);
   }
   const float rsh = 0.5f * rs;
+  if (probe) p.clk[4] = __builtin_amdgcn_s_memtime();            // rows normalised
 
   int off4[4];
 #pragma unroll
@@ -172,6 +177,7 @@ __global__ __launch_bounds__(FF_NW * 64) void ffn_kernel(const FArgs p) {
       if (t < T) up(t);
     }
   }
+  if (probe) { p.clk[5] = __builtin_amdgcn_s_memtime(); p.clk[6] = p.clk[5]; }       // tiles done
   // ---- + skip, store -------------------------------------------------------------------------------------------------------------
   const u16* xrow = p.X + (size_t)rowc * K;
   u16* yrow = p.Y + (size_t)rowc * K;
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(FF_NW * 64) void ffn_kernel(const FArgs p) {
     for (int r = 0; r < 16; ++r) v[r] = acc_o[ob][r] + sk[r];
     store_block_bf16(yrow + 32 * ob, v, lh, ok);
   }
+  if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)T; }
 }
 
 }  // namespace b16
@@ -208,6 +215,7 @@ extern "C" int kd_ffn_bf16(const KdFfn* dp, void* stream) {
   a.Wu = reinterpret_cast<const char*>(d.Wp_up); a.Wd = reinterpret_cast<const char*>(d.Wp_down);
   a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample; a.eps = d.eps;
   a.M = d.M; a.n_tiles = d.d_ff / 64;
+  a.clk = g_clk;
   // 1 (default) plain, 3 skewed wave pairs.  Measured equal within noise (64.5 / 68.6 us at the level-0 shape; a third form with
   // one wave per SIMD and the two row blocks' MFMA / GEGLU streams interleaved instruction by instruction took 71 us):
   // profiles/r02_ffn_fused.md -- under this kernel the chip runs against its power limit and re-arranging the same work buys nothing.

@@ -387,10 +387,24 @@ struct TArgs {
 #define KD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define KD_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <int AMODE, int EPI, int BMT>
-__global__ __launch_bounds__(256 * BMT, BMT == 1 ? 2 : 1) void gemm_tiled_kernel(const TArgs p) {
+// s_waitcnt vmcnt(n) for a run-time n (the immediate has to be a constant: one case per value)
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+  switch (n) {
+#define KD_C(v) case v: asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); break;
+    KD_C(0) KD_C(1) KD_C(2) KD_C(3) KD_C(4) KD_C(5) KD_C(6) KD_C(7) KD_C(8) KD_C(9) KD_C(10) KD_C(11) KD_C(12) KD_C(13) KD_C(14) KD_C(15)
+    KD_C(16) KD_C(17) KD_C(18) KD_C(19) KD_C(20) KD_C(21) KD_C(22) KD_C(23) KD_C(24) KD_C(25) KD_C(26) KD_C(27) KD_C(28) KD_C(29) KD_C(30) KD_C(31)
+    KD_C(32) KD_C(33) KD_C(34) KD_C(35) KD_C(36) KD_C(37) KD_C(38) KD_C(39) KD_C(40)
+#undef KD_C
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// DEEP (BMT = 1 only): 4-slot ring, one workgroup per CU -- for grids of at most one tile per CU (the level-2 shapes: 8192 rows),
+// where the second workgroup of the 2-slot form does not exist and every K step would wait a full L2 round trip for its blocks.
+template <int AMODE, int EPI, int BMT, bool DEEP = false>
+__global__ __launch_bounds__(256 * BMT, (BMT == 1 && !DEEP) ? 2 : 1) void gemm_tiled_kernel(const TArgs p) {
   constexpr int NWV = 4 * BMT, BMR = 128 * BMT;
-  constexpr int A_IMG = BMR * 128, STG = A_IMG + WBLK, NSTG = BMT == 1 ? 2 : 3;
+  constexpr int A_IMG = BMR * 128, STG = A_IMG + WBLK, NSTG = BMT == 1 ? (DEEP ? 4 : 2) : 3;
   constexpr int WPC = 16 / NWV;                      // weight pieces (1 KiB) per wave per step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -451,31 +465,40 @@ __global__ __launch_bounds__(256 * BMT, BMT == 1 ? 2 : 1) void gemm_tiled_kernel
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) off4[cc] = swz128(l31, 2 * cc + lh);
 
-  issue(0);
-  if (NSTG == 3 && nk > 1) issue(1);
+#pragma unroll
+  for (int kt = 0; kt < NSTG - 1; ++kt)
+    if (kt < nk) issue(kt);
   for (int kt = 0; kt < nk; ++kt) {
-    if (NSTG == 3) {
-      if (kt + 1 < nk) { if (WPC == 4) KD_WAIT_VM(8); else KD_WAIT_VM(6); } else KD_WAIT_VM(0);
-    } else {
-      KD_WAIT_VM(0);
-    }
+    wait_vm_dyn((4 + WPC) * min(NSTG - 2, nk - 1 - kt));      // the steps requested after kt may stay in flight
     KD_BARRIER();                 // every wave's pieces of step kt are in; everyone is done reading the slot refilled next
     if (kt + NSTG - 1 < nk) issue(kt + NSTG - 1);
     const char* st = smem + (kt % NSTG) * STG;
     const char* ab = st + (wr * 64) * 128;
     const char* wb = st + A_IMG + (wc * 64) * 128;
+    // explicit double buffer: the 4 fragment reads of chunk cc + 1 are issued before the 4 MFMAs of chunk cc (with one wave per
+    // SIMD -- grids of one tile per CU -- nobody else covers the LDS latency of a read-then-use sequence)
+    bf16x8 af[2][2], wf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      af[0][u] = *reinterpret_cast<const bf16x8*>(ab + u * 32 * 128 + off4[0]);
+      wf[0][u] = *reinterpret_cast<const bf16x8*>(wb + u * 32 * 128 + off4[0]);
+    }
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
-      bf16x8 af[2], wf[2];
+      if (cc + 1 < 4) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        af[u] = *reinterpret_cast<const bf16x8*>(ab + u * 32 * 128 + off4[cc]);
-        wf[u] = *reinterpret_cast<const bf16x8*>(wb + u * 32 * 128 + off4[cc]);
+        for (int u = 0; u < 2; ++u) {
+          af[(cc + 1) & 1][u] = *reinterpret_cast<const bf16x8*>(ab + u * 32 * 128 + off4[cc + 1]);
+          wf[(cc + 1) & 1][u] = *reinterpret_cast<const bf16x8*>(wb + u * 32 * 128 + off4[cc + 1]);
+        }
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cc & 1][i], af[cc & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -520,10 +543,10 @@ __global__ __launch_bounds__(256 * BMT, BMT == 1 ? 2 : 1) void gemm_tiled_kernel
   }
 }
 
-template <int AMODE, int EPI, int BMT>
+template <int AMODE, int EPI, int BMT, bool DEEP = false>
 static int launch_tiled(const TArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {
-  auto kern = gemm_tiled_kernel<AMODE, EPI, BMT>;
-  constexpr int LDS = (BMT == 1 ? 2 : 3) * (128 * BMT * 128 + WBLK);
+  auto kern = gemm_tiled_kernel<AMODE, EPI, BMT, DEEP>;
+  constexpr int LDS = (BMT == 1 ? (DEEP ? 4 : 2) : 3) * (128 * BMT * 128 + WBLK);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -552,12 +575,16 @@ int gemm_tiled_try(const KdGemm& d, hipStream_t s, int* rc) {
   char nm[96] = "gemm_tiled";
   if (prof_on()) snprintf(nm, sizeof(nm), "gemm_bf16_tiled<a%d,e%d> M=%d N=%d K=%d", d.a_mode, d.epi, d.M, d.N, d.K);
   // 256-row tiles halve the weight traffic per flop; worth it once they still give every CU a workgroup
-  const long tiles256 = (long)((d.M + 255) / 256) * a.n_tiles_n;
+  const long tiles256 = (long)((d.M + 255) / 256) * a.n_tiles_n, tiles128 = (long)((d.M + 127) / 128) * a.n_tiles_n;
   const int bmt = option("tiled_bm", 0);
   const bool big = bmt ? bmt == 256 : tiles256 >= cu_count();
+  // 4-slot ring for grids of at most one tile per CU: measured no better than the 2-slot form (level-2 shapes 10.2 vs 9.5 us,
+  // 21.5 vs 21.5: the block latency is not what those steps wait for) -- on request only
+  const bool deep = !big && tiles128 <= cu_count() && option("tiled_deep", 0);
 #define KD_TL(AM, EP)                                                                       \
   if (d.a_mode == AM && d.epi == EP) {                                                      \
-    *rc = big ? launch_tiled<AM, EP, 2>(a, nm, flops, bytes, s) : launch_tiled<AM, EP, 1>(a, nm, flops, bytes, s); \
+    *rc = big ? launch_tiled<AM, EP, 2>(a, nm, flops, bytes, s)                             \
+              : (deep ? launch_tiled<AM, EP, 1, true>(a, nm, flops, bytes, s) : launch_tiled<AM, EP, 1>(a, nm, flops, bytes, s)); \
     return 0;                                                                               \
   }
   KD_TL(KD_A_PLAIN, KD_EPI_STORE)
@@ -580,17 +607,6 @@ int gemm_tiled_try(const KdGemm& d, hipStream_t s, int* rc) {
 //            weight stream alone asked for ~50 bytes / clock / CU, i.e. that path, not the matrix pipe, set the pace.
 // vmcnt bookkeeping (loads and stores retire in issue order): the wait before block s allows the blocks requested after it AND the
 // epilogue stores issued after it to stay outstanding (full panels only; ragged panels wait for their stores).
-__device__ __forceinline__ void wait_vm_dyn(int n) {
-  switch (n) {
-#define KD_C(v) case v: asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); break;
-    KD_C(0) KD_C(1) KD_C(2) KD_C(3) KD_C(4) KD_C(5) KD_C(6) KD_C(7) KD_C(8) KD_C(9) KD_C(10) KD_C(11) KD_C(12) KD_C(13) KD_C(14) KD_C(15)
-    KD_C(16) KD_C(17) KD_C(18) KD_C(19) KD_C(20) KD_C(21) KD_C(22) KD_C(23) KD_C(24) KD_C(25) KD_C(26) KD_C(27) KD_C(28) KD_C(29) KD_C(30) KD_C(31)
-    KD_C(32) KD_C(33) KD_C(34) KD_C(35) KD_C(36) KD_C(37) KD_C(38) KD_C(39) KD_C(40)
-#undef KD_C
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-}
-
 template <int NC, int EPI, int NWV>
 __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_astat_kernel(const GArgs p) {
   constexpr int K = NC * 16, NK = NC / 4, NSTG = NWV == 4 ? 4 : 8, PDIST = NSTG - 1;
