@@ -871,14 +871,19 @@ template <int NC, int EPI>
 static int launch_astat(const GArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {
   // panels x n-splits: 128-row panels, two workgroups per CU, n-tiles split until the grid fills them ("astat_rows" = 256: the
   // 256-row / one-workgroup-per-CU form).
-  auto pick = [&](int panels, int want) {
-    int splits = 1;
+  // n-splits of a panel: every workgroup pays the row prologue (about one n-tile's worth of time, profiles/r02_astat_timeline.md)
+  // and then its share of the n-tiles; the grid runs in ceil(workgroups / resident slots) rounds.  Pick the divisor of n_tiles
+  // with the smallest estimated time  rounds x (1 + tiles per split)  (ties: fewer splits = fewer redundant prologues).
+  auto pick = [&](int panels, int slots) {
+    int best = 1;
+    long best_cost = -1;
     for (int sp = 1; sp <= a.n_tiles; ++sp) {
       if (a.n_tiles % sp) continue;
-      splits = sp;
-      if (panels * sp >= want) break;
+      const long rounds = ((long)panels * sp + slots - 1) / slots;
+      const long cost = rounds * (1 + a.n_tiles / sp);
+      if (best_cost < 0 || cost < best_cost) { best = sp; best_cost = cost; }
     }
-    return splits;
+    return best;
   };
   const int forced = option("astat_splits", 0), rows = option("astat_rows", 0);
   const int p256 = (a.M + 255) / 256, s256 = pick(p256, cu_count());
