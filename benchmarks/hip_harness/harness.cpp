@@ -201,7 +201,7 @@ static void run_gemm_case(const GemmCase& c) {
   }
   const float us = time_us([&] { kd_gemm_bf16(&d, nullptr); });
   char clk_note[256] = "";
-  if (strstr(c.name, "wstat") || strstr(c.name, "clock") || strstr(c.name, "astat")) {       // shader clock under this kernel's load (s_memtime vs the 100 MHz s_memrealtime)
+  if (strstr(c.name, "wstat") || strstr(c.name, "clock") || strstr(c.name, "astat") || strstr(c.name, "tiled")) {       // shader clock under this kernel's load (s_memtime vs the 100 MHz s_memrealtime)
     DevBuf<unsigned long long> dClk(8);
     HIPCHK(hipMemset(dClk.p, 0, 64));
     kd_prof_clock_buffer(dClk.p);
@@ -210,7 +210,10 @@ static void run_gemm_case(const GemmCase& c) {
     kd_prof_clock_buffer(nullptr);
     auto ck = dClk.down();
     if (ck[3] > ck[1]) snprintf(clk_note, sizeof(clk_note), "  clk %.2f GHz", (double)(ck[2] - ck[0]) / (double)(ck[3] - ck[1]) * 0.1);
-    if (ck[3] > ck[1] && ck[4])      // astat time line of workgroup 0 (shader clocks): whole / row prologue / first tile K loop / its epilogue; ring blocks
+    if (ck[3] > ck[1] && ck[4] && strstr(c.name, "tiled"))
+      snprintf(clk_note + strlen(clk_note), sizeof(clk_note) - strlen(clk_note), "  wg0: %llu clk = first blocks in %llu + K loop %llu (%llu steps) + epilogue %llu",
+               ck[2] - ck[0], ck[4] - ck[0], ck[5] - ck[4], ck[7], ck[2] - ck[5]);
+    else if (ck[3] > ck[1] && ck[4])      // astat time line of workgroup 0 (shader clocks): whole / row prologue / first tile K loop / its epilogue; ring blocks
       snprintf(clk_note + strlen(clk_note), sizeof(clk_note) - strlen(clk_note), "  wg0: %llu clk = prologue %llu + [K loop %llu + epilogue %llu] x tiles (%llu blocks)",
                ck[2] - ck[0], ck[4] - ck[0], ck[5] - ck[4], ck[6] - ck[5], ck[7]);
   }
