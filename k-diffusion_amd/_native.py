@@ -145,11 +145,17 @@ _env_applied = None
 
 
 def _sync_options(handle):
+    """KDIFF_* variables -> kd_set_option; KDIFF_OPTIONS="name=value,..." sets any library option by name (A-B runs of bench.py)."""
     global _env_applied
-    cur = tuple(os.environ.get(k) for k in _ENV_OPTIONS)
+    cur = tuple(os.environ.get(k) for k in _ENV_OPTIONS) + (os.environ.get("KDIFF_OPTIONS"),)
     if cur != _env_applied:
         for (env, (name, dflt)), val in zip(_ENV_OPTIONS.items(), cur):
             handle.kd_set_option(name.encode(), dflt if val is None or val == "" else int(val))
+        for item in (cur[-1] or "").split(","):
+            if item.strip():
+                name, _, val = item.partition("=")
+                if handle.kd_set_option(name.strip().encode(), int(val)) != 0:
+                    raise ValueError(f"KDIFF_OPTIONS: unknown library option {name.strip()!r}")
         _env_applied = cur
 
 
