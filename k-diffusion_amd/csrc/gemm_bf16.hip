@@ -465,6 +465,30 @@ __global__ __launch_bounds__(256 * BMT, (BMT == 1 && !DEEP) ? 2 : 1) void gemm_t
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) off4[cc] = swz128(l31, 2 * cc + lh);
 
+  // residual / skip operand of this lane's 4 output blocks: requested two K steps before the end of the loop (raw 16-byte pieces,
+  // 32 registers), so that the epilogue does not start with a full memory round trip (8 000 of the workgroup's 37 000 clocks at
+  // the level-1 down projection: profiles/r02_astat_timeline.md).  The last step's vmcnt(0) then also covers them.
+  constexpr bool HAS_R = EPI == KD_EPI_RESIDUAL || EPI == KD_EPI_SPLIT_LERP;
+  u32x4 rraw[2][2][2];
+  size_t roff[2][2];
+  if (HAS_R) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gmc = min(m0 + wr * 64 + 32 * j + l31, p.M - 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int nbc = min(n0 + wc * 64 + 32 * i, p.N - 32);
+        if (EPI == KD_EPI_SPLIT_LERP) {
+          const int hw = p.gh * p.gw, cout = p.N >> 2;
+          const int b = gmc / hw, rr = gmc - b * hw, h = rr / p.gw, w = rr - h * p.gw;
+          const int qd = nbc / cout, e = nbc - qd * cout;
+          roff[i][j] = (((size_t)b * (2 * p.gh) + 2 * h + (qd >> 1)) * (2 * p.gw) + 2 * w + (qd & 1)) * cout + e;
+        } else {
+          roff[i][j] = (size_t)gmc * p.N + nbc;
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int kt = 0; kt < NSTG - 1; ++kt)
     if (kt < nk) issue(kt);
@@ -472,6 +496,12 @@ __global__ __launch_bounds__(256 * BMT, (BMT == 1 && !DEEP) ? 2 : 1) void gemm_t
     wait_vm_dyn((4 + WPC) * min(NSTG - 2, nk - 1 - kt));      // the steps requested after kt may stay in flight
     KD_BARRIER();                 // every wave's pieces of step kt are in; everyone is done reading the slot refilled next
     if (kt + NSTG - 1 < nk) issue(kt + NSTG - 1);
+    if (HAS_R && kt == max(nk - 2, 0)) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) load_block_raw(p.R + roff[i][j], rraw[i][j], lh);
+    }
     const char* st = smem + (kt % NSTG) * STG;
     const char* ab = st + (wr * 64) * 128;
     const char* wb = st + A_IMG + (wc * 64) * 128;
@@ -527,7 +557,7 @@ __global__ __launch_bounds__(256 * BMT, (BMT == 1 && !DEEP) ? 2 : 1) void gemm_t
       for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
       if (EPI == KD_EPI_RESIDUAL || EPI == KD_EPI_SPLIT_LERP) {
         float rr_[16];
-        load_block_bf16(p.R + off, rr_, lh);
+        block_from_raw(rraw[i][j], rr_);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if (EPI == KD_EPI_RESIDUAL) {
