@@ -245,7 +245,7 @@ static void run_ffn_case(const char* name, int M, int K, int dff, int rps) {
   memset(&f, 0, sizeof(f));
   f.x = dX.p; f.out = dY.p; f.scale = dS.p; f.scale_stride = K; f.rows_per_sample = rps; f.eps = 1e-6f;
   f.Wp_up = dPu.p; f.Wp_down = dPd.p; f.M = M; f.K = K; f.d_ff = dff;
-  if (K != 128) { printf("%-28s not supported by kd_ffn_bf16\n", name); return; }     // (kd_ffn_bf16_supported also asks for M >= 16384: a speed rule)
+  if (K != 128 && K != 256) { printf("%-28s not supported by kd_ffn_bf16\n", name); return; }     // (kd_ffn_bf16_supported also asks for M >= 16384: a speed rule)
   if (int rc = kd_ffn_bf16(&f, nullptr)) { printf("%-28s REJECTED (%d): %s\n", name, rc, kd_last_error()); ++g_fail; return; }
   HIPCHK(hipDeviceSynchronize());
   auto Y_h = dY.down();
@@ -716,6 +716,9 @@ int main(int argc, char** argv) {
     run_ffn_case("ffn L0", 131072, 128, 384, 4096);
     run_ffn_case("ffn ragged", 4128 + 77, 128, 448, 96);
     run_ffn_case("ffn tiny", 37, 128, 64, 37);
+    run_ffn_case("ffn L1 (K=256)", 32768, 256, 768, 1024);
+    run_ffn_case("ffn K=256 ragged", 1000 + 77, 256, 192, 96);
+    run_ffn_case("ffn K=256 one tile", 130, 256, 64, 130);
     run_ffn_case("ffn one tile", 300, 128, 64, 100);
     run_ffn_case("ffn two tiles", 300, 128, 128, 100);
   }

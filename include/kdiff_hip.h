@@ -38,7 +38,7 @@ const char* kd_last_error(void);
  *   bf16 kernels : "bf16_fast" (1; 0 = generic kernel only) "wstat" (1) "wstat_waves" (0 = per shape) "wstat_max_slices" (24)
  *                  "wstat_prefetch" (0; 1 next-chunk prefetch, 2 software-pipelined tiles) "astat_bf16" (1) "astat_splits" (0 = auto)
  *                  "tiled_bm" (0 = auto, 128, 256) "attn_global_qw" (8) "patch_fast" (1; 0 = patch-in / patch-out through the generic kernel)
- *                  "ffn_fused" (1; 0 = kd_ffn_bf16_supported answers no) */
+ *                  "ffn_fused" (1; 0 = kd_ffn_bf16_supported answers no) "ffn_fused_256" (0) */
 int kd_set_option(const char* name, int value);
 int kd_get_option(const char* name, int dflt);
 
@@ -113,7 +113,8 @@ int kd_pack_weight_bf16(const float* W, void* out, int N, int K, int geglu, void
  * d_ff-wide hidden activation ever leaving the chip.  x, out: bf16 [M, K] (out may be x); scale: fp32 norm scales, row m uses
  * scale + (m / rows_per_sample) * scale_stride; Wp_up = kd_pack_weight_bf16(up_proj.weight [2 d_ff, K], N = d_ff, geglu = 1);
  * Wp_down = kd_pack_weight_bf16(down_proj.weight [K, d_ff], N = K, K = d_ff, geglu = 2).
- * Shapes: K == 128, d_ff % 64 == 0 (kd_ffn_bf16_supported); anything else returns KD_EINVAL and the caller uses the pair. */
+ * Shapes: K == 128 or 256, d_ff % 64 == 0; anything else returns KD_EINVAL and the caller uses the pair.  kd_ffn_bf16_supported
+ * additionally says where the fused form is the FASTER one (K == 128 and M >= 16384; K == 256 only with option "ffn_fused_256"). */
 typedef struct KdFfn {
   const void* x;
   void* out;

@@ -32,6 +32,11 @@ struct FArgs {
 #define KD_BARRIER() asm volatile("s_barrier" ::: "memory")
 
 extern unsigned long long* g_clk;                     // gemm_bf16.hip (kd_prof_clock_buffer)
+__device__ __forceinline__ void wait_vm_count(int n) {      // s_waitcnt vmcnt(n) for the few run-time values the half-unit ring needs
+  if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 constexpr int FF_NW = 8;
 
 // SKEW: waves 4..7 (the second wave of every SIMD) run half a tile behind waves 0..3 -- in interval t they finish tile t - 1
@@ -192,6 +197,174 @@ __global__ __launch_bounds__(FF_NW * 64) void ffn_kernel(const FArgs p) {
   if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)T; }
 }
 
+// ---- width 256 --------------------------------------------------------------------------------------------------------------
+// The same block at K = 256 (level 1 of the headline config: 32 768 tokens, d_ff 768).  A row's fragments (64 registers) plus
+// the 256-wide fp32 output accumulators (128) no longer fit two waves per SIMD, so a workgroup is 4 waves x 32 rows with the
+// whole register file per wave, and a d_ff tile's weights (64 KiB up + 32 KiB down) stream as TWO 48 KiB half units through the
+// same 3-slot ring:   A_t = up-projection k-steps 0, 1, 2      B_t = up-projection k-step 3 + both down-projection blocks.
+//   top of tile: wait A_t, barrier (B_t-1's slot is free: request A_t+1) | up chunks 0..11 from A_t |
+//   wait B_t, barrier (A_t's slot is free: request B_t+1) | up chunks 12..15, GEGLU, down projection from B_t
+// A_t is released after 40 % of the tile and B_t at its end, so every request has a whole tile (~7 000 clocks) to arrive.
+// Weight fragments are read one chunk ahead of their MFMAs, across the phase boundaries too (explicit double buffer: one wave
+// per SIMD has no partner to cover LDS latency).
+constexpr int F2_NW = 4;
+
+__global__ __launch_bounds__(F2_NW * 64) void ffn256_kernel(const FArgs p) {
+  constexpr int NC = 16, K = 256, KB = 8;
+  constexpr int HU = 3 * WBLK;                        // half unit: 2 up-projection blocks + 1 down-projection block
+  constexpr int PCS = HU / 1024 / F2_NW;              // 12 pieces per wave per half unit
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int row = blockIdx.x * (F2_NW * 32) + wid * 32 + l31;
+  const bool ok = row < p.M;
+  const int rowc = ok ? row : p.M - 1;
+  const int T = p.n_tiles, U = 2 * T;
+  const bool probe = p.clk && blockIdx.x == 0 && tid == 0;
+  if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
+
+  auto issue = [&](int u) {
+    const int t = u >> 1, half = u & 1;
+    char* slot = smem + (u % 3) * HU;
+#pragma unroll
+    for (int i = 0; i < PCS; ++i) {
+      const int pi = wid + F2_NW * i;                 // 0..47
+      const char* src;
+      if (half == 0) src = p.Wu + ((size_t)t * 4) * WBLK + pi * 1024;                       // up k-steps 0, 1, 2: 48 contiguous KiB
+      else if (pi < 16) src = p.Wu + ((size_t)t * 4 + 3) * WBLK + pi * 1024;                // up k-step 3
+      else src = p.Wd + ((size_t)((pi - 16) >> 4) * T + t) * WBLK + ((pi - 16) & 15) * 1024;   // down rows 0..127, 128..255
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(slot + pi * 1024), 16, 0, 0);
+    }
+  };
+  int issued = 0;
+  for (; issued < 3 && issued < U; ++issued) issue(issued);
+
+  bf16x8 a[NC];
+  float rs;
+  {
+    const u32x4* ap = reinterpret_cast<const u32x4*>(p.X + (size_t)rowc * K + 8 * lh);
+    const float* sp = p.scale + (size_t)(rowc / p.rows_per_sample) * p.scale_stride + 8 * lh;
+    u32x4 raw[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) raw[c] = ap[2 * c];
+    float ssq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp + 16 * c), s1 = *reinterpret_cast<const f32x4*>(sp + 16 * c + 4);
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[2 * e] = bf_lo(raw[c][e]); x[2 * e + 1] = bf_hi(raw[c][e]); }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ssq = fmaf(x[e], x[e], ssq);
+      u32x4 o = {pack_bf16(x[0] * s0[0], x[1] * s0[1]), pack_bf16(x[2] * s0[2], x[3] * s0[3]),
+                 pack_bf16(x[4] * s1[0], x[5] * s1[1]), pack_bf16(x[6] * s1[2], x[7] * s1[3])};
+      asm volatile("" : "+v"(o));
+      a[c] = __builtin_bit_cast(bf16x8, o);
+    }
+    ssq += __shfl_xor(ssq, 32, 64);
+    rs = rsqrtf(ssq / (float)K + p.eps);
+  }
+  const float rsh = 0.5f * rs;
+  if (probe) p.clk[4] = __builtin_amdgcn_s_memtime();
+
+  int off4[4];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) off4[cc] = swz128(l31, 2 * cc + lh);
+  f32x16 acc_o[KB];
+#pragma unroll
+  for (int ob = 0; ob < KB; ++ob)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[ob][r] = 0.f;
+
+  f32x16 acc[4];
+  bf16x8 hf[4];
+  // weight fragment of the up projection: chunk c (0..15) of block j; chunks 0..11 in half unit A, 12..15 in B's first block
+  auto up_frag = [&](const char* sa, const char* sb, int c, int j) -> bf16x8 {
+    const char* blk = c < 12 ? sa + (c >> 2) * WBLK : sb;
+    return *reinterpret_cast<const bf16x8*>(blk + off4[c & 3] + j * 32 * 128);
+  };
+  auto down_frag = [&](const char* sb, int half, int g, int ob) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(sb + (1 + half) * WBLK + ob * 32 * 128 + off4[g]);
+  };
+  for (int t = 0; t < T; ++t) {
+    const int ua = 2 * t, ub = 2 * t + 1;
+    wait_vm_count(PCS * (issued - 1 - ua));            // A_t is in (later half units may stay in flight)
+    KD_BARRIER();                                      // ... for every wave; every wave is done with B_{t-1}'s slot
+    if (t > 0 && issued < U) { issue(issued); ++issued; }       // A_{t+1} (requested in the prologue for t = 0)
+    const char* sa = smem + (ua % 3) * HU;
+    const char* sb = smem + (ub % 3) * HU;
+    // ---- up projection, 16 chunks, fragments one chunk ahead ---------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    bf16x8 wf[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[0][j] = up_frag(sa, sb, 0, j);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c == 11) {
+        // the last fragments of A_t are in flight (chunk 11's were requested a step ago): once they are in registers A_t's slot
+        // goes to B_{t+1}; B_t has to be in for chunk 12
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0)
+        wait_vm_count(PCS * (issued - 1 - ub));
+        KD_BARRIER();
+        if (issued < U) { issue(issued); ++issued; }
+      }
+      if (c + 1 < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[(c + 1) & 1][j] = up_frag(sa, sb, c + 1, j);
+      } else {
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) wf[(c + 1) & 1][ob] = down_frag(sb, 0, 0, ob);  // first fragments of the down projection: they
+      }                                                                                //  arrive while the GEGLU below runs
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c & 1][j], a[c], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      unsigned pk[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 o = geglu_pair(f32x2{acc[2 * jj][r], acc[2 * jj][r + 1]} * rsh, f32x2{acc[2 * jj + 1][r], acc[2 * jj + 1][r + 1]} * rs);
+        pk[r >> 1] = pack_bf16(o.x, o.y);
+      }
+      hf[2 * jj] = __builtin_bit_cast(bf16x8, u32x4{pk[0], pk[1], pk[2], pk[3]});
+      hf[2 * jj + 1] = __builtin_bit_cast(bf16x8, u32x4{pk[4], pk[5], pk[6], pk[7]});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- down projection: 8 steps (2 halves of the output x 4 hidden chunks), wf[0] holds step 0's fragments ------------------------
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int half = st >> 2, g = st & 3;
+      if (st + 1 < 8) {
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) wf[(st + 1) & 1][ob] = down_frag(sb, (st + 1) >> 2, (st + 1) & 3, ob);
+      }
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob)
+        acc_o[4 * half + ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[st & 1][ob], hf[g], acc_o[4 * half + ob], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                // B_t's fragments are in registers before the next tile's barrier releases its slot
+  }
+  if (probe) { p.clk[5] = __builtin_amdgcn_s_memtime(); p.clk[6] = p.clk[5]; }
+  const u16* xrow = p.X + (size_t)rowc * K;
+  u16* yrow = p.Y + (size_t)rowc * K;
+#pragma unroll
+  for (int ob = 0; ob < KB; ++ob) {
+    float sk[16], v[16];
+    load_block_bf16(xrow + 32 * ob, sk, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc_o[ob][r] + sk[r];
+    store_block_bf16(yrow + 32 * ob, v, lh, ok);
+  }
+  if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)T; }
+}
+
 }  // namespace b16
 }  // namespace kd
 
@@ -200,7 +373,10 @@ using namespace kd::b16;
 
 extern "C" int kd_ffn_bf16_supported(int M, int K, int d_ff) {
   // below ~16k rows the panels do not fill the chip and the two-kernel form (row-parallel over more, smaller units) is faster
-  return (M >= 16384 && K == 128 && d_ff > 0 && d_ff % 64 == 0 && option("ffn_fused", 1)) ? 1 : 0;
+  if (!(M >= 16384 && d_ff > 0 && d_ff % 64 == 0 && option("ffn_fused", 1))) return 0;
+  // K = 256: correct, but measured level with the two-kernel form (65.1 vs 65.6 us at the level-1 shape; 8 300 clocks per tile for 3 072
+  // matrix clocks with one wave per SIMD) -- on request only ("ffn_fused_256")
+  return (K == 128 || (K == 256 && option("ffn_fused_256", 0))) ? 1 : 0;
 }
 
 extern "C" int kd_ffn_bf16(const KdFfn* dp, void* stream) {
@@ -208,7 +384,7 @@ extern "C" int kd_ffn_bf16(const KdFfn* dp, void* stream) {
   const KdFfn& d = *dp;
   if (!d.x || !d.out || !d.scale || !d.Wp_up || !d.Wp_down) return fail(KD_EINVAL, "kd_ffn_bf16: null x / out / scale / Wp_up / Wp_down");
   if (d.M <= 0 || d.rows_per_sample <= 0 || (d.scale_stride & 3)) return fail(KD_EINVAL, "kd_ffn_bf16: needs M, rows_per_sample > 0, scale_stride %% 4 == 0");
-  if (d.K != 128 || d.d_ff <= 0 || d.d_ff % 64) return fail(KD_EINVAL, "kd_ffn_bf16: K = %d, d_ff = %d not supported (K == 128, d_ff %% 64 == 0)", d.K, d.d_ff);
+  if ((d.K != 128 && d.K != 256) || d.d_ff <= 0 || d.d_ff % 64) return fail(KD_EINVAL, "kd_ffn_bf16: K = %d, d_ff = %d not supported (K == 128 or 256, d_ff %% 64 == 0)", d.K, d.d_ff);
   hipStream_t s = (hipStream_t)stream;
   FArgs a{};
   a.X = reinterpret_cast<const u16*>(d.x); a.Y = reinterpret_cast<u16*>(d.out);
@@ -216,6 +392,19 @@ extern "C" int kd_ffn_bf16(const KdFfn* dp, void* stream) {
   a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample; a.eps = d.eps;
   a.M = d.M; a.n_tiles = d.d_ff / 64;
   a.clk = g_clk;
+  if (d.K == 256) {
+    constexpr int LDS256 = 9 * WBLK;
+    static bool attr256 = false;
+    if (!attr256) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
+      attr256 = true;
+    }
+    char nm2[96] = "ffn_bf16";
+    if (prof_on()) snprintf(nm2, sizeof(nm2), "ffn_bf16 M=%d K=%d dff=%d", d.M, d.K, d.d_ff);
+    LaunchScope prof2(nm2, 2.0 * d.M * (double)d.K * (3.0 * d.d_ff), 4.0 * d.M * (double)d.K + 6.0 * d.d_ff * (double)d.K, s);
+    hipLaunchKernelGGL(ffn256_kernel, dim3((unsigned)((d.M + F2_NW * 32 - 1) / (F2_NW * 32))), dim3(F2_NW * 64), LDS256, s, a);
+    return check_launch("kd_ffn_bf16");
+  }
   // 1 (default) plain, 3 skewed wave pairs.  Measured equal within noise (64.5 / 68.6 us at the level-0 shape; a third form with
   // one wave per SIMD and the two row blocks' MFMA / GEGLU streams interleaved instruction by instruction took 71 us):
   // profiles/r02_ffn_fused.md -- under this kernel the chip runs against its power limit and re-arranging the same work buys nothing.

@@ -150,7 +150,28 @@ def test_bf16_fused_ffn(ops, B, T, d_ff):
     assert ops.ffn_supported(B * T, K, d_ff) == (B * T >= 16384)
     assert not ops.ffn_supported(1 << 20, 256, 768) and not ops.ffn_supported(1 << 20, 128, 100)
     with pytest.raises(RuntimeError):
-        ops.ffn(_bf(rn(B, 64, 256, seed=1)), g(1 + 0.2 * rn(B, 256, seed=2)), g(rn(2 * 64, 256, seed=3)), g(rn(256, 64, seed=4)), rows_per_sample=64)
+        ops.ffn(_bf(rn(B, 64, 512, seed=1)), g(1 + 0.2 * rn(B, 512, seed=2)), g(rn(2 * 64, 512, seed=3)), g(rn(512, 64, seed=4)), rows_per_sample=64)
+
+
+@pytest.mark.parametrize("B,T,d_ff", [(3, 1024, 768), (2, 77, 192), (1, 130, 64)])
+def test_bf16_fused_ffn_width_256(ops, B, T, d_ff):
+    """The width-256 form of kd_ffn_bf16 (half-unit weight ring, one wave per SIMD; off by default because it is not faster than the
+    two-kernel form) against the fp32 oracle and the two-kernel form."""
+    from k_diffusion_amd import _native as nat
+    K = 256
+    x, scale = rn(B, T, K, seed=24), 1 + 0.2 * rn(B, K, seed=25)
+    wu, wd = rn(2 * d_ff, K, seed=26, scale=K ** -0.5), rn(K, d_ff, seed=27, scale=d_ff ** -0.5)
+    xb = _bf(x)
+    ref = _rt(x) + hdit.linear_geglu(hdit.rms_norm(_rt(x), scale[:, None, :]), _rt(wu)) @ _rt(wd).T
+    y = ops.ffn(xb, g(scale), g(wu), g(wd), rows_per_sample=T)
+    assert relerr(y, ref) < 8e-3
+    hid = ops.norm_linear(xb, g(scale), g(wu), rows_per_sample=T, epi=nat.EPI_GEGLU)
+    assert relerr(y, ops.linear(hid, g(wd), residual=xb).float()) < 6e-3
+    nat.set_option("ffn_fused_256", 1)
+    try:
+        assert ops.ffn_supported(1 << 20, 256, 768)
+    finally:
+        nat.set_option("ffn_fused_256", 0)
 
 
 @pytest.mark.parametrize("H,W,nh,B,K", [(16, 16, 2, 2, 128), (32, 32, 2, 1, 128), (20, 24, 4, 1, 256), (8, 8, 8, 3, 512)])
