@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cctype>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
@@ -70,6 +71,54 @@ __global__ __launch_bounds__(1024) void work_kernel(int iters, float* sink, unsi
   float s = 0.f;
   for (int j = 0; j < 4; ++j) { s += acc[j][0] + acc[j][7]; s += v[j].x + v[j].y; }
   if (s == 12345.678f) sink[threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = __builtin_amdgcn_s_memtime() - t0;
+    clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+  }
+}
+
+// Which vector instruction classes serialise with the matrix pipe?  KIND: 0 v_fma_f32, 1 v_exp_f32 (transcendental), 2 v_pk_fma_f32,
+// 3 integer (v_add_u32 / v_xor), 4 v_cvt_pk_bf16_f32.  8 instructions of the class per MFMA slot, independent chains.
+template <int DO_MFMA, int KIND>
+__global__ __launch_bounds__(512) void kind_kernel(int iters, float* sink, unsigned long long* clk) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long t0 = 0, r0 = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (lane + i)); b[i] = (__bf16)(0.002f * (lane - i)); }
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float f[8];
+  f32x2 pf[8];
+  unsigned u[8];
+  for (int j = 0; j < 8; ++j) { f[j] = 0.01f * lane + j; pf[j] = f32x2{f[j], -f[j]}; u[j] = lane * 77u + j; }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (DO_MFMA) acc[s & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[s & 3], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (KIND == 0) f[j] = fmaf(f[j], 0.999f, 1e-3f);
+        else if (KIND == 1) f[j] = __builtin_amdgcn_exp2f(f[j]);
+        else if (KIND == 2) pf[j] = __builtin_elementwise_fma(pf[j], f32x2{0.999f, 1.001f}, f32x2{1e-3f, -1e-3f});
+        else if (KIND == 3) u[j] = (u[j] + 0x9E3779B9u) ^ (u[j] >> 7);
+        else {
+          typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+          const bf2 v = {(__bf16)f[j], (__bf16)__uint_as_float(u[j] | 0x3f000000u)};
+          u[j] = __builtin_bit_cast(unsigned, v);
+        }
+      }
+      if (DO_MFMA) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x402, 20, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  float sum = 0.f;
+  for (int j = 0; j < 4; ++j) sum += acc[j][0] + acc[j][7];
+  for (int j = 0; j < 8; ++j) sum += f[j] + pf[j].x + pf[j].y + (float)u[j];
+  if (sum == 12345.678f) sink[threadIdx.x] = sum;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     clk[0] = __builtin_amdgcn_s_memtime() - t0;
     clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
@@ -165,8 +214,10 @@ struct Sampler {
   void stop() { run = false; th.join(); }
 };
 
+static const char* g_only = nullptr;                  // argv[1]: run only the measurements whose name contains it
 template <class F>
 static void measure(const char* name, Sampler& smp, F&& launch, double work_unit, const char* unit, unsigned long long* clk_dev) {
+  if (g_only && !strstr(name, g_only)) return;
   for (int i = 0; i < 3; ++i) launch();
   CHK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
@@ -196,7 +247,8 @@ static void measure(const char* name, Sampler& smp, F&& launch, double work_unit
          ck[1] ? (double)ck[0] / (double)ck[1] * 0.1 : 0.0, smp.n);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) g_only = argv[1];
   int dev = 0, cus = 0;
   CHK(hipGetDevice(&dev));
   CHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -241,6 +293,16 @@ int main() {
   measure("mfma + 1 read, 16 CUs", smp, [&] { hipLaunchKernelGGL((lds_kernel<1, 1>), dim3(16), dim3(512), 65536, 0, iters, sink, clk); }, mfma_flops / cus * 16e-6, "TFLOP/s", clk);
   measure("2 reads only, 16 CUs", smp, [&] { hipLaunchKernelGGL((lds_kernel<0, 2>), dim3(16), dim3(512), 65536, 0, iters, sink, clk); }, 2 * lds_bytes16 * 1e-3, "GB/s", clk);
   measure("mfma + 2 reads, 16 CUs", smp, [&] { hipLaunchKernelGGL((lds_kernel<1, 2>), dim3(16), dim3(512), 65536, 0, iters, sink, clk); }, mfma_flops / cus * 16e-6, "TFLOP/s", clk);
+  // instruction classes beside the MFMA, 16 CUs (full clock): alone / with one MFMA per 8 of them
+#define KIND_PAIR(K, label) \
+  measure(label " alone, 16 CUs", smp, [&] { hipLaunchKernelGGL((kind_kernel<0, K>), dim3(16), dim3(512), 0, 0, iters, sink, clk); }, 0.0, "-", clk); \
+  measure("mfma + " label ", 16 CUs", smp, [&] { hipLaunchKernelGGL((kind_kernel<1, K>), dim3(16), dim3(512), 0, 0, iters, sink, clk); }, mfma_flops / cus * 16e-6, "TFLOP/s", clk);
+  KIND_PAIR(0, "v_fma_f32 x8")
+  KIND_PAIR(1, "v_exp_f32 x8")
+  KIND_PAIR(2, "v_pk_fma_f32 x8")
+  KIND_PAIR(3, "int add/xor x8")
+  KIND_PAIR(4, "v_cvt_pk_bf16 x8")
+#undef KIND_PAIR
   // a quarter of the CUs: far below any power limit -- does the sum rule survive?
   const int q = cus / 4;
   measure("mfma, 64 CUs", smp, [&] { hipLaunchKernelGGL((work_kernel<1, 0, 8>), dim3(q), dim3(512), 0, 0, iters, sink, clk); }, mfma_flops * 0.25e-6, "TFLOP/s", clk);
