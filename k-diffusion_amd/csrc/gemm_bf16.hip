@@ -846,10 +846,19 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_astat_kernel(
         const int vec = (n0 >> 6) + vv;
         const int which = vec / p.n_heads, head = vec - which * p.n_heads;
         if (which < 2) {
+          // The head's 8 RoPE frequencies and its cosine-sim scale through the SCALAR cache (s_load, lgkmcnt).  As ordinary loads
+          // (the compiler cannot prove that the kernel's own stores leave them alone, so it will not use s_load by itself) they
+          // came back through vmcnt -- and the s_waitcnt vmcnt(0) in front of their first use drained the whole weight ring in
+          // flight, once per 64 output columns.
+          typedef float f32x8s __attribute__((ext_vector_type(8)));
+          f32x8s fq;
+          float qsc;
+          asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                       : "=s"(fq), "=s"(qsc) : "s"(p.freq + head * 8), "s"(p.qk_scale + head) : "memory");
           float fr[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) fr[u] = lh ? p.freq[head * 8 + 4 + u] : p.freq[head * 8 + u];
-          qk_prep_blocks(acc[2 * vv], acc[2 * vv + 1], rs, sqrtf(p.qk_scale[head]), p.eps, py, px, fr);
+          for (int u = 0; u < 4; ++u) fr[u] = lh ? fq[4 + u] : fq[u];
+          qk_prep_blocks(acc[2 * vv], acc[2 * vv + 1], rs, sqrtf(qsc), p.eps, py, px, fr);
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) { acc[2 * vv][r] *= rs; acc[2 * vv + 1][r] *= rs; }
