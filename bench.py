@@ -35,6 +35,7 @@ import k_diffusion_amd as K  # noqa: E402
 # /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 FP32_MFMA_PEAK_TFLOPS = 157.3      # v_mfma_f32_32x32x2_f32 dense peak (KDIFF_GEMM=exact)
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak (split3 mode executes 3 bf16 products per fp32 product)
+BF16_MFMA_SUSTAINED_TFLOPS = 2000.0  # measured: a pure MFMA kernel on all 256 CUs (profiles/r02_pipe_overlap.md); informational only
 HBM_PEAK_GBS = 8000.0              # HBM3E spec (6.3 TB/s is the measured streaming ceiling)
 
 
@@ -112,6 +113,10 @@ def family_roofline(name, g, mode, total_ms):
     if mult:
         common["mfma_useful_frac"] = round(tfl_alg / peak, 4)
         common["mfma_executed_frac"] = round(tfl_alg * mult / peak, 4)
+        if peak == BF16_MFMA_PEAK_TFLOPS:
+            # what a register-only bf16 MFMA loop sustains chip-wide on these boxes (power limited: 1.9-2.0 GHz, ~1300 W):
+            # benchmarks/probe/power_probe.cpp, profiles/r02_pipe_overlap.md
+            common["mfma_executed_frac_of_sustained_2000TF"] = round(tfl_alg * mult / BF16_MFMA_SUSTAINED_TFLOPS, 4)
     if t_hbm >= t_mfma:
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), **common,
                 "note": "algorithmic bytes (inputs once + outputs once at their storage width, DESIGN.md section 4) of every launch of this "
