@@ -262,8 +262,11 @@ int kd_prof_enable(int on);
 int kd_prof_count(void);
 int kd_prof_get(int i, char* name, int name_cap, float* ms, double* flops, double* bytes);
 int kd_prof_reset(void);
-/* Shader-clock probe (benchmarks/): while `dev_ptr` (4 x uint64 of device memory) is set, workgroup 0 of the W-stationary bf16 GEMM
- * writes {s_memtime, s_memrealtime} at entry and at exit: clock under load = d(memtime) / d(realtime) x 100 MHz.  NULL switches it off. */
+/* In-kernel time line probe (benchmarks/): while `dev_ptr` (8 x uint64 of device memory) is set, workgroup 0 of the bf16 GEMM kernels
+ * (W-stationary, A-stationary, tiled) and of kd_ffn_bf16 writes s_memtime stamps: [0] entry, [2] exit, [1] / [3] s_memrealtime at
+ * entry / exit (shader clock under load = ([2]-[0]) / ([3]-[1]) x 100 MHz), [4] end of the row prologue / first blocks in,
+ * [5] end of the first tile's K loop (tiled, ffn: of the whole loop), [6] end of its epilogue, [7] number of ring blocks / tiles.
+ * NULL switches it off.  Not for concurrent launches. */
 int kd_prof_clock_buffer(void* dev_ptr);
 
 #ifdef __cplusplus
