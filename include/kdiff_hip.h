@@ -89,7 +89,7 @@ typedef struct {
                            (hi = bf16(x), lo = bf16(x - hi)) in the 16 bytes of its 4 floats -- the operand format of the
                            split-bf16x3 attention cores, which then take it as stored (their prep = 2)        */
   const float* rope_pos;  /* kd_gemm_bf16 + KD_EPI_QKV: [rows_per_sample, 2] axial position (y, x) of every token       */
-  const float* rope_freq; /* kd_gemm_bf16 + KD_EPI_QKV: [n_heads, 8] AxialRoPE freqs / (2 pi) (angles in revolutions)   */
+  const float* rope_freq; /* kd_gemm_bf16 + KD_EPI_QKV: [n_heads, 8] AxialRoPE freqs / (2 pi) (angles in revolutions); 32-byte aligned */
 } KdGemm;
 
 int kd_gemm_f32(const KdGemm* desc, void* stream);

@@ -189,10 +189,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
           const int vec = (n0 >> 6) + vv;                       // (q|k|v, head) vector index of these 64 columns
           const int which = vec / p.n_heads, head = vec - which * p.n_heads;
           if (which < 2) {
+            // per-head constants through the scalar cache (see the astat kernel: as vector loads they sit behind a vmcnt(0) that
+            // also waits for this wave's earlier stores)
+            typedef float f32x8s __attribute__((ext_vector_type(8)));
+            f32x8s fq;
+            float qsc;
+            asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                         : "=s"(fq), "=s"(qsc) : "s"(p.freq + head * 8), "s"(p.qk_scale + head) : "memory");
             float fr[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) fr[u] = lh ? p.freq[head * 8 + 4 + u] : p.freq[head * 8 + u];
-            qk_prep_blocks(acc[2 * vv], acc[2 * vv + 1], rs, sqrtf(p.qk_scale[head]), p.eps, py, px, fr);
+            for (int u = 0; u < 4; ++u) fr[u] = lh ? fq[4 + u] : fq[u];
+            qk_prep_blocks(acc[2 * vv], acc[2 * vv + 1], rs, sqrtf(qsc), p.eps, py, px, fr);
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[2 * vv][r] *= rs; acc[2 * vv + 1][r] *= rs; }
@@ -1300,6 +1307,8 @@ extern "C" int kd_gemm_bf16(const KdGemm* dp, void* stream) {
   if (d.epi == KD_EPI_RESIDUAL && !d.R) return fail(KD_EINVAL, "kd_gemm_bf16: residual needs R");
   if (d.epi == KD_EPI_QKV && (d.n_heads <= 0 || d.N != 3 * d.n_heads * 64 || d.rows_per_sample <= 0 || !d.qk_scale || !d.rope_pos || !d.rope_freq))
     return fail(KD_EINVAL, "kd_gemm_bf16: qkv epilogue needs N == 3*n_heads*64, rows_per_sample, qk_scale, rope_pos, rope_freq");
+  if (d.epi == KD_EPI_QKV && ((reinterpret_cast<uintptr_t>(d.rope_freq) & 31) || (reinterpret_cast<uintptr_t>(d.qk_scale) & 3)))
+    return fail(KD_EINVAL, "kd_gemm_bf16: rope_freq must be 32-byte aligned (a head's 8 frequencies are one scalar load), qk_scale 4-byte aligned");
   if (d.a_mode != KD_A_PLAIN && (d.gh <= 0 || d.gw <= 0 || d.M % (d.gh * d.gw))) return fail(KD_EINVAL, "kd_gemm_bf16: gather mode needs gh, gw with M %% (gh*gw) == 0");
   if (d.epi == KD_EPI_SPLIT_LERP && (!d.R || !d.fac || (d.N & 3) || d.gh <= 0 || d.gw <= 0 || d.M % (d.gh * d.gw))) return fail(KD_EINVAL, "kd_gemm_bf16: split needs R, fac, N%%4==0, gh, gw");
   int rc = 0;
