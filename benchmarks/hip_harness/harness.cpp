@@ -770,6 +770,9 @@ int main(int argc, char** argv) {
       {"attn na k3", 2, 2, 20, 33, 2, 3, 0},
       {"attn na k5", 2, 2, 20, 33, 2, 5, 0},
       {"attn na k9", 2, 2, 20, 33, 2, 9, 0},
+      {"attn na k11", 2, 2, 24, 40, 2, 11, 0},
+      {"attn na k13", 2, 2, 32, 29, 2, 13, 0},
+      {"attn na k13 L1", 2, 32, 32, 32, 4, 13, 0},
   };
   for (const auto& c : acs) run_attn_case(c);
   if (want("attn global L2")) {

@@ -187,7 +187,8 @@ int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, int W, int 
 
 /* The three attention cores in bf16 arithmetic (KD_PREC_BF16): qkv is the bf16 output of kd_gemm_bf16's KD_EPI_QKV epilogue
  * ([tokens, 3, nh, 64], q and k already prepared), out is bf16 [tokens, nh * 64].  bf16 MFMA products, fp32 scores / softmax /
- * accumulators.  Same reference call sites as the fp32 entry points above; kd_attn_na2d_bf16 takes kernel sizes 3, 5, 7, 9. */
+ * accumulators.  Same reference call sites as the fp32 entry points above; kd_attn_na2d_bf16 takes kernel sizes 3 .. 13 (odd;
+ * 3 .. 9 in the tuned form, 11 and 13 in a general one). */
 int kd_attn_global_bf16(const void* qkv, void* out, int batch, int T, int nh, void* stream);
 int kd_attn_window_bf16(const void* qkv, void* out, int batch, int H, int W, int nh, int ws, int shift, void* stream);
 int kd_attn_na2d_bf16(const void* qkv, void* out, int batch, int H, int W, int nh, int ks, void* stream);

@@ -454,6 +454,135 @@ __global__ __launch_bounds__(256, (NaGeo<KS>::LDS <= 80 * 1024) ? 2 : 1) void at
   store_o(a.out + ((size_t)b * T + q_tok) * (a.nh * DH) + head * DH, O, 1.0f / l, h2, q_ok);
 }
 
+// ---- neighbourhood core, kernel sizes 11 and 13 ------------------------------------------------------------------------------------
+// The 4x8 query block of a wave now needs a patch of (4 + KS - 1) rows x (8 + KS - 1) = 18 / 20 columns: no longer a power-of-two
+// width, so the patch is walked DENSELY: local key kl = 20 r + c (columns padded to 20, a multiple of 4 so that the 4-key groups of
+// the V^T reads never straddle two patch rows), tiles of 32 keys, every key's (row, column) by constant division, validity per
+// accumulator register from those.  One workgroup per CU (122 / 145 KiB of halo images), the whole register file per wave.
+// Correctness form for the sizes no shipped config uses; the 3..9 kernel above is the tuned one.
+template <int KS>
+struct NaWide {
+  static constexpr int HR = NA_TH + KS - 1, HC = NA_TW + KS - 1;
+  static constexpr int PR = 4 + KS - 1, PC = 20;                            // patch rows; padded patch width
+  static constexpr int NKT = (PR * PC + 31) / 32;
+  static constexpr int ROWS = ((HR * HC + 2 * PC + 7) / 8) * 8;             // slack: padded columns and the last tile's tail poke past the halo
+  static constexpr int LDS = 2 * ROWS * 128;
+  static_assert(8 + KS - 1 <= PC, "patch width");
+};
+
+template <int KS>
+__global__ __launch_bounds__(256, 1) void attn_na2d_wide_bf16_kernel(const NArgs a) {
+  using G = NaWide<KS>;
+  constexpr int HR = G::HR, HC = G::HC, PR = G::PR, PC = G::PC, NKT = G::NKT, ROWS = G::ROWS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kimg = smem;
+  char* Vimg = smem + ROWS * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h2 = lane >> 5;
+  const int wy_ = wid >> 1, wx_ = wid & 1;
+  const int tiles_x = (a.W + NA_TW - 1) / NA_TW, tiles_y = (a.H + NA_TH - 1) / NA_TH;
+  int r = blockIdx.x;
+  const int tx = r % tiles_x; r /= tiles_x;
+  const int ty = r % tiles_y; r /= tiles_y;
+  const int head = r % a.nh, b = r / a.nh;
+  const int T = a.H * a.W;
+  const size_t row_bytes = (size_t)3 * a.nh * DH * 2;
+  const char* base = reinterpret_cast<const char*>(a.qkv) + (size_t)b * T * row_bytes + head * (DH * 2);
+  const int ty0 = ty * NA_TH, tx0 = tx * NA_TW;
+  const int hy0 = max(0, min(ty0 - KS / 2, a.H - HR)), hx0 = max(0, min(tx0 - KS / 2, a.W - HC));
+  for (int pc = wid; pc < ROWS / 8; pc += 4) {
+    const int row = 8 * pc + (lane >> 3);
+    const int ky = min(hy0 + row / HC, a.H - 1), kx = min(hx0 + row % HC, a.W - 1);       // rows past the halo: any real token (masked)
+    const char* src = base + (size_t)(ky * a.W + kx) * row_bytes + (((lane & 7) ^ asw(row)) << 4);
+    glds16(src + a.nh * DH * 2, Kimg + pc * 1024);
+    glds16(src + 2 * a.nh * DH * 2, Vimg + pc * 1024);
+  }
+  const int qy_raw = ty0 + 4 * wy_ + (l31 >> 3), qx_raw = tx0 + 8 * wx_ + (l31 & 7);
+  const bool q_ok = qy_raw < a.H && qx_raw < a.W;
+  const int qy = min(qy_raw, a.H - 1), qx = min(qx_raw, a.W - 1);
+  const int q_tok = qy * a.W + qx;
+  bf16x8 qf[4];
+  {
+    const u32x4* qp = reinterpret_cast<const u32x4*>(base + (size_t)q_tok * row_bytes + 16 * h2);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) qf[st] = __builtin_bit_cast(bf16x8, qp[2 * st]);
+  }
+  const int wy = max(0, min(qy - KS / 2, a.H - KS)) - hy0, wx = max(0, min(qx - KS / 2, a.W - KS)) - hx0;
+  const int row_lo = min(max(0, min(min(ty0 + 4 * wy_, a.H - 1) - KS / 2, a.H - KS)) - hy0, HR - PR);
+  const int col_lo = min(max(0, min(min(tx0 + 8 * wx_, a.W - 1) - KS / 2, a.W - KS)) - hx0, HC - (8 + KS - 1));
+  const int korg = row_lo * HC + col_lo;
+  const int r0 = wy - row_lo, c0 = wx - col_lo;
+  auto img_row = [&](int kl) -> int { return korg + (kl / PC) * HC + (kl % PC); };     // LDS row of local key kl
+  KD_WAIT_VM(0);
+  KD_BARRIER();
+
+  f32x16 S[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    const int kr = min(img_row(32 * t + l31), ROWS - 1);
+    const int ka = kr * 128 + ((h2 ^ asw(kr)) << 4);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kimg + (ka ^ (32 * st)));
+      S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], S[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kl = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h2;
+      const int pr = kl / PC, pcn = kl % PC;
+      const bool valid = (unsigned)(pr - r0) < (unsigned)KS && (unsigned)(pcn - c0) < (unsigned)KS && pr < PR;
+      S[t][i] = valid ? S[t][i] : -INFINITY;
+    }
+  const float m = score_max<NKT>(S);
+  float l = score_exp<NKT>(S, m);
+  l += __shfl_xor(l, 32, 64);
+
+  f32x16 O[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) O[e][i] = 0.f;
+  const int c = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1), sub = (lane & 1) * 8;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const bf16x8 pf = p_frag(S[t], u);
+      // k-slots of lane-half h2: keys 32 t + 16 u + 4 h2 + {0..3} and the same + 8 -- two 4-key groups, each inside one patch row
+      const int k0 = 32 * t + 16 * u + 4 * h2;
+      const int ra = min(img_row(k0) + vt_lane_row(lane), ROWS - 1), rb = min(img_row(k0 + 8) + vt_lane_row(lane), ROWS - 1);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4 __attribute__((address_space(3)))*)(Vimg + ra * 128 + (((4 * e + c) ^ asw(ra)) << 4) + sub));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4 __attribute__((address_space(3)))*)(Vimg + rb * 128 + (((4 * e + c) ^ asw(rb)) << 4) + sub));
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2v = __builtin_bit_cast(u32x2, hi);
+        O[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4{l2[0], l2[1], h2v[0], h2v[1]}), pf, O[e], 0, 0, 0);
+      }
+    }
+  store_o(a.out + ((size_t)b * T + q_tok) * (a.nh * DH) + head * DH, O, 1.0f / l, h2, q_ok);
+}
+
+template <int KS>
+static int launch_na_wide(const NArgs& a, hipStream_t s) {
+  auto k = attn_na2d_wide_bf16_kernel<KS>;
+  static bool set = false;
+  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, NaWide<KS>::LDS); set = true; }
+  const long nb = (long)a.batch * a.nh * ((a.H + NA_TH - 1) / NA_TH) * ((a.W + NA_TW - 1) / NA_TW);
+  char nm[64] = "attn_na2d_bf16";
+  if (prof_on()) snprintf(nm, sizeof(nm), "attn_na2d_bf16 k%d %dx%d nh=%d", KS, a.H, a.W, a.nh);
+  LaunchScope prof(nm, 4.0 * a.batch * (double)a.H * a.W * a.nh * DH * KS * KS, 8.0 * a.batch * (double)a.H * a.W * a.nh * DH, s);
+  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(256), NaWide<KS>::LDS, s, a);
+  return check_launch("kd_attn_na2d_bf16");
+}
+
 template <int MODE, int NT, int QW>
 static int launch_dense(const DArgs& a, long nproblems, const char* name, hipStream_t s) {
   constexpr int LDS = NT * 32 * 256, NQB = (NT + QW - 1) / QW;
@@ -522,7 +651,7 @@ extern "C" int kd_attn_window_bf16(const void* qkv, void* out, int batch, int H,
 
 extern "C" int kd_attn_na2d_bf16(const void* qkv, void* out, int batch, int H, int W, int nh, int ks, void* stream) {
   if (!qkv || !out || batch <= 0 || nh <= 0) return fail(KD_EINVAL, "kd_attn_na2d_bf16: bad arguments");
-  if (ks < 3 || ks > 9 || !(ks & 1)) return fail(KD_EINVAL, "kd_attn_na2d_bf16: kernel_size %d unsupported (3, 5, 7 or 9)", ks);
+  if (ks < 3 || ks > 13 || !(ks & 1)) return fail(KD_EINVAL, "kd_attn_na2d_bf16: kernel_size %d unsupported (3, 5, 7, 9, 11 or 13)", ks);
   if (H < ks || W < ks) return fail(KD_EINVAL, "kd_attn_na2d_bf16: grid %dx%d smaller than the %dx%d neighbourhood", H, W, ks, ks);
   NArgs a{reinterpret_cast<const u16*>(qkv), reinterpret_cast<u16*>(out), batch, H, W, nh};
   hipStream_t s = (hipStream_t)stream;
@@ -530,6 +659,8 @@ extern "C" int kd_attn_na2d_bf16(const void* qkv, void* out, int batch, int H, i
     case 3: return launch_na<3>(a, s);
     case 5: return launch_na<5>(a, s);
     case 7: return launch_na<7>(a, s);
-    default: return launch_na<9>(a, s);
+    case 9: return launch_na<9>(a, s);
+    case 11: return launch_na_wide<11>(a, s);
+    default: return launch_na_wide<13>(a, s);
   }
 }

@@ -638,7 +638,8 @@ def test_bf16_attention_cores(ops, golden):
         q, k, v = o[f"attn_{tag}.q"], o[f"attn_{tag}.k"], o[f"attn_{tag}.v"]
         y = ops.attn_window(_bf(_pack(q, k, v)), q.shape[3], ws, shift).float().cpu().view(q.shape)
         assert relerr(y, o[f"attn_{tag}.o"]) < 1.2e-2, tag
-    for ks, (B, H, W, nh) in ((3, (2, 9, 12, 2)), (5, (2, 20, 13, 1)), (7, (1, 32, 32, 4)), (7, (2, 7, 7, 1)), (9, (2, 20, 33, 2)), (9, (1, 9, 9, 1))):
+    for ks, (B, H, W, nh) in ((3, (2, 9, 12, 2)), (5, (2, 20, 13, 1)), (7, (1, 32, 32, 4)), (7, (2, 7, 7, 1)), (9, (2, 20, 33, 2)), (9, (1, 9, 9, 1)),
+                              (11, (2, 24, 40, 2)), (11, (1, 11, 13, 1)), (13, (1, 32, 32, 2)), (13, (2, 13, 21, 1)), (13, (1, 45, 19, 1))):
         q, k, v = (rn(B, H, W, nh, 64, seed=s, scale=sc) for s, sc in ((1, 0.5), (2, 0.5), (3, 1.0)))
         y = ops.attn_na2d(_bf(_pack(q, k, v)), nh, ks).float().cpu().view(B, H, W, nh, 64)
         assert relerr(y, hdit.na2d(_rt(q), _rt(k), _rt(v), ks, 1.0)) < 1.2e-2, (ks, H, W)
@@ -650,7 +651,9 @@ def test_bf16_attention_cores(ops, golden):
     with pytest.raises(ValueError, match="prepared"):
         ops.attn_global(qkv.view(2, 256, -1), 2, prep=(g(o["qk.scale"]), None, None))
     with pytest.raises(RuntimeError, match="kernel_size"):
-        ops.attn_na2d(qkv, 2, 11)
+        ops.attn_na2d(qkv, 2, 15)
+    with pytest.raises(RuntimeError, match="kernel_size"):
+        ops.attn_na2d(qkv, 2, 6)
 
 
 def test_bf16_merge_split_patch(ops, golden):
