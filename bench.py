@@ -269,10 +269,10 @@ def main():
     # region because ~9k event records per pass cost ~5% throughput.
     if ctx.is_main_process and not args.no_kernel_events:
         K._native.lib().kd_prof_reset()
-        K._native.lib().kd_prof_enable(1)
+        K._native.prof_enable(True)
         sampler(den, x0, sigmas, extra_args=extra, disable=True)
         torch.cuda.synchronize()
-        K._native.lib().kd_prof_enable(0)
+        K._native.prof_enable(False)
     assert torch.isfinite(out).all()
 
     if ctx.is_main_process:

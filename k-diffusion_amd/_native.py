@@ -142,11 +142,12 @@ _ENV_OPTIONS = {"KDIFF_SKINNY": ("skinny", 1), "KDIFF_ASTAT": ("astat", 1), "KDI
                 "KDIFF_ASTAT_WAVES": ("astat_waves", 4), "KDIFF_ASTAT_STOREWAIT": ("astat_storewait", 0), "KD_GEMM_DEBUG": ("gemm_debug", 0),
                 "KDIFF_BF16_FAST": ("bf16_fast", 1)}
 _env_applied = None
+option_epoch = 0          # bumped whenever a library option may have changed: captured launch graphs are bound to one epoch
 
 
 def _sync_options(handle):
     """KDIFF_* variables -> kd_set_option; KDIFF_OPTIONS="name=value,..." sets any library option by name (A-B runs of bench.py)."""
-    global _env_applied
+    global _env_applied, option_epoch
     cur = tuple(os.environ.get(k) for k in _ENV_OPTIONS) + (os.environ.get("KDIFF_OPTIONS"),)
     if cur != _env_applied:
         for (env, (name, dflt)), val in zip(_ENV_OPTIONS.items(), cur):
@@ -157,11 +158,25 @@ def _sync_options(handle):
                 if handle.kd_set_option(name.strip().encode(), int(val)) != 0:
                     raise ValueError(f"KDIFF_OPTIONS: unknown library option {name.strip()!r}")
         _env_applied = cur
+        option_epoch += 1
+
+
+prof_active = False
+
+
+def prof_enable(on):
+    """Per-launch HIP-event timing of every kernel (kd_prof_*).  While it is on, the model issues its launch lists directly
+    (a captured graph has no per-kernel events to read back)."""
+    global prof_active
+    check(lib().kd_prof_enable(1 if on else 0), "kd_prof_enable")
+    prof_active = bool(on)
 
 
 def set_option(name, value):
     """Tuning / A-B switch of the library (include/kdiff_hip.h: kd_set_option)."""
+    global option_epoch
     check(lib().kd_set_option(name.encode(), int(value)), "kd_set_option")
+    option_epoch += 1
 
 
 def check(code, what="libkdiff_hip"):

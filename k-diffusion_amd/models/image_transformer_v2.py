@@ -36,6 +36,22 @@ from .. import ops
 from . import axial_rope
 
 D_HEAD = 64
+# Launch-bound regime: below this many level-0 tokens per forward the 60-odd kernels of the main chain are shorter than the host
+# needs to issue them one by one, so the chain is captured once per (scale table, preconditioning) combination and replayed as a
+# hipGraph (one host call per forward).  Above it the host stays ahead anyway and replay measured 2 % slower.
+# KDIFF_GRAPH=0 / 1 forces never / always.
+GRAPH_AUTO_MAX_TOKENS = 16384
+
+
+def _graph_policy(tokens):
+    mode = os.environ.get("KDIFF_GRAPH", "auto").lower()
+    if mode in ("0", "off", "never"):
+        return False
+    if mode in ("1", "on", "always"):
+        return True
+    if mode != "auto":
+        raise ValueError(f"KDIFF_GRAPH={mode!r}: expected 0, 1 or auto")
+    return tokens <= GRAPH_AUTO_MAX_TOKENS
 
 
 # ---------------------------------------------------------------------------------- configuration
@@ -163,6 +179,12 @@ class _Plan:
                 raise ValueError(f"token grid {gh}x{gw} cannot be merged 2x2")
             grids.append((gh // 2, gw // 2))
         self.B, self.grids = B, grids
+        self.out_shape = (B, m.out_channels, H, W)
+        self.use_graph = _graph_policy(B * grids[0][0] * grids[0][1])
+        self.graphs, self.cond_graphs = {}, {}              # captured main chains / conditioning chains (see replay())
+        self.g_x = self.g_out = self.capture_stream = None   # their fixed input / output images
+        self.direct_runs = self.direct_cond_runs = 0
+        self.graph_epoch = nat.option_epoch
         mw, mdff = m.mapping_spec.width, m.mapping_spec.d_ff
 
         # ---- static buffers -----------------------------------------------------------------
@@ -378,6 +400,61 @@ class _Plan:
             if rc:
                 nat.check(rc, ln.what)
 
+    # ---- hipGraph replay (launch-bound batch sizes only: ``use_graph``) ---------------------------------------------------
+    def _capture(self, issue):
+        # capture_begin / capture_end rather than the torch.cuda.graph context: that one synchronises the device, runs the
+        # garbage collector and empties the allocator cache first, none of which a capture of pure kernel launches needs
+        # (the library allocates nothing and never syncs; nothing executes during capture)
+        g = torch.cuda.CUDAGraph()
+        if self.capture_stream is None:
+            self.capture_stream = torch.cuda.Stream(device=self.sigma.device)
+        with torch.cuda.stream(self.capture_stream):
+            g.capture_begin(capture_error_mode="thread_local")
+            try:
+                issue()
+            finally:
+                g.capture_end()
+        return g
+
+    def _graph_epoch(self):
+        """Kernel selection inside the library follows its options (kd_set_option): graphs captured under other settings are dropped."""
+        if self.graph_epoch != nat.option_epoch:
+            self.graphs, self.cond_graphs, self.graph_epoch = {}, {}, nat.option_epoch
+            self.direct_runs = self.direct_cond_runs = 0          # another kernel family may see its first launch now
+
+    def replay(self, x, sigma_data, buf):
+        """``run`` through a captured graph.  Kernel arguments are frozen at capture, so the chain reads a fixed input image
+        and writes a fixed output image (two small copies per forward at these sizes) and there is one graph per
+        (scale table, preconditioning) combination.  The first forward of a plan is issued directly (one-time kernel
+        attribute set-up must not happen under capture)."""
+        if self.g_x is None:
+            self.g_x = torch.empty_like(x)
+            self.g_out = torch.empty(self.out_shape, device=x.device, dtype=torch.float32)
+        self.g_x.copy_(x, non_blocking=True)
+        self._graph_epoch()
+        key = (buf, None if sigma_data is None else float(sigma_data))
+        g = self.graphs.get(key)
+        if g is None and self.direct_runs == 0:
+            self.direct_runs += 1
+            self.run(self.g_x, self.g_out, sigma_data, buf)
+        else:
+            if g is None:
+                g = self.graphs[key] = self._capture(lambda: self.run(self.g_x, self.g_out, sigma_data, buf))
+            g.replay()
+        return self.g_out.clone()
+
+    def replay_cond(self, buf):
+        """``run_cond`` on the current stream, replayed from a graph after the first direct pass."""
+        self._graph_epoch()
+        g = self.cond_graphs.get(buf)
+        if g is None and self.direct_cond_runs == 0:
+            self.direct_cond_runs += 1
+            self.run_cond(buf, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            return
+        if g is None:
+            g = self.cond_graphs[buf] = self._capture(lambda: self.run_cond(buf, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        g.replay()
+
 
 # ---------------------------------------------------------------------------------- the model
 
@@ -504,7 +581,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
             self._plans, self._fingerprint, self._packed = {}, fp, {}
         has_class = self.class_emb is not None
         key = (B, H, W, aug_cond is not None, has_class, self.mapping_cond_in_proj is not None, x.device, nat.default_precision(),
-               os.environ.get("KDIFF_QKV_PACKED", "1"))
+               os.environ.get("KDIFF_QKV_PACKED", "1"), os.environ.get("KDIFF_GRAPH", "auto"))
         plan = self._plans.get(key)
         if plan is None:
             if self.patch_in.proj.weight.device != x.device:
@@ -518,6 +595,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
                     del self._plans[key]
                     raise IndexError(f"class_cond ids must lie in [0, {self.class_emb.weight.shape[0] - 1}] (got {lo}..{hi})")
         cur = torch.cuda.current_stream()
+        graphed = plan.use_graph and not nat.prof_active and not torch.cuda.is_current_stream_capturing()
         ident = self._cond_identity(sigma, aug_cond, class_cond, mapping_cond)
         pre, plan.prefetched = plan.prefetched, None
         if pre is not None and pre[0] == ident:
@@ -528,10 +606,15 @@ class ImageTransformerDenoiserModelV2(nn.Module):
             if pre is not None:
                 cur.wait_event(pre[2])            # an unused prefetch still owns the conditioning workspace: order behind it
             self._fill_cond_inputs(plan, B, sigma, aug_cond, class_cond, mapping_cond)
-            plan.run_cond(buf, C.c_void_p(cur.cuda_stream))
+            if graphed:
+                plan.replay_cond(buf)
+            else:
+                plan.run_cond(buf, C.c_void_p(cur.cuda_stream))
         plan.last_buf = buf
         plan.sigma.copy_(sigma.reshape(-1).expand(B) if sigma.numel() == 1 else sigma.reshape(B), non_blocking=True)
         plan.main_entry.record(cur)               # everything before this step's main chain (incl. an inline conditioning chain)
+        if graphed:
+            return plan.replay(x, sigma_data, buf)
         out = torch.empty(B, self.out_channels, H, W, device=x.device, dtype=torch.float32)
         plan.run(x, out, sigma_data, buf)
         return out
@@ -559,7 +642,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
             return
         B, _, H, W = x_like.shape
         key = (B, H, W, aug_cond is not None, self.class_emb is not None, self.mapping_cond_in_proj is not None, x_like.device,
-               nat.default_precision(), os.environ.get("KDIFF_QKV_PACKED", "1"))
+               nat.default_precision(), os.environ.get("KDIFF_QKV_PACKED", "1"), os.environ.get("KDIFF_GRAPH", "auto"))
         plan = self._plans.get(key)
         if plan is None or plan.prefetched is not None or self._weights_fingerprint() != self._fingerprint:
             return
@@ -570,7 +653,10 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         side.wait_event(plan.main_entry)          # table `buf` and the conditioning workspace are free once the main chain of
         with torch.cuda.stream(side):             # the step in flight has started (its predecessors are complete in stream order)
             self._fill_cond_inputs(plan, B, sigma, aug_cond, class_cond, mapping_cond)
-            plan.run_cond(buf, C.c_void_p(side.cuda_stream))
+            if plan.use_graph and not nat.prof_active:
+                plan.replay_cond(buf)
+            else:
+                plan.run_cond(buf, C.c_void_p(side.cuda_stream))
             done = torch.cuda.Event()
             done.record(side)
         # the record keeps the hinted tensors alive: while it is pending their storage cannot be freed and handed to another

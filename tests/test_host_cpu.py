@@ -54,7 +54,7 @@ def test_bad_arguments_are_rejected_without_a_gpu(KD):
     d.M, d.N, d.K, d.precision = 8, 8, 8, 1
     assert lib.kd_gemm_bf16(ctypes.byref(d), None) == -1
     assert b"KD_PREC_BF16" in lib.kd_last_error()
-    assert lib.kd_attn_na2d_bf16(1, 1, 1, 16, 16, 1, 11, None) == -1
+    assert lib.kd_attn_na2d_bf16(1, 1, 1, 16, 16, 1, 15, None) == -1          # kernel sizes 3 .. 13 (odd)
     assert b"kernel_size" in lib.kd_last_error()
     assert lib.kd_attn_window_bf16(1, 1, 1, 16, 16, 1, 7, 0, None) == -1
     assert lib.kd_attn_global_bf16(None, 1, 1, 16, 1, None) == -1
