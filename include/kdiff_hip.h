@@ -90,6 +90,10 @@ typedef struct {
                            split-bf16x3 attention cores, which then take it as stored (their prep = 2)        */
   const float* rope_pos;  /* kd_gemm_bf16 + KD_EPI_QKV: [rows_per_sample, 2] axial position (y, x) of every token       */
   const float* rope_freq; /* kd_gemm_bf16 + KD_EPI_QKV: [n_heads, 8] AxialRoPE freqs / (2 pi) (angles in revolutions); 32-byte aligned */
+  int per_row;          /* kd_gemm_f32, products with one row per SAMPLE (the conditioning chain): always use the per-row fp32 FMA
+                           kernel, also above its 128-row default limit.  A row's result then does not depend on how many rows
+                           share the launch, so the conditioning of a whole sigma schedule (steps x batch rows in one launch)
+                           is bit-identical with computing it step by step */
 } KdGemm;
 
 int kd_gemm_f32(const KdGemm* desc, void* stream);

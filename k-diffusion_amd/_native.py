@@ -47,6 +47,7 @@ class KdGemm(C.Structure):
         ("precision", C.c_int), ("Wp", C.c_void_p),
         ("n_heads", C.c_int), ("qk_scale", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
         ("qkv_packed", C.c_int), ("rope_pos", C.c_void_p), ("rope_freq", C.c_void_p),
+        ("per_row", C.c_int),
     ]
 
 

@@ -1,4 +1,5 @@
-// Skinny GEMM for the conditioning chain: C[M, N] = epilogue( norm(A)[M, K] @ W[N, K]^T ) with M <= 128 rows.
+// Skinny GEMM for the conditioning chain: C[M, N] = epilogue( norm(A)[M, K] @ W[N, K]^T ) with M <= 128 rows (any M when the
+// descriptor asks for it with `per_row`: the conditioning of a whole sigma schedule in one launch, bit-identical per row).
 //
 // The mapping network, the time / class / augmentation embeddings and the AdaRMSNorm scale projection
 // (image_transformer_v2.py:569-581, :734-740, :155-166) multiply a [batch, width] activation by a weight: one row per
@@ -98,7 +99,7 @@ static int launch(const KdGemm& d, hipStream_t s) {
 // returns 0 when the descriptor was served here (*rc = launch status), 1 when it is not eligible
 int gemm_skinny_try(const GemmP& d, hipStream_t s, int* rc) {
   using namespace skinny;
-  if (d.M > 2 * ROWS || d.a_mode != KD_A_PLAIN || !d.W || d.debug) return 1;
+  if ((d.M > 2 * ROWS && !d.per_row) || d.a_mode != KD_A_PLAIN || !d.W || d.debug) return 1;
   if (d.norm && d.scale_stride != 0) return 1;            // per-sample scale vectors: not the conditioning chain's case
   if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_RESIDUAL && d.epi != KD_EPI_GEGLU) return 1;
 #define KD_SK(NO, EP) if ((d.norm != 0) == NO && d.epi == EP) { *rc = launch<NO, EP>(d, s); return 0; }

@@ -32,6 +32,11 @@ class Denoiser(nn.Module):
     def loss(self, *args, **kwargs):
         raise NotImplementedError('training losses are outside this package\'s scope (sampling hot path only)')
 
+    def prefetch_schedule(self, x_like, sigma_table, **kwargs):
+        """Solver-loop hint (see ImageTransformerDenoiserModelV2.prefetch_schedule); a no-op for foreign inner models."""
+        hint = getattr(self.inner_model, 'prefetch_schedule', None)
+        return hint(x_like, sigma_table, **kwargs) if hint is not None else False
+
     def prefetch_conditioning(self, x_like, sigma, **kwargs):
         """Solver-loop hint (see ImageTransformerDenoiserModelV2.prefetch_conditioning); a no-op for foreign inner models."""
         hint = getattr(self.inner_model, 'prefetch_conditioning', None)

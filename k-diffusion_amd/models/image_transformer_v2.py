@@ -36,22 +36,21 @@ from .. import ops
 from . import axial_rope
 
 D_HEAD = 64
-# Launch-bound regime: below this many level-0 tokens per forward the 60-odd kernels of the main chain are shorter than the host
-# needs to issue them one by one, so the chain is captured once per (scale table, preconditioning) combination and replayed as a
-# hipGraph (one host call per forward).  Above it the host stays ahead anyway and replay measured 2 % slower.
-# KDIFF_GRAPH=0 / 1 forces never / always.
-GRAPH_AUTO_MAX_TOKENS = 16384
+# KDIFF_GRAPH=1: replay the main and the per-step conditioning chain of a forward from captured hipGraphs (one host call per
+# forward) instead of issuing their 60-odd launches one by one.  Off by default: replay measured 2 % slower at batch 32 (the
+# host stays ahead of the GPU there anyway) and no faster at batch 1..8, where a forward costs ~1 ms whatever the batch --
+# ~15 us per DEPENDENT kernel on the device, which a graph of the same kernels does not shorten
+# (profiles/r02_small_batch_graph.log).
+# Largest [steps, B, scale_width] scale table kept per sigma schedule (prefetch_schedule); longer schedules use the per-step chain.
+SCHEDULE_TABLE_MAX_BYTES = 1 << 30
+SCHEDULES_KEPT = 4            # a run of a two-stage solver hints two tables; older records (and their tensors) are dropped
 
 
-def _graph_policy(tokens):
-    mode = os.environ.get("KDIFF_GRAPH", "auto").lower()
-    if mode in ("0", "off", "never"):
-        return False
-    if mode in ("1", "on", "always"):
-        return True
-    if mode != "auto":
-        raise ValueError(f"KDIFF_GRAPH={mode!r}: expected 0, 1 or auto")
-    return tokens <= GRAPH_AUTO_MAX_TOKENS
+def _graph_policy():
+    mode = os.environ.get("KDIFF_GRAPH", "0").lower()
+    if mode not in ("0", "1"):
+        raise ValueError(f"KDIFF_GRAPH={mode!r}: expected 0 or 1")
+    return mode == "1"
 
 
 # ---------------------------------------------------------------------------------- configuration
@@ -154,6 +153,56 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+class _CondChain:
+    """Launch list + buffers of the conditioning chain for a fixed number of rows (one row per sample and model call).
+    Every kernel of the chain works row by row (the products go through the per-row fp32 FMA kernel, KdGemm.per_row), so
+    a row's scales do not depend on how many rows share the launches: B rows per solver step or steps x B rows at once."""
+
+    def __init__(self, rows):
+        self.rows, self.launches, self.keep = rows, [], []
+        self.c_sigma = self.class_ids = self.aug_in = self.map_in = self.d_scales = None
+
+    def fill(self, sigma, aug_cond, class_cond, mapping_cond, repeat=1):
+        """Inputs of the chain on the current stream.  ``sigma``: [rows] (or one value); the other tensors are per sample
+        ([rows / repeat, ...]) and repeated for every step of a schedule."""
+        rows = self.rows
+        self.c_sigma.copy_(sigma.reshape(-1).expand(rows) if sigma.numel() == 1 else sigma.reshape(rows), non_blocking=True)
+        B = rows // repeat
+        if self.class_ids is not None and class_cond is not None:
+            self.class_ids.view(repeat, B).copy_(class_cond.reshape(1, B).expand(repeat, B), non_blocking=True)
+        if self.aug_in is not None:
+            self.aug_in.view(repeat, B, 9).copy_(aug_cond.reshape(1, B, 9).expand(repeat, B, 9), non_blocking=True)
+        if self.map_in is not None:
+            self.map_in.view(repeat, B, -1).copy_(mapping_cond.reshape(1, B, -1).expand(repeat, B, -1), non_blocking=True)
+
+    def run(self, table_ptr, stream):
+        """Scales of every AdaRMSNorm of the network for every row -> [rows, scale_width] fp32 at ``table_ptr``."""
+        self.d_scales.C = table_ptr
+        for ln in self.launches:
+            rc = ln.fn(*ln.args, stream)
+            if rc:
+                nat.check(rc, ln.what)
+
+
+class _Schedule:
+    """Scale tables of a whole sigma schedule: rows of ``sigma_table`` ([n, B], one row per model call) -> tables[i]."""
+
+    def __init__(self, sigma_table, others, ident_others, tables, done):
+        self.base, self.version, self.n, self.B = sigma_table.data_ptr(), sigma_table._version, sigma_table.shape[0], sigma_table.shape[1]
+        self.ident_others, self.tables, self.done = ident_others, tables, done
+        # the record keeps the hinted tensors alive, so their addresses cannot be handed to other tensors while it exists
+        self.keep = (sigma_table, others)
+
+    def row_of(self, sigma):
+        """Index of the table row ``sigma`` is a view of, or None."""
+        if sigma.dtype != torch.float32 or sigma.numel() != self.B or not sigma.is_contiguous() or sigma._version != self.version:
+            return None
+        off = sigma.data_ptr() - self.base
+        if off < 0 or off % (4 * self.B) or off // (4 * self.B) >= self.n:
+            return None
+        return off // (4 * self.B)
+
+
 class _Plan:
     """Workspace + prebuilt launch list for one (batch, H, W, conditioning-kinds) combination."""
 
@@ -180,7 +229,7 @@ class _Plan:
             grids.append((gh // 2, gw // 2))
         self.B, self.grids = B, grids
         self.out_shape = (B, m.out_channels, H, W)
-        self.use_graph = _graph_policy(B * grids[0][0] * grids[0][1])
+        self.use_graph = _graph_policy()
         self.graphs, self.cond_graphs = {}, {}              # captured main chains / conditioning chains (see replay())
         self.g_x = self.g_out = self.capture_stream = None   # their fixed input / output images
         self.direct_runs = self.direct_cond_runs = 0
@@ -189,19 +238,11 @@ class _Plan:
 
         # ---- static buffers -----------------------------------------------------------------
         self.sigma = torch.empty(B, **f32)                  # read by the patch-in / patch-out preconditioning of the MAIN chain
-        # inputs of the CONDITIONING chain (its own copies: the chain of the next solver step may run on the side
-        # stream while the main chain of the current step is still in flight)
-        self.c_sigma = torch.empty(B, **f32)
-        self.class_ids = torch.zeros(B, device=device, dtype=torch.int64)
-        self.aug_in = torch.zeros(B, 9, **f32) if has_aug else None
-        self.map_in = torch.zeros(B, m.mapping_cond_dim, **f32) if has_mapping_cond else None
         xs = [torch.empty(B, gh, gw, lv.width, **act) for (gh, gw), lv in zip(grids, levels)]
         toks = [B * gh * gw for gh, gw in grids]
         qkv = torch.empty(max(t * 3 * lv.width for t, lv in zip(toks, levels)), **act)
         att = torch.empty(max(t * lv.width for t, lv in zip(toks, levels)), **act)
         hid = torch.empty(max(t * lv.d_ff for t, lv in zip(toks, levels)), **act)
-        ff, temb, emb, mres, cond = (torch.empty(B, mw, **f32) for _ in range(5))
-        mh = torch.empty(B, mdff, **f32)
         norm_mods = m._ada_norm_modules()
         offsets, total = {}, 0
         for name, mod in norm_mods:
@@ -214,8 +255,8 @@ class _Plan:
         self.last_buf, self.prefetched = 1, None            # prefetched: (identity of the conditioning tensors, table, done event)
         self.side_stream = torch.cuda.Stream(device=device)
         self.main_entry = torch.cuda.Event()
-        self.cond_launches = []
-        self.keep += [xs, qkv, att, hid, ff, temb, emb, mres, cond, mh, wcat]
+        self.schedules, self.schedule_chains = [], {}       # conditioning of whole sigma schedules (prefetch_schedule); chains by length
+        self.keep += [xs, qkv, att, hid, wcat]
         self.xs = xs
 
         def gemm(what, A, Wt, Cc, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, scale_ptr=None, scale_stride=0,
@@ -224,6 +265,7 @@ class _Plan:
             d.M, d.N, d.K, d.a_mode, d.epi = M, N, K, a_mode, epi
             main = target is self.launches
             d.precision = precision if main else cond_precision
+            d.per_row = 0 if main else 1                    # conditioning products: one row per sample, see _CondChain
             if d.precision == nat.PREC_BF16:
                 d.Wp = m._packed_image(Wt, N, K, epi == nat.EPI_GEGLU, bf16=True).data_ptr()
             elif d.precision == nat.PREC_SPLIT3:
@@ -245,48 +287,66 @@ class _Plan:
                 d.qk_scale, d.rope_pos, d.rope_freq, d.n_heads = qk[0].data_ptr(), qk[1].data_ptr(), qk[2].data_ptr(), qk[3]
             elif qk is not None:
                 d.qk_scale, d.rope_cos, d.rope_sin, d.n_heads = qk[0].data_ptr(), qk[1].data_ptr(), qk[2].data_ptr(), qk[3]
-            self.keep.append(d)
+            (self.keep if main else chain.keep).append(d)
             target.append(_Launch(lib.kd_gemm_bf16 if d.precision == nat.PREC_BF16 else lib.kd_gemm_f32, (C.byref(d),), what))
             return d
 
         def call(what, fn, *args):
             target.append(_Launch(fn, args, what))
 
-        target = self.cond_launches
+        def build_cond(rows):
+            """The conditioning chain (image_transformer_v2.py:734-740, :569-581) for ``rows`` rows: FourierFeatures ->
+            mapping network -> every AdaRMSNorm scale of the network, with its own input and work buffers."""
+            nonlocal target, chain
+            ch = _CondChain(rows)
+            saved, target, chain = target, ch.launches, ch
+            try:
+                ch.c_sigma = torch.empty(rows, **f32)
+                ch.class_ids = torch.zeros(rows, device=device, dtype=torch.int64)
+                ch.aug_in = torch.zeros(rows, 9, **f32) if has_aug else None
+                ch.map_in = torch.zeros(rows, m.mapping_cond_dim, **f32) if has_mapping_cond else None
+                ff, temb, emb, mres, cond = (torch.empty(rows, mw, **f32) for _ in range(5))
+                mh = torch.empty(rows, mdff, **f32)
+                ch.keep += [ff, temb, emb, mres, cond, mh]
+                call("fourier_sigma", lib.kd_fourier_sigma_f32, _ptr(ch.c_sigma), _ptr(m.time_emb.weight), _ptr(ff), rows, mw // 2)
+                gemm("time_in_proj", ff, m.time_in_proj.weight, temb, rows, mw, mw)
+                if has_aug:
+                    aug_ff, aug_proj = torch.empty(rows, mw, **f32), torch.empty(rows, mw, **f32)
+                    ch.keep += [aug_ff, aug_proj]
+                    call("fourier_aug", lib.kd_fourier_f32, _ptr(ch.aug_in), _ptr(m.aug_emb.weight), _ptr(aug_ff), rows, 9, mw // 2)
+                    gemm("aug_in_proj", aug_ff, m.aug_in_proj.weight, aug_proj, rows, mw, mw)
+                    aug_term, aug_rows = aug_proj, 1
+                else:
+                    # aug_cond = zeros  =>  FourierFeatures = [cos 0, sin 0] = [1..1, 0..0]: a constant vector
+                    z_ff, aug_const = torch.empty(1, mw, **f32), torch.empty(1, mw, **f32)
+                    zeros9 = torch.zeros(1, 9, **f32)
+                    ch.keep += [z_ff, aug_const, zeros9]
+                    call("fourier_aug0", lib.kd_fourier_f32, _ptr(zeros9), _ptr(m.aug_emb.weight), _ptr(z_ff), 1, 9, mw // 2)
+                    gemm("aug_in_proj0", z_ff, m.aug_in_proj.weight, aug_const, 1, mw, mw)
+                    aug_term, aug_rows = aug_const, 0
+                map_term = None
+                if has_mapping_cond:
+                    map_term = torch.empty(rows, mw, **f32)
+                    ch.keep.append(map_term)
+                    gemm("mapping_cond_in_proj", ch.map_in, m.mapping_cond_in_proj.weight, map_term, rows, mw, m.mapping_cond_dim)
+                call("cond_sum", lib.kd_cond_sum_f32, _ptr(emb), _ptr(temb), _ptr(aug_term), aug_rows,
+                     _ptr(m.class_emb.weight) if has_class else None, _ptr(ch.class_ids) if has_class else None,
+                     None if map_term is None else _ptr(map_term), rows, mw)
+                call("mapping.in_norm", lib.kd_rmsnorm_f32, _ptr(emb), _ptr(m.mapping.in_norm.scale), _ptr(mres), rows, mw, C.c_float(1e-6))
+                for blk in m.mapping.blocks:
+                    gemm("mapping.up_proj", mres, blk.up_proj.weight, mh, rows, mdff, mw, epi=nat.EPI_GEGLU,
+                         scale_ptr=blk.norm.scale.data_ptr(), scale_stride=0, rows_per_sample=rows)
+                    gemm("mapping.down_proj", mh, blk.down_proj.weight, mres, rows, mw, mdff, epi=nat.EPI_RESIDUAL, R=mres)
+                call("mapping.out_norm", lib.kd_rmsnorm_f32, _ptr(mres), _ptr(m.mapping.out_norm.scale), _ptr(cond), rows, mw, C.c_float(1e-6))
+                ch.d_scales = gemm("ada_norm_scales", cond, wcat, None, rows, total, mw, out_add=1.0)
+            finally:
+                target, chain = saved, None
+            return ch
 
-        # ---- conditioning (image_transformer_v2.py:734-740, :569-581) ------------------------------
-        call("fourier_sigma", lib.kd_fourier_sigma_f32, _ptr(self.c_sigma), _ptr(m.time_emb.weight), _ptr(ff), B, mw // 2)
-        gemm("time_in_proj", ff, m.time_in_proj.weight, temb, B, mw, mw)
-        if has_aug:
-            aug_ff, aug_proj = torch.empty(B, mw, **f32), torch.empty(B, mw, **f32)
-            self.keep += [aug_ff, aug_proj]
-            call("fourier_aug", lib.kd_fourier_f32, _ptr(self.aug_in), _ptr(m.aug_emb.weight), _ptr(aug_ff), B, 9, mw // 2)
-            gemm("aug_in_proj", aug_ff, m.aug_in_proj.weight, aug_proj, B, mw, mw)
-            aug_term, aug_rows = aug_proj, 1
-        else:
-            # aug_cond = zeros  =>  FourierFeatures = [cos 0, sin 0] = [1..1, 0..0]: a constant vector
-            z_ff, aug_const = torch.empty(1, mw, **f32), torch.empty(1, mw, **f32)
-            self.keep += [z_ff, aug_const]
-            zeros9 = torch.zeros(1, 9, **f32)
-            self.keep.append(zeros9)
-            call("fourier_aug0", lib.kd_fourier_f32, _ptr(zeros9), _ptr(m.aug_emb.weight), _ptr(z_ff), 1, 9, mw // 2)
-            gemm("aug_in_proj0", z_ff, m.aug_in_proj.weight, aug_const, 1, mw, mw)
-            aug_term, aug_rows = aug_const, 0
-        map_term = None
-        if has_mapping_cond:
-            map_term = torch.empty(B, mw, **f32)
-            self.keep.append(map_term)
-            gemm("mapping_cond_in_proj", self.map_in, m.mapping_cond_in_proj.weight, map_term, B, mw, m.mapping_cond_dim)
-        call("cond_sum", lib.kd_cond_sum_f32, _ptr(emb), _ptr(temb), _ptr(aug_term), aug_rows,
-             _ptr(m.class_emb.weight) if has_class else None, _ptr(self.class_ids) if has_class else None,
-             None if map_term is None else _ptr(map_term), B, mw)
-        call("mapping.in_norm", lib.kd_rmsnorm_f32, _ptr(emb), _ptr(m.mapping.in_norm.scale), _ptr(mres), B, mw, C.c_float(1e-6))
-        for blk in m.mapping.blocks:
-            gemm("mapping.up_proj", mres, blk.up_proj.weight, mh, B, mdff, mw, epi=nat.EPI_GEGLU,
-                 scale_ptr=blk.norm.scale.data_ptr(), scale_stride=0, rows_per_sample=B)
-            gemm("mapping.down_proj", mh, blk.down_proj.weight, mres, B, mw, mdff, epi=nat.EPI_RESIDUAL, R=mres)
-        call("mapping.out_norm", lib.kd_rmsnorm_f32, _ptr(mres), _ptr(m.mapping.out_norm.scale), _ptr(cond), B, mw, C.c_float(1e-6))
-        self.d_scales = gemm("ada_norm_scales", cond, wcat, None, B, total, mw, out_add=1.0)
+        target = chain = None
+        self.build_cond = build_cond
+        self.scale_width = total
+        self.step_chain = build_cond(B)                     # the per-step chain (inline, or one step ahead on the side stream)
 
         # ---- hourglass ------------------------------------------------------------------------
         target = self.launches
@@ -370,19 +430,14 @@ class _Plan:
                                 rows_per_sample=grids[0][0] * grids[0][1], grid=grids[0], patch=(ph, pw, m.out_channels))
 
     def run_cond(self, buf, stream):
-        """Conditioning chain (FourierFeatures -> mapping network -> every AdaRMSNorm scale of the network) into scale
-        table ``buf`` on ``stream``; its inputs ``c_sigma`` / ``class_ids`` / ``aug_in`` / ``map_in`` were filled by the
-        caller on the same stream."""
-        self.d_scales.C = self.scales[buf].data_ptr()
-        for ln in self.cond_launches:
-            rc = ln.fn(*ln.args, stream)
-            if rc:
-                nat.check(rc, ln.what)
+        """Per-step conditioning chain into scale table ``buf`` on ``stream``; its inputs were filled by the caller on the
+        same stream (``step_chain.fill``)."""
+        self.step_chain.run(self.scales[buf].data_ptr(), stream)
 
-    def run(self, x, out, sigma_data, buf):
+    def run(self, x, out, sigma_data, base):
         """Main chain on the current stream.  x: input image (read by patch_in and, when preconditioning, by patch_out);
-        out: result image; ``self.sigma`` was filled by the caller; scale table ``buf`` holds this step's scales."""
-        base = self.scales[buf].data_ptr()
+        out: result image; ``self.sigma`` was filled by the caller; the [B, scale_width] table at ``base`` holds this
+        step's AdaRMSNorm scales."""
         for d, off in self.norm_descs:
             d.scale = base + off
         pin, pout = self.d_patch_in, self.d_patch_out
@@ -422,7 +477,7 @@ class _Plan:
             self.graphs, self.cond_graphs, self.graph_epoch = {}, {}, nat.option_epoch
             self.direct_runs = self.direct_cond_runs = 0          # another kernel family may see its first launch now
 
-    def replay(self, x, sigma_data, buf):
+    def replay(self, x, sigma_data, base):
         """``run`` through a captured graph.  Kernel arguments are frozen at capture, so the chain reads a fixed input image
         and writes a fixed output image (two small copies per forward at these sizes) and there is one graph per
         (scale table, preconditioning) combination.  The first forward of a plan is issued directly (one-time kernel
@@ -432,14 +487,14 @@ class _Plan:
             self.g_out = torch.empty(self.out_shape, device=x.device, dtype=torch.float32)
         self.g_x.copy_(x, non_blocking=True)
         self._graph_epoch()
-        key = (buf, None if sigma_data is None else float(sigma_data))
+        key = (base, None if sigma_data is None else float(sigma_data))
         g = self.graphs.get(key)
         if g is None and self.direct_runs == 0:
             self.direct_runs += 1
-            self.run(self.g_x, self.g_out, sigma_data, buf)
+            self.run(self.g_x, self.g_out, sigma_data, base)
         else:
             if g is None:
-                g = self.graphs[key] = self._capture(lambda: self.run(self.g_x, self.g_out, sigma_data, buf))
+                g = self.graphs[key] = self._capture(lambda: self.run(self.g_x, self.g_out, sigma_data, base))
             g.replay()
         return self.g_out.clone()
 
@@ -576,14 +631,54 @@ class ImageTransformerDenoiserModelV2(nn.Module):
             raise TypeError(f"fp32 inputs only (got {x.dtype})")
         x = x.contiguous()
         B, _, H, W = x.shape
+        plan = self._plan_for(x, aug_cond, class_cond, create=True)
+        cur = torch.cuda.current_stream()
+        graphed = plan.use_graph and not nat.prof_active and not torch.cuda.is_current_stream_capturing()
+        ident = self._cond_identity(sigma, aug_cond, class_cond, mapping_cond)
+        table = None
+        for sch in plan.schedules:                # this call's scales were computed with its whole sigma schedule
+            i = sch.row_of(sigma) if sch.ident_others == ident[1:] else None
+            if i is not None:
+                cur.wait_event(sch.done)
+                table = sch.tables[i].data_ptr()
+                break
+        if table is None:
+            pre, plan.prefetched = plan.prefetched, None
+            if pre is not None and pre[0] == ident:
+                buf = pre[1]                      # this step's scale table was computed ahead of time on the side stream
+                cur.wait_event(pre[2])
+            else:
+                buf = 1 - plan.last_buf
+                if pre is not None:
+                    cur.wait_event(pre[2])        # an unused prefetch still owns the conditioning workspace: order behind it
+                plan.step_chain.fill(sigma, aug_cond, class_cond, mapping_cond)
+                if graphed:
+                    plan.replay_cond(buf)
+                else:
+                    plan.run_cond(buf, C.c_void_p(cur.cuda_stream))
+            plan.last_buf = buf
+            table = plan.scales[buf].data_ptr()
+        plan.sigma.copy_(sigma.reshape(-1).expand(B) if sigma.numel() == 1 else sigma.reshape(B), non_blocking=True)
+        plan.main_entry.record(cur)               # everything before this step's main chain (incl. an inline conditioning chain)
+        if graphed:
+            return plan.replay(x, sigma_data, table)
+        out = torch.empty(B, self.out_channels, H, W, device=x.device, dtype=torch.float32)
+        plan.run(x, out, sigma_data, table)
+        return out
+
+    def _plan_for(self, x, aug_cond, class_cond, create):
+        """The launch plan of this (batch, size, conditioning kinds, device, arithmetic mode) combination."""
+        B, _, H, W = x.shape
         fp = self._weights_fingerprint()
         if fp != self._fingerprint:
+            if not create:
+                return None
             self._plans, self._fingerprint, self._packed = {}, fp, {}
         has_class = self.class_emb is not None
         key = (B, H, W, aug_cond is not None, has_class, self.mapping_cond_in_proj is not None, x.device, nat.default_precision(),
-               os.environ.get("KDIFF_QKV_PACKED", "1"), os.environ.get("KDIFF_GRAPH", "auto"))
+               os.environ.get("KDIFF_QKV_PACKED", "1"), os.environ.get("KDIFF_GRAPH", "0"))
         plan = self._plans.get(key)
-        if plan is None:
+        if plan is None and create:
             if self.patch_in.proj.weight.device != x.device:
                 raise RuntimeError(f"model weights are on {self.patch_in.proj.weight.device}, input on {x.device}")
             plan = self._plans[key] = _Plan(self, B, H, W, key[3], has_class, key[5], x.device)
@@ -594,65 +689,67 @@ class ImageTransformerDenoiserModelV2(nn.Module):
                 if lo < 0 or hi >= self.class_emb.weight.shape[0]:
                     del self._plans[key]
                     raise IndexError(f"class_cond ids must lie in [0, {self.class_emb.weight.shape[0] - 1}] (got {lo}..{hi})")
-        cur = torch.cuda.current_stream()
-        graphed = plan.use_graph and not nat.prof_active and not torch.cuda.is_current_stream_capturing()
-        ident = self._cond_identity(sigma, aug_cond, class_cond, mapping_cond)
-        pre, plan.prefetched = plan.prefetched, None
-        if pre is not None and pre[0] == ident:
-            buf = pre[1]                          # this step's scale table was computed ahead of time on the side stream
-            cur.wait_event(pre[2])
-        else:
-            buf = 1 - plan.last_buf
-            if pre is not None:
-                cur.wait_event(pre[2])            # an unused prefetch still owns the conditioning workspace: order behind it
-            self._fill_cond_inputs(plan, B, sigma, aug_cond, class_cond, mapping_cond)
-            if graphed:
-                plan.replay_cond(buf)
-            else:
-                plan.run_cond(buf, C.c_void_p(cur.cuda_stream))
-        plan.last_buf = buf
-        plan.sigma.copy_(sigma.reshape(-1).expand(B) if sigma.numel() == 1 else sigma.reshape(B), non_blocking=True)
-        plan.main_entry.record(cur)               # everything before this step's main chain (incl. an inline conditioning chain)
-        if graphed:
-            return plan.replay(x, sigma_data, buf)
-        out = torch.empty(B, self.out_channels, H, W, device=x.device, dtype=torch.float32)
-        plan.run(x, out, sigma_data, buf)
-        return out
+        return plan
 
     # ---- conditioning ahead of time ---------------------------------------------------------------
     def _cond_identity(self, sigma, aug_cond, class_cond, mapping_cond):
         return tuple(None if t is None else (t.data_ptr(), t._version, tuple(t.shape)) for t in (sigma, aug_cond, class_cond, mapping_cond))
 
-    def _fill_cond_inputs(self, plan, B, sigma, aug_cond, class_cond, mapping_cond):
-        plan.c_sigma.copy_(sigma.reshape(-1).expand(B) if sigma.numel() == 1 else sigma.reshape(B), non_blocking=True)
-        if self.class_emb is not None:
-            plan.class_ids.copy_(class_cond.reshape(B), non_blocking=True)
-        if plan.aug_in is not None:
-            plan.aug_in.copy_(aug_cond.reshape(B, 9), non_blocking=True)
-        if plan.map_in is not None:
-            plan.map_in.copy_(mapping_cond.reshape(B, self.mapping_cond_dim), non_blocking=True)
+    def _hint_usable(self, x_like, class_cond, mapping_cond):
+        if not x_like.is_cuda or x_like.dim() != 4:
+            return False
+        return not ((class_cond is None and self.class_emb is not None) or (mapping_cond is None and self.mapping_cond_in_proj is not None))
+
+    @torch.no_grad()
+    def prefetch_schedule(self, x_like, sigma_table, aug_cond=None, class_cond=None, mapping_cond=None):
+        """Hint from the solver loop: model calls of this run will pass ROWS of ``sigma_table`` ([n, B] fp32 on the device,
+        one row per call) as their sigma, together with exactly these other conditioning tensors.  The conditioning chain
+        depends on sigma / class / aug / mapping_cond only, never on x, so it runs here once for all n x B rows (the same
+        row-by-row kernels as the per-step chain: bit-identical scales) and every such call finds its [B, scale_width]
+        table ready.  Calls that pass anything else fall back to the per-step chain.  Returns True when taken."""
+        if not self._hint_usable(x_like, class_cond, mapping_cond) or sigma_table.dim() != 2 or not sigma_table.is_cuda:
+            return False
+        n, B = sigma_table.shape
+        if B != x_like.shape[0] or n == 0 or sigma_table.dtype != torch.float32 or not sigma_table.is_contiguous():
+            return False
+        plan = self._plan_for(x_like, aug_cond, class_cond, create=True)
+        if plan.use_graph or n * B * plan.scale_width * 4 > SCHEDULE_TABLE_MAX_BYTES:
+            return False                          # (a captured main chain is bound to the address of its scale table)
+        chain = plan.schedule_chains.get(n)
+        if chain is None:
+            chain = plan.schedule_chains[n] = plan.build_cond(n * B)
+        cur = torch.cuda.current_stream()
+        for sch in plan.schedules:                # an earlier schedule's chain of the same length shares the work buffers
+            cur.wait_event(sch.done)
+        tables = torch.empty(n, B, plan.scale_width, device=sigma_table.device, dtype=torch.float32)
+        chain.fill(sigma_table, aug_cond, class_cond, mapping_cond, repeat=n)
+        chain.run(tables.data_ptr(), C.c_void_p(cur.cuda_stream))
+        done = torch.cuda.Event()
+        done.record(cur)
+        others = (aug_cond, class_cond, mapping_cond)
+        plan.schedules.append(_Schedule(sigma_table, others, self._cond_identity(None, *others)[1:], tables, done))
+        del plan.schedules[:-SCHEDULES_KEPT]
+        return True
 
     @torch.no_grad()
     def prefetch_conditioning(self, x_like, sigma, aug_cond=None, class_cond=None, mapping_cond=None):
-        """Hint from the solver loop: the NEXT model call will use exactly these conditioning tensors.  The conditioning
-        chain (it depends on sigma / class / aug / mapping_cond only, never on x) then runs on a side HIP stream,
-        concurrently with the main chain of the step in flight, into the other scale table; the next ``forward`` with the
-        same tensors just waits for its event.  A hint that is not followed costs nothing but the side-stream work."""
-        if not x_like.is_cuda:
+        """Hint from the solver loop: the NEXT model call will use exactly these conditioning tensors.  Unless a schedule
+        hint already covers that call, the conditioning chain then runs on a side HIP stream, concurrently with the main
+        chain of the step in flight, into the other scale table; the next ``forward`` with the same tensors just waits for
+        its event.  A hint that is not followed costs nothing but the side-stream work."""
+        if not self._hint_usable(x_like, class_cond, mapping_cond):
             return
-        B, _, H, W = x_like.shape
-        key = (B, H, W, aug_cond is not None, self.class_emb is not None, self.mapping_cond_in_proj is not None, x_like.device,
-               nat.default_precision(), os.environ.get("KDIFF_QKV_PACKED", "1"), os.environ.get("KDIFF_GRAPH", "auto"))
-        plan = self._plans.get(key)
-        if plan is None or plan.prefetched is not None or self._weights_fingerprint() != self._fingerprint:
+        plan = self._plan_for(x_like, aug_cond, class_cond, create=False)
+        if plan is None or plan.prefetched is not None:
             return
-        if (class_cond is None and self.class_emb is not None) or (mapping_cond is None and self.mapping_cond_in_proj is not None):
+        others = self._cond_identity(None, aug_cond, class_cond, mapping_cond)[1:]
+        if any(sch.ident_others == others and sch.row_of(sigma) is not None for sch in plan.schedules):
             return
         buf = 1 - plan.last_buf
         side = plan.side_stream
         side.wait_event(plan.main_entry)          # table `buf` and the conditioning workspace are free once the main chain of
         with torch.cuda.stream(side):             # the step in flight has started (its predecessors are complete in stream order)
-            self._fill_cond_inputs(plan, B, sigma, aug_cond, class_cond, mapping_cond)
+            plan.step_chain.fill(sigma, aug_cond, class_cond, mapping_cond)
             if plan.use_graph and not nat.prof_active:
                 plan.replay_cond(buf)
             else:

@@ -79,12 +79,14 @@ def pack_weight(W, N, K, geglu, cache=True, bf16=False):
 
 def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scale=None, scale_stride=0,
          rows_per_sample=0, residual=None, grid=(0, 0), patch=(0, 0, 0), eps=1e-6, out_add=0.0,
-         sigma=None, sigma_data=1.0, fac=None, scale_ptr=None, precision=None, qk=None, qkv_packed=False):
+         sigma=None, sigma_data=1.0, fac=None, scale_ptr=None, precision=None, qk=None, qkv_packed=False, per_row=False):
     """Fused GEMM (see KdGemm in include/kdiff_hip.h).  ``norm_scale`` may be a tensor or, with
     ``scale_ptr``, a raw device address inside a larger scale table.  ``precision``: nat.PREC_EXACT /
     nat.PREC_SPLIT3 / nat.PREC_BF16 (default: KDIFF_GEMM env, split3).  In bf16 mode A, out and residual are bf16 tensors
-    (except the fp32 image side of the patch modes) and ``qk`` = (scale_h, rope_pos [T, 2], rope_freq [nh, 8], nh)."""
+    (except the fp32 image side of the patch modes) and ``qk`` = (scale_h, rope_pos [T, 2], rope_freq [nh, 8], nh).
+    ``per_row`` (fp32 modes): the per-row FMA kernel of the conditioning chain whatever M (KdGemm.per_row)."""
     d = nat.KdGemm()
+    d.per_row = 1 if per_row else 0
     d.precision = nat.default_precision() if precision is None else precision
     bf = d.precision == nat.PREC_BF16
     act = torch.bfloat16 if bf else torch.float32

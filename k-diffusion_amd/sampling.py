@@ -187,9 +187,16 @@ class _Loop:
         return len(self.sig) - 1
 
     def sigma_rows(self, values):
-        """[len(values), B] device table of per-sample sigma vectors (sigma * s_in)."""
+        """[len(values), B] device table of per-sample sigma vectors (sigma * s_in): row i is the sigma argument of one
+        model call of the run.  The model is told so (``prefetch_schedule``): the conditioning chain is a function of
+        sigma / class / ... only, so a model that takes the hint runs it once for the whole table instead of once per call."""
         v = torch.stack([torch.as_tensor(s, dtype=torch.float32).reshape(()) for s in values])
-        return v.to(self.x.device)[:, None].expand(len(values), self.B).contiguous()
+        table = v.to(self.x.device)[:, None].expand(len(values), self.B).contiguous()
+        if _COND_PREFETCH and len(values):
+            hint = getattr(self.model, 'prefetch_schedule', None)
+            if hint is not None:
+                hint(self.x, table, **self.extra)
+        return table
 
     def denoise(self, sigma_row, x=None, next_row=None):
         """model(x, sigma).  ``next_row``: the sigma vector of the NEXT model call, when the loop knows it: the

@@ -128,6 +128,39 @@ def test_qkv_epilogue_prepares_q_and_k(ops, gtol):
         ops.norm_linear(g(x), g(scale), g(w[: 2 * d]), rows_per_sample=H * W, epi=5, qk=(g(sh), g(cos), g(sin), nh))
 
 
+@pytest.mark.parametrize("mode", ["exact", "split3"])
+def test_per_row_products_do_not_depend_on_the_row_count(KD, ops, monkeypatch, mode):
+    """KdGemm.per_row: the conditioning products (one row per sample) go through the per-row fp32 FMA kernel whatever M, so
+    the conditioning of a whole sigma schedule (steps x batch rows in one launch) is bit-identical with computing it
+    32 rows at a time -- and agrees with fp64 to fp32 rounding."""
+    monkeypatch.setenv("KDIFF_GEMM", mode)
+    nat = KD._native
+    g = torch.Generator().manual_seed(5)
+    M, K = 1000, 256
+    A = torch.randn(M, K, generator=g).to(DEV)
+    scale = (1 + 0.1 * torch.randn(K, generator=g)).to(DEV)
+    for N, epi, norm in [(256, nat.EPI_STORE, False), (768, nat.EPI_GEGLU, True), (256, nat.EPI_RESIDUAL, False), (1792, nat.EPI_STORE, False)]:
+        W = (torch.randn((2 if epi == nat.EPI_GEGLU else 1) * N, K, generator=g) / K ** 0.5).to(DEV)
+        R = torch.randn(M, N, generator=g).to(DEV) if epi == nat.EPI_RESIDUAL else None
+        kw = dict(N=N, K=K, epi=epi, norm_scale=scale if norm else None, rows_per_sample=M if norm else 0, out_add=1.0 if epi == nat.EPI_STORE else 0.0)
+        whole = ops.gemm(A, W, torch.empty(M, N, device=DEV), M=M, residual=R, per_row=True, **kw)
+        parts = []
+        for m0 in range(0, M, 32):
+            m1 = min(M, m0 + 32)
+            kw["rows_per_sample"] = (m1 - m0) if norm else 0
+            parts.append(ops.gemm(A[m0:m1].contiguous(), W, torch.empty(m1 - m0, N, device=DEV), M=m1 - m0,
+                                  residual=None if R is None else R[m0:m1].contiguous(), **kw))
+        assert torch.equal(whole, torch.cat(parts)), (N, epi, norm)
+        a = A.double().cpu()
+        if norm:
+            a = a * scale.double().cpu() * torch.rsqrt(a.pow(2).mean(1, keepdim=True) + 1e-6)
+        y = a @ W.double().cpu().T
+        if epi == nat.EPI_GEGLU:
+            y = y[:, :N] * torch.nn.functional.gelu(y[:, N:])
+        y = y + (1.0 if epi == nat.EPI_STORE else 0.0) + (0 if R is None else R.double().cpu())
+        assert relerr(whole, y) < 1e-5
+
+
 @pytest.mark.parametrize("B,T,d_ff", [(8, 4096, 384), (5, 4096, 448), (1, 16500, 64), (2, 300, 128)])
 def test_bf16_fused_ffn(ops, B, T, d_ff):
     """kd_ffn_bf16 (the whole FeedForwardBlock, image_transformer_v2.py:487-493, hidden activation on-chip) against the fp32
