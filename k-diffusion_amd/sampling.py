@@ -24,6 +24,7 @@ from . import _native as nat
 from . import ops, utils
 
 _COND_PREFETCH = os.environ.get('KDIFF_COND_PREFETCH', '1') != '0'      # A/B switch (benchmarks/): side-stream conditioning
+_COND_SCHEDULE = os.environ.get('KDIFF_COND_SCHEDULE', '1') != '0'      # A/B switch: conditioning of the whole sigma table at once
 
 # --------------------------------------------------------------------------------- schedules
 
@@ -192,7 +193,7 @@ class _Loop:
         sigma / class / ... only, so a model that takes the hint runs it once for the whole table instead of once per call."""
         v = torch.stack([torch.as_tensor(s, dtype=torch.float32).reshape(()) for s in values])
         table = v.to(self.x.device)[:, None].expand(len(values), self.B).contiguous()
-        if _COND_PREFETCH and len(values):
+        if _COND_PREFETCH and _COND_SCHEDULE and len(values):
             hint = getattr(self.model, 'prefetch_schedule', None)
             if hint is not None:
                 hint(self.x, table, **self.extra)
