@@ -237,7 +237,8 @@ class _Plan:
         mw, mdff = m.mapping_spec.width, m.mapping_spec.d_ff
 
         # ---- static buffers -----------------------------------------------------------------
-        self.sigma = torch.empty(B, **f32)                  # read by the patch-in / patch-out preconditioning of the MAIN chain
+        self.sigma = torch.empty(B, **f32)                  # preconditioning sigmas of the MAIN chain when the caller's cannot be read in place
+        self.sigma_ptr = self.sigma.data_ptr()
         xs = [torch.empty(B, gh, gw, lv.width, **act) for (gh, gw), lv in zip(grids, levels)]
         toks = [B * gh * gw for gh, gw in grids]
         qkv = torch.empty(max(t * 3 * lv.width for t, lv in zip(toks, levels)), **act)
@@ -436,7 +437,7 @@ class _Plan:
 
     def run(self, x, out, sigma_data, base):
         """Main chain on the current stream.  x: input image (read by patch_in and, when preconditioning, by patch_out);
-        out: result image; ``self.sigma`` was filled by the caller; the [B, scale_width] table at ``base`` holds this
+        out: result image; ``self.sigma_ptr`` was set by the caller; the [B, scale_width] table at ``base`` holds this
         step's AdaRMSNorm scales."""
         for d, off in self.norm_descs:
             d.scale = base + off
@@ -446,7 +447,7 @@ class _Plan:
         if sigma_data is None:
             pin.sigma, pout.sigma, pout.R = None, None, None
         else:
-            sp = self.sigma.data_ptr()
+            sp = self.sigma_ptr
             pin.sigma, pout.sigma, pout.R = sp, sp, x.data_ptr()
             pin.sigma_data = pout.sigma_data = float(sigma_data)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -658,7 +659,12 @@ class ImageTransformerDenoiserModelV2(nn.Module):
                     plan.run_cond(buf, C.c_void_p(cur.cuda_stream))
             plan.last_buf = buf
             table = plan.scales[buf].data_ptr()
-        plan.sigma.copy_(sigma.reshape(-1).expand(B) if sigma.numel() == 1 else sigma.reshape(B), non_blocking=True)
+        if sigma_data is not None:                # per-sample sigma of the preconditioning folded into patch-in / patch-out
+            if graphed or sigma.numel() != B or sigma.dtype != torch.float32 or not sigma.is_contiguous() or sigma.device != x.device:
+                plan.sigma.copy_(sigma.reshape(-1).expand(B) if sigma.numel() == 1 else sigma.reshape(B), non_blocking=True)
+                plan.sigma_ptr = plan.sigma.data_ptr()
+            else:
+                plan.sigma_ptr = sigma.data_ptr()  # read in place: freed storage is not reused before this stream's work is done
         plan.main_entry.record(cur)               # everything before this step's main chain (incl. an inline conditioning chain)
         if graphed:
             return plan.replay(x, sigma_data, table)
