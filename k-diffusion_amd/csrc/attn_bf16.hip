@@ -30,6 +30,7 @@ struct DArgs {
   const u16* qkv; u16* out;
   int batch, T, nh;          // T = tokens per sample
   int H, W, ws, shift;       // window modes
+  int warm;                  // code warm-up workgroups (kd_common.h)
 };
 
 template <int MODE>
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(QW * 64, (QW <= 4 && MODE != MODE_WINDOW16) ? 2 : 1
   char* Kimg = smem;
   char* Vimg = smem + TP * 128;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h2 = lane >> 5;
+  const auto warm = code_warm_begin<(MODE == MODE_WINDOW16 ? 16 : 10) * 1024>((int)blockIdx.x < a.warm && tid < 64);
   constexpr int NQB = (NT + QW - 1) / QW;            // query blocks per problem
   int r = blockIdx.x;
   const int qblk = r % NQB; r /= NQB;
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(QW * 64, (QW <= 4 && MODE != MODE_WINDOW16) ? 2 : 1
     for (int st = 0; st < 4; ++st) qf[st] = __builtin_bit_cast(bf16x8, qp[2 * st]);
   }
   KD_WAIT_VM(0);
+  code_warm_end(warm);
   KD_BARRIER();
   if ((qblk * QW + wid) * 32 >= T) return;            // a wave without queries (no barrier follows)
 
@@ -231,6 +234,7 @@ constexpr int GL_IMG = GL_KB * 128, GL_BUF = 2 * GL_IMG, GL_LDS = 2 * GL_BUF;
 __global__ __launch_bounds__(GL_QW * 64) void attn_long_bf16_kernel(const DArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h2 = lane >> 5;
+  const auto warm = code_warm_begin<6144>((int)blockIdx.x < a.warm && tid < 64);
   const int T = a.T, nqb = (T + GL_QW * 32 - 1) / (GL_QW * 32);
   int r = blockIdx.x;
   const int qb = r % nqb; r /= nqb;
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(GL_QW * 64) void attn_long_bf16_kernel(const DArgs 
   const int ka = l31 * 128 + ((h2 ^ asw(l31)) << 4);
   const int va = vt_addr(4 * h2 + vt_lane_row(lane), lane);
   const int nkb = (T + GL_KB - 1) / GL_KB;
+  code_warm_end(warm);
   for (int kb = 0; kb < nkb; ++kb) {
     if (kb + 1 < nkb) { issue(kb + 1); KD_WAIT_VM(4); } else { KD_WAIT_VM(0); }
     KD_BARRIER();                                  // block kb is in for every wave
@@ -322,6 +327,7 @@ __global__ __launch_bounds__(GL_QW * 64) void attn_long_bf16_kernel(const DArgs 
 struct NArgs {
   const u16* qkv; u16* out;
   int batch, H, W, nh;
+  int warm;                  // code warm-up workgroups (kd_common.h)
 };
 constexpr int NA_TH = 8, NA_TW = 16;
 
@@ -345,6 +351,7 @@ __global__ __launch_bounds__(256, (NaGeo<KS>::LDS <= 80 * 1024) ? 2 : 1) void at
   char* Kimg = smem;
   char* Vimg = smem + ROWS * 128;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h2 = lane >> 5;
+  const auto warm = code_warm_begin<7168>((int)blockIdx.x < a.warm && tid < 64);
   const int wy_ = wid >> 1, wx_ = wid & 1;
   const int tiles_x = (a.W + NA_TW - 1) / NA_TW, tiles_y = (a.H + NA_TH - 1) / NA_TH;
   int r;
@@ -406,6 +413,7 @@ __global__ __launch_bounds__(256, (NaGeo<KS>::LDS <= 80 * 1024) ? 2 : 1) void at
     for (int p = 0; p < 2 * NKT; ++p) rowv[p] = ((unsigned)(p - r0) < (unsigned)KS) ? INFINITY : -INFINITY;
   }
   KD_WAIT_VM(0);
+  code_warm_end(warm);
   KD_BARRIER();
 
   // ---- S^T = K Q^T over the wave's key tiles: tile t, local key 32 t + i = patch row 2 t + (i >> 4), column i & 15 -------------
@@ -478,6 +486,7 @@ __global__ __launch_bounds__(256, 1) void attn_na2d_wide_bf16_kernel(const NArgs
   char* Kimg = smem;
   char* Vimg = smem + ROWS * 128;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h2 = lane >> 5;
+  const auto warm = code_warm_begin<24576>((int)blockIdx.x < a.warm && tid < 64);
   const int wy_ = wid >> 1, wx_ = wid & 1;
   const int tiles_x = (a.W + NA_TW - 1) / NA_TW, tiles_y = (a.H + NA_TH - 1) / NA_TH;
   int r = blockIdx.x;
@@ -513,6 +522,7 @@ __global__ __launch_bounds__(256, 1) void attn_na2d_wide_bf16_kernel(const NArgs
   const int r0 = wy - row_lo, c0 = wx - col_lo;
   auto img_row = [&](int kl) -> int { return korg + (kl / PC) * HC + (kl % PC); };     // LDS row of local key kl
   KD_WAIT_VM(0);
+  code_warm_end(warm);
   KD_BARRIER();
 
   f32x16 S[NKT];
@@ -616,7 +626,7 @@ using namespace kd::b16;
 
 extern "C" int kd_attn_global_bf16(const void* qkv, void* out, int batch, int T, int nh, void* stream) {
   if (!qkv || !out || batch <= 0 || nh <= 0 || T <= 0) return fail(KD_EINVAL, "kd_attn_global_bf16: bad arguments");
-  DArgs a{reinterpret_cast<const u16*>(qkv), reinterpret_cast<u16*>(out), batch, T, nh, 0, 0, 0, 0};
+  DArgs a{reinterpret_cast<const u16*>(qkv), reinterpret_cast<u16*>(out), batch, T, nh, 0, 0, 0, 0, option("code_warm", 64)};
   hipStream_t s = (hipStream_t)stream;
   const long nb = (long)batch * nh;
   if (T > 256) {
@@ -641,7 +651,7 @@ extern "C" int kd_attn_window_bf16(const void* qkv, void* out, int batch, int H,
   if (ws != 4 && ws != 8 && ws != 16) return fail(KD_EINVAL, "kd_attn_window_bf16: window_size %d unsupported (4, 8 or 16)", ws);
   if ((H % ws) || (W % ws)) return fail(KD_EINVAL, "kd_attn_window_bf16: grid %dx%d not divisible by the window", H, W);
   if (shift < 0 || shift >= ws) return fail(KD_EINVAL, "kd_attn_window_bf16: bad shift %d", shift);
-  DArgs a{reinterpret_cast<const u16*>(qkv), reinterpret_cast<u16*>(out), batch, H * W, nh, H, W, ws, shift};
+  DArgs a{reinterpret_cast<const u16*>(qkv), reinterpret_cast<u16*>(out), batch, H * W, nh, H, W, ws, shift, option("code_warm", 64)};
   const long nb = (long)batch * nh * (H / ws) * (W / ws);
   hipStream_t s = (hipStream_t)stream;
   if (ws == 8) return launch_dense<MODE_WINDOW, 2, 2>(a, nb, "attn_window_bf16", s);
@@ -653,7 +663,7 @@ extern "C" int kd_attn_na2d_bf16(const void* qkv, void* out, int batch, int H, i
   if (!qkv || !out || batch <= 0 || nh <= 0) return fail(KD_EINVAL, "kd_attn_na2d_bf16: bad arguments");
   if (ks < 3 || ks > 13 || !(ks & 1)) return fail(KD_EINVAL, "kd_attn_na2d_bf16: kernel_size %d unsupported (3, 5, 7, 9, 11 or 13)", ks);
   if (H < ks || W < ks) return fail(KD_EINVAL, "kd_attn_na2d_bf16: grid %dx%d smaller than the %dx%d neighbourhood", H, W, ks, ks);
-  NArgs a{reinterpret_cast<const u16*>(qkv), reinterpret_cast<u16*>(out), batch, H, W, nh};
+  NArgs a{reinterpret_cast<const u16*>(qkv), reinterpret_cast<u16*>(out), batch, H, W, nh, option("code_warm", 64)};
   hipStream_t s = (hipStream_t)stream;
   switch (ks) {
     case 3: return launch_na<3>(a, s);
@@ -664,3 +674,5 @@ extern "C" int kd_attn_na2d_bf16(const void* qkv, void* out, int batch, int H, i
     default: return launch_na_wide<13>(a, s);
   }
 }
+
+KD_TEXT_PAD(attn_bf16)      // last function of this code object: kd_common.h, code warm-up

@@ -26,6 +26,7 @@ struct FArgs {
   const float* scale; int scale_stride, rows_per_sample; float eps;
   int M, n_tiles;            // n_tiles = d_ff / 64
   unsigned long long* clk;   // kd_prof_clock_buffer: time line of workgroup 0
+  int warm;                  // code warm-up workgroups (kd_common.h)
 };
 
 #define KD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(FF_NW * 64) void ffn_kernel(const FArgs p) {
   static_assert(K % 128 == 0 && (UNIT / 1024) % FF_NW == 0, "unit = whole pieces per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const auto warm = code_warm_begin<(SKEW ? 12 : 9) * 1024>((int)blockIdx.x < p.warm && tid < 64);     // kd_common.h
   const int row = blockIdx.x * (FF_NW * 32) + wid * 32 + l31;
   const bool ok = row < p.M;
   const int rowc = ok ? row : p.M - 1;
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(FF_NW * 64) void ffn_kernel(const FArgs p) {
     rs = rsqrtf(ssq / (float)K + p.eps);
   }
   const float rsh = 0.5f * rs;
+  code_warm_end(warm);
   if (probe) p.clk[4] = __builtin_amdgcn_s_memtime();            // rows normalised
 
   int off4[4];
@@ -392,6 +395,7 @@ extern "C" int kd_ffn_bf16(const KdFfn* dp, void* stream) {
   a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample; a.eps = d.eps;
   a.M = d.M; a.n_tiles = d.d_ff / 64;
   a.clk = g_clk;
+  a.warm = option("code_warm", 64);
   if (d.K == 256) {
     constexpr int LDS256 = 9 * WBLK;
     static bool attr256 = false;
@@ -426,3 +430,5 @@ extern "C" int kd_ffn_bf16(const KdFfn* dp, void* stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)((d.M + panel - 1) / panel)), dim3(threads), LDS, s, a);
   return check_launch("kd_ffn_bf16");
 }
+
+KD_TEXT_PAD(ffn_bf16)      // last function of this code object: kd_common.h, code warm-up

@@ -25,6 +25,7 @@ struct GArgs {
   int tiles_per_slice, n_slices;
   int n_heads; const float* qk_scale; const float* pos; const float* freq;
   unsigned long long* clk;  // kd_prof_clock_buffer: {s_memtime, s_memrealtime} at entry and exit of workgroup 0 (shader clock under load)
+  int warm;                 // code warm-up workgroups (kd_common.h code_warm_begin; option "code_warm")
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
   static_assert(NC % 4 == 0, "K must be a multiple of 64");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const auto warm = code_warm_begin<((EPI == KD_EPI_QKV || EPI == KD_EPI_GEGLU) ? 8 : 4) * 1024>((int)blockIdx.x < p.warm && tid < 64);
   const int slice = blockIdx.x % p.n_slices, grp = blockIdx.x / p.n_slices, ngrp = gridDim.x / p.n_slices;
   const int nt0 = slice * p.tiles_per_slice;
   const int ntn = min(p.tiles_per_slice, p.n_tiles - nt0);
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
                                        (__attribute__((address_space(3))) void*)(smem + off), 16, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    code_warm_end(warm);
     __syncthreads();
   }
 
@@ -334,6 +337,7 @@ int gemm_wstat_try(const KdGemm& d, hipStream_t s, int* rc) {
   a.M = d.M; a.N = d.N; a.n_tiles = n_tiles; a.tiles_per_slice = tps; a.n_slices = n_slices;
   a.n_heads = d.n_heads; a.qk_scale = d.qk_scale; a.pos = d.rope_pos; a.freq = d.rope_freq;
   a.clk = g_clk;
+  a.warm = option("code_warm", 64);
   const int lds = tps * nk * WBLK;
   const double n_eff = geglu ? 2.0 * d.N : (double)d.N;
   const double flops = 2.0 * d.M * n_eff * d.K;
@@ -389,6 +393,7 @@ struct TArgs {
   const u16* A; const char* Wp; u16* C; const u16* R; const float* fac;
   int M, N, K, n_tiles_n, nk;
   int gh, gw, cin;
+  int warm;                 // code warm-up workgroups (kd_common.h)
 };
 
 #define KD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -415,6 +420,7 @@ __global__ __launch_bounds__(256 * BMT, (BMT == 1 && !DEEP) ? 2 : 1) void gemm_t
   constexpr int WPC = 16 / NWV;                      // weight pieces (1 KiB) per wave per step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const auto warm = code_warm_begin<(EPI == KD_EPI_SPLIT_LERP ? 6 : 4) * 1024>((int)blockIdx.x < p.warm && tid < 64);
   const int wc = wid & 1, wr = wid >> 1;
   int tile;
   {   // XCD-aware order, n fastest: the n-tiles of one row panel run back to back on ONE L2 (bijective for any grid)
@@ -539,6 +545,7 @@ __global__ __launch_bounds__(256 * BMT, (BMT == 1 && !DEEP) ? 2 : 1) void gemm_t
     }
   }
 
+  code_warm_end(warm);
   // ---- epilogue -------------------------------------------------------------------------------------------------------------------
   const float fac = EPI == KD_EPI_SPLIT_LERP ? *p.fac : 0.f;
 #pragma unroll
@@ -607,6 +614,7 @@ int gemm_tiled_try(const KdGemm& d, hipStream_t s, int* rc) {
   a.C = reinterpret_cast<u16*>(d.C); a.R = reinterpret_cast<const u16*>(d.R); a.fac = d.fac;
   a.M = d.M; a.N = d.N; a.K = d.K; a.n_tiles_n = (d.N + 127) / 128; a.nk = d.K / 64;
   a.gh = d.gh; a.gw = d.gw; a.cin = d.K >> 2;
+  a.warm = option("code_warm", 64);
   const double flops = 2.0 * d.M * (double)d.N * d.K;
   const double bytes = 2.0 * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N) + (d.epi != KD_EPI_STORE ? 2.0 * d.M * d.N : 0.0);
   char nm[96] = "gemm_tiled";
@@ -653,6 +661,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_astat_kernel(
   constexpr int NST = GEGLU ? 4 : 8;                 // 16-byte stores per lane per n-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const auto warm = code_warm_begin<(NC == 32 ? 26 : 16) * 1024>((int)blockIdx.x < p.warm && tid < 64);   // kd_common.h: this kernel's code -> L2
   // workgroup -> (row panel, n-split).  Workgroups go to the 8 XCDs round-robin by id: with the panel count a multiple of 8 the
   // splits of ONE panel are given ids 8 apart, i.e. they run on one XCD at about the same time and its L2 fetches the panel's rows
   // from HBM once instead of once per split (at level 2 the 8 splits otherwise read 67 MB for an 8 MB activation).
@@ -777,6 +786,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_astat_kernel(
     py = p.pos[2 * tok];
     px = p.pos[2 * tok + 1];
   }
+  code_warm_end(warm);
   KD_BARRIER();                                        // every wave has taken its rows out of the slot it borrowed
 #pragma unroll
   for (int s = 0; s < PDIST; ++s)
@@ -956,6 +966,7 @@ int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
   a.M = d.M; a.N = d.N; a.n_tiles = d.N / ncol;
   a.n_heads = d.n_heads; a.qk_scale = d.qk_scale; a.pos = d.rope_pos; a.freq = d.rope_freq;
   a.clk = g_clk;
+  a.warm = option("code_warm", 64);
   const double n_eff = geglu ? 2.0 * d.N : (double)d.N;
   const double flops = 2.0 * d.M * n_eff * d.K;
   const double bytes = 2.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N);
@@ -1327,3 +1338,5 @@ extern "C" int kd_gemm_bf16(const KdGemm* dp, void* stream) {
   if (!b16::gemm_generic_try(d, s, &rc)) return rc;
   return fail(KD_EINVAL, "kd_gemm_bf16: unsupported combination a_mode=%d norm=%d epi=%d M=%d N=%d K=%d", d.a_mode, d.norm, d.epi, d.M, d.N, d.K);
 }
+
+KD_TEXT_PAD(gemm_bf16)      // last function of this code object: kd_common.h, code warm-up

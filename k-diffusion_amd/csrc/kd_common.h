@@ -109,6 +109,49 @@ __device__ __forceinline__ f32x2 geglu_pair(f32x2 vh, f32x2 g) {
   return __builtin_elementwise_fma(vg, er, vg);
 }
 
+// ---- code warm-up ----------------------------------------------------------------------------------------------------------
+// A kernel that has not run for ~1 ms finds its code evicted from the L2s (4 MB per XCD; several GB of activations went through
+// since): the first launch of a forward then walks its code through one exposed instruction-cache miss after the other, ~1.2 us
+// per KiB of code on boxes whose memory-side cache does not hold it either (the first layer of every level: 25-32 us on a 37 us
+// launch of the 21-26 KiB A-stationary kernels, profiles/r02_level_entry.md).  gfx950 has no instruction prefetch, but
+// instruction misses are served by the L2: the first waves of a launch read the BYTES after the kernel's entry as DATA, all lines at
+// once, so that the instruction fetches behind them find the code in L2.  The values are only kept so that the loads stay ordered
+// with the kernel's own (code_warm_end after its first vmcnt wait).
+// Safety of the range: every code object of the library ends with kd_text_pad_kernel (KD_TEXT_PAD at the end of each .hip file),
+// KD_CODE_WARM_MAX + 4 KiB of s_nop behind the last real kernel, so [entry, entry + BYTES) never leaves the loaded image;
+// csrc/check_code_objects.py verifies that layout at build time (Makefile, __graft_entry__.build).
+constexpr int KD_CODE_WARM_MAX = 32768;
+template <int TAG>
+__global__ __attribute__((section(".kd_text_pad"))) void kd_text_pad_kernel() {            // its own section: the linker puts it
+  asm volatile(".fill 9216, 4, 0xbf800000");                                              // behind .text, in the same segment
+}                                                                                          // 36 KiB of s_nop; never launched
+#define KD_TEXT_PAD(tag) \
+  __attribute__((used)) static const void* const kd_text_pad_ref_##tag = reinterpret_cast<const void*>(&kd::kd_text_pad_kernel<0>);
+
+template <int BYTES> struct CodeWarm { int v[(BYTES + 4095) / 4096]; };
+template <int BYTES>
+__device__ __forceinline__ CodeWarm<BYTES> code_warm_begin(bool on) {
+  static_assert(BYTES % 64 == 0 && BYTES >= 64 && BYTES <= KD_CODE_WARM_MAX, "code warm-up range");
+  constexpr int N = (BYTES + 4095) / 4096;
+  CodeWarm<BYTES> w;
+#pragma unroll
+  for (int i = 0; i < N; ++i) w.v[i] = 0;
+  if (on) {
+    unsigned long long pc;
+    asm volatile("s_getpc_b64 %0" : "=s"(pc));
+    const char* base = reinterpret_cast<const char*>(pc & ~63ull);
+    const int lo = (threadIdx.x & 63) * 64;
+#pragma unroll
+    for (int i = 0; i < N; ++i) w.v[i] = *reinterpret_cast<const volatile int*>(base + min(i * 4096 + lo, BYTES - 64));
+  }
+  return w;
+}
+template <int BYTES>
+__device__ __forceinline__ void code_warm_end(const CodeWarm<BYTES>& w) {
+#pragma unroll
+  for (int i = 0; i < (BYTES + 4095) / 4096; ++i) asm volatile("" ::"v"(w.v[i]));
+}
+
 constexpr int KD_ROT = 16;       // rotary angles per head: dims [0,16) pair with [16,32)
 // ---- DPP helpers: cross-lane moves inside a 16-lane row as plain VALU ops (no LDS round trip like ds_bpermute) ----
 template <int CTRL>

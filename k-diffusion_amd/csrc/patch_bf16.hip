@@ -28,6 +28,7 @@ struct PArgs {
   int M, N, K;
   int gh, gw, ph, chan;
   const float* sigma; float sigma_data;
+  int warm;                  // code warm-up workgroups (kd_common.h)
 };
 
 __device__ __forceinline__ void glds16p(const void* src, void* dst) {
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(PNW * 64) void unpatch4_kernel(const PArgs p) {
   constexpr int K = NC * 16, NK = NC / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const auto warm = code_warm_begin<8192>((int)blockIdx.x < p.warm && tid < 64);                  // kd_common.h
   for (int off = wid * 1024; off < NK * WBLK; off += PNW * 1024) glds16p(p.Wp + off + lane * 16, smem + off);
   const int G = p.N >> 2;                     // runs of 4 pixels per token
   // LDS row this lane reads as MFMA row l31 of block j: the feature of tile row rho = 32 j + l31 -> run rho >> 2, pixel rho & 3
@@ -55,6 +57,7 @@ __global__ __launch_bounds__(PNW * 64) void unpatch4_kernel(const PArgs p) {
     for (int cc = 0; cc < 4; ++cc) off4[j][cc] = swz128(n, 2 * cc + lh);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  code_warm_end(warm);
   __syncthreads();
 
   const int chunks = (p.M + 31) >> 5;
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(PNW * 64) void unpatch4_kernel(const PArgs p) {
 __global__ __launch_bounds__(PNW * 64) void patchin4_kernel(const PArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const auto warm = code_warm_begin<6144>((int)blockIdx.x < p.warm && tid < 64);                  // kd_common.h
   const int n_tiles = p.N >> 7, G = p.K >> 2, nch = (G + 3) >> 2;
   // weight images with the k order of the fragments: 16-byte chunk q of row n = runs 2q, 2q + 1 (4 pixels each)
   for (int idx = tid; idx < n_tiles * 1024; idx += PNW * 64) {
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(PNW * 64) void patchin4_kernel(const PArgs p) {
     }
     *reinterpret_cast<u32x4*>(smem + t * WBLK + swz128(n, q)) = u32x4{pk[0], pk[1], pk[2], pk[3]};
   }
+  code_warm_end(warm);
   __syncthreads();
   int off4[4];
 #pragma unroll
@@ -262,6 +267,7 @@ int gemm_patch_try(const KdGemm& d, hipStream_t s, int* rc) {
   const int feat = 4 * d.ph * d.chan;
   PArgs a{};
   a.Wp = reinterpret_cast<const char*>(d.Wp);
+  a.warm = option("code_warm", 64);
   a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample > 0 ? d.rows_per_sample : d.M; a.eps = d.eps;
   a.M = d.M; a.N = d.N; a.K = d.K; a.gh = d.gh; a.gw = d.gw; a.ph = d.ph; a.chan = d.chan;
   a.sigma = d.sigma; a.sigma_data = d.sigma_data;
@@ -289,3 +295,5 @@ int gemm_patch_try(const KdGemm& d, hipStream_t s, int* rc) {
 
 }  // namespace b16
 }  // namespace kd
+
+KD_TEXT_PAD(patch_bf16)      // last function of this code object: kd_common.h, code warm-up
