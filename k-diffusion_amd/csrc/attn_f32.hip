@@ -60,6 +60,7 @@ struct DenseArgs {
   int batch, T, nh;          // T = tokens per sample
   int H, W, ws, shift;       // window mode
   float eps;
+  int warm;                  // code warm-up workgroups (kd_common.h)
 };
 
 // slot -> token index inside the sample (or -1), for the problem owned by this block
@@ -82,6 +83,7 @@ __device__ __forceinline__ int slot_region(int slot, int wi, int wj, int shift) 
 template <int MODE, int MAXT, bool PREP>
 __global__ __launch_bounds__(MAXT * 64) void attn_dense_kernel(const DenseArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const auto warm = code_warm_begin<16384>((int)blockIdx.x < a.warm && blockIdx.y == 0 && threadIdx.x < 64);   // kd_common.h: this kernel's code -> L2
   constexpr int TP = MAXT * 32;
   float* Ks = smem;                 // [TP][LDS_ROW]
   float* Vs = smem + TP * LDS_ROW;  // [TP][LDS_ROW]
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(MAXT * 64) void attn_dense_kernel(const DenseArgs a
       q[c + 2] = x2 * cc + x1 * sc;
     }
   }
+  code_warm_end(warm);
   __syncthreads();
   if (!wave_active) return;
 
@@ -268,6 +271,7 @@ struct NaArgs {
   const float* scale_h; const float* cos_t; const float* sin_t;
   int batch, H, W, nh;
   float eps;
+  int warm;                  // code warm-up workgroups (kd_common.h)
 };
 
 constexpr int NA_K = 7, NA_TH = 8, NA_TW = 16;
@@ -323,6 +327,7 @@ template <int PMODE, bool FULL>      // PMODE 0: q, k prepared (fp32)  1: raw fp
 __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
   constexpr bool PREP = PMODE == 1, PK = PMODE == 2;
   extern __shared__ __attribute__((aligned(16))) char na_smem[];
+  const auto warm = code_warm_begin<32768>((int)blockIdx.x < a.warm && blockIdx.y == 0 && threadIdx.x < 64);   // kd_common.h: this kernel's code -> L2
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h2 = lane >> 5;
   const int wy_ = wid >> 1, wx_ = wid & 1;                            // this wave's 4x8 query block
@@ -456,6 +461,7 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_kernel(const NaArgs a) {
   const int row_lo = min(clampi(min(ty0 + 4 * wy_, a.H - 1) - NA_K / 2, 0, a.H - NA_K) - hy0, NA_HR - 10);
   const int col_lo = min(clampi(min(tx0 + 8 * wx_, a.W - 1) - NA_K / 2, 0, a.W - NA_K) - hx0, NA_HC - 14) & ~1;
   const int korg = row_lo * NA_HC + col_lo;      // halo index of the patch's key (0, 0); local key 16r + c is korg + 22r + c
+  code_warm_end(warm);
   __syncthreads();
 
   // ---- S^T = K Q^T over the wave's 5 key tiles ----------------------------------------------------------------------
@@ -665,6 +671,7 @@ template <int MODE, int NT, int PMODE>
 __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseArgs a) {
   constexpr bool PREP = PMODE == 1, PK = PMODE == 2;
   extern __shared__ __attribute__((aligned(16))) char gs_smem[];
+  const auto warm = code_warm_begin<32768>((int)blockIdx.x < a.warm && blockIdx.y == 0 && threadIdx.x < 64);   // kd_common.h: this kernel's code -> L2
   constexpr int TP = NT * 32, NTHR = NT * 64;
   constexpr int VSTR = TP * 2 + 4;                       // bytes per e-row of V^T: odd dword count -> conflict-free dword-pair reads
   constexpr int IMG_K = TP * 128, IMG_V = DH * VSTR;
@@ -765,6 +772,7 @@ __global__ __launch_bounds__(NT * 64) void attn_global_split_kernel(const DenseA
     qh[st] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
     ql[st] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
   }
+  code_warm_end(warm);
   __syncthreads();
 
   // ---- S^T = K Q^T over all NT key tiles (step-major, term-major issue order) ------------------------------------------------------
@@ -920,6 +928,7 @@ template <int PMODE>
 __global__ __launch_bounds__(GL_THR) void attn_global_long_kernel(const DenseArgs a) {
   constexpr bool PREP = PMODE == 1, PK = PMODE == 2;
   extern __shared__ __attribute__((aligned(16))) char gl_smem[];
+  (void)code_warm_begin<32768>((int)blockIdx.x < a.warm && blockIdx.y == 0 && threadIdx.x < 64);   // kd_common.h: this kernel's code -> L2
   char* Khi = gl_smem;
   char* Klo = gl_smem + GL_IMG_K;
   char* Vhi = gl_smem + 2 * GL_IMG_K;
@@ -1231,7 +1240,7 @@ extern "C" int kd_attn_global_f32(const float* qkv, float* out, int batch, int T
                                   const float* cos_t, const float* sin_t, float eps, int precision, void* stream) {
   if (!qkv || !out || batch <= 0 || nh <= 0 || T <= 0) return fail(KD_EINVAL, "kd_attn_global_f32: bad arguments");
   if (int e = check_prep(prep, scale_h, cos_t, sin_t, "kd_attn_global_f32")) return e;
-  DenseArgs a{qkv, out, scale_h, cos_t, sin_t, batch, T, nh, 0, 0, 0, 0, eps};
+  DenseArgs a{qkv, out, scale_h, cos_t, sin_t, batch, T, nh, 0, 0, 0, 0, eps, option("code_warm", 64)};
   const long nb = (long)batch * nh;
   hipStream_t s = (hipStream_t)stream;
   if (precision != KD_PREC_EXACT && precision != KD_PREC_SPLIT3) return fail(KD_EINVAL, "kd_attn_global_f32: precision must be KD_PREC_EXACT or KD_PREC_SPLIT3");
@@ -1258,7 +1267,7 @@ extern "C" int kd_attn_window_f32(const float* qkv, float* out, int batch, int H
   if ((H % ws) || (W % ws)) return fail(KD_EINVAL, "kd_attn_window_f32: grid %dx%d not divisible by the window", H, W);
   if (shift < 0 || shift >= ws) return fail(KD_EINVAL, "kd_attn_window_f32: bad shift %d", shift);
   if (int e = check_prep(prep, scale_h, cos_t, sin_t, "kd_attn_window_f32")) return e;
-  DenseArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H * W, nh, H, W, ws, shift, eps};
+  DenseArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H * W, nh, H, W, ws, shift, eps, option("code_warm", 64)};
   const long nb = (long)batch * nh * (H / ws) * (W / ws);
   if (precision != KD_PREC_EXACT && precision != KD_PREC_SPLIT3) return fail(KD_EINVAL, "kd_attn_window_f32: precision must be KD_PREC_EXACT or KD_PREC_SPLIT3");
   hipStream_t s = (hipStream_t)stream;
@@ -1280,7 +1289,7 @@ extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, 
   if (ks != NA_K) return fail(KD_EINVAL, "kd_attn_na2d_f32: kernel_size %d unsupported (only 7)", ks);
   if (H < ks || W < ks) return fail(KD_EINVAL, "kd_attn_na2d_f32: grid %dx%d smaller than the %dx%d neighbourhood", H, W, ks, ks);
   if (int e = check_prep(prep, scale_h, cos_t, sin_t, "kd_attn_na2d_f32")) return e;
-  NaArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H, W, nh, eps};
+  NaArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H, W, nh, eps, option("code_warm", 64)};
   const long nb = (long)batch * nh * ((H + NA_TH - 1) / NA_TH) * ((W + NA_TW - 1) / NA_TW);
   hipStream_t s = (hipStream_t)stream;
   char nm[64] = "attn_na2d";
@@ -1303,3 +1312,5 @@ extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, 
 #undef KD_NA
   return check_launch("kd_attn_na2d_f32");
 }
+
+KD_TEXT_PAD(attn_f32)      // last function of this code object: kd_common.h, code warm-up

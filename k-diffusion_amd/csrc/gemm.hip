@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_kernel(const G
   constexpr bool SPLIT = PREC == KD_PREC_SPLIT3;
   static_assert(KS == 1 || (SPLIT && !NORM && AMODE == KD_A_PLAIN), "K split: split3, plain A, no norm prologue");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const auto warm = code_warm_begin<32768>((int)blockIdx.x < p.warm && blockIdx.y == 0 && threadIdx.x < 64);   // kd_common.h: this kernel's code -> L2
   const int grp = KS == 1 ? 0 : (int)(threadIdx.x >> 8);
   float* As = smem;                       // exact mode
   float* Bs = smem + 2 * BM * S;
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void gemm_kernel(const G
     for (int k = tid * 4; k < K; k += 1024) *reinterpret_cast<f32x4*>(sc_tab + k) = *reinterpret_cast<const f32x4*>(src + k);
     __syncthreads();
   }
+  code_warm_end(warm);
 
   const int frag_off = (lane & 31) * S + 4 * (lane >> 5);
   const int l31 = lane & 31, lh = lane >> 5;
@@ -616,6 +618,7 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
   GemmP e;
   static_cast<KdGemm&>(e) = d;
   e.debug = option("gemm_debug", 0);
+  e.warm = option("code_warm", 64);
   if (e.rows_per_sample <= 0) e.rows_per_sample = e.M;
   // all rows of a 128-row tile share their scale vector: stage it in LDS once per tile
   e.scale_tab = e.norm && e.a_mode == KD_A_PLAIN && e.K <= SCALE_TAB_MAX_K && (e.scale_stride == 0 || e.rows_per_sample % BM == 0);
@@ -676,3 +679,5 @@ extern "C" int kd_pack_weight_bf16x3(const float* W, void* out, int N, int K, in
                      reinterpret_cast<char*>(out), N, K, geglu, n_tiles, nk);
   return check_launch("kd_pack_weight_bf16x3");
 }
+
+KD_TEXT_PAD(gemm)      // last function of this code object: kd_common.h, code warm-up

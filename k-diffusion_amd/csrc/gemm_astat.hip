@@ -68,6 +68,7 @@ __global__ __launch_bounds__(64 * NWV, (NC <= 8 && NWV == 4) ? 2 : 1) void gemm_
   constexpr int NCOL = GEGLU ? 64 : 128;                  // output columns per n-tile
   static_assert(NK % NSTG == 0, "ring slot of a stage must be a compile-time constant");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  (void)code_warm_begin<32768>((int)blockIdx.x < p.warm && blockIdx.y == 0 && threadIdx.x < 64);   // kd_common.h: this kernel's code -> L2
   char* ring = smem;
   float* strips = reinterpret_cast<float*>(smem + LDS_RING);
   float* rs_tab = strips + NWV * 8 * 64;
@@ -325,3 +326,5 @@ int gemm_astat_try(const GemmP& d, hipStream_t s, int* rc) {
 }
 
 }  // namespace kd
+
+KD_TEXT_PAD(gemm_astat)      // last function of this code object: kd_common.h, code warm-up

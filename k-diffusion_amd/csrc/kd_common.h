@@ -18,6 +18,7 @@ constexpr int WAVE = 64;
 
 // the public descriptor plus what only the library sets (kept out of the ABI)
 struct GemmP : KdGemm {
+  int warm;         // code warm-up workgroups (code_warm_begin below; option "code_warm")
   int debug;        // benchmarks/ only (kd_set_option("gemm_debug")): 1 no C stores, 2 no MFMA, 8 GEGLU without erf, 32 conservative store wait
   int scale_tab;    // norm scales of a tile's sample staged in LDS
 };
