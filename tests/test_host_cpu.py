@@ -33,6 +33,23 @@ def test_library_exports_every_declared_symbol(KD):
     assert lib.kd_version() >= 100
 
 
+def test_code_objects_end_with_the_text_pad():
+    """Kernels that warm their own code read up to 32 KiB behind their entry point: every such code object must end with the
+    36 KiB .kd_text_pad section right behind .text (csrc/check_code_objects.py, also run by every build)."""
+    import subprocess
+    import sys
+    csrc = os.path.join(REPO, "k-diffusion_amd", "csrc")
+    objs = [os.path.join(csrc, f) for f in ("gemm_bf16.o", "patch_bf16.o", "ffn_bf16.o", "attn_bf16.o", "gemm.o", "gemm_astat.o", "attn_f32.o")]
+    if not all(os.path.exists(o) for o in objs):
+        pytest.skip("object files not in the tree (library built elsewhere)")
+    out = subprocess.run([sys.executable, os.path.join(csrc, "check_code_objects.py"), *objs], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count(": ok") == len(objs)
+    # a code object without the pad is refused
+    bad = subprocess.run([sys.executable, os.path.join(csrc, "check_code_objects.py"), os.path.join(csrc, "elementwise.o")], capture_output=True, text=True)
+    assert bad.returncode != 0 and "kd_text_pad" in (bad.stdout + bad.stderr)
+
+
 def test_bad_arguments_are_rejected_without_a_gpu(KD):
     """Argument validation happens before any launch: error code + message, never a throw."""
     lib = KD._native.lib()
