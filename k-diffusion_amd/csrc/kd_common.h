@@ -115,7 +115,8 @@ __device__ __forceinline__ f32x2 geglu_pair(f32x2 vh, f32x2 g) {
 // since): the first launch of a forward then walks its code through one exposed instruction-cache miss after the other, ~1.2 us
 // per KiB of code on boxes whose memory-side cache does not hold it either (the first layer of every level: 25-32 us on a 37 us
 // launch of the 21-26 KiB A-stationary kernels, profiles/r02_level_entry.md).  gfx950 has no instruction prefetch, but
-// instruction misses are served by the L2: the first waves of a launch read the BYTES after the kernel's entry as DATA, all lines at
+// instruction misses are served by the L2: the first wave of the first 8 workgroups of a launch (one per XCD: workgroups go to the
+// XCDs round-robin; 8 measured better than 64, 512 or all) reads the BYTES after the kernel's entry as DATA, all lines at
 // once, so that the instruction fetches behind them find the code in L2.  The values are only kept so that the loads stay ordered
 // with the kernel's own (code_warm_end after its first vmcnt wait).
 // Safety of the range: every code object of the library ends with kd_text_pad_kernel (KD_TEXT_PAD at the end of each .hip file),
