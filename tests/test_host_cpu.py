@@ -33,6 +33,25 @@ def test_library_exports_every_declared_symbol(KD):
     assert lib.kd_version() >= 100
 
 
+def test_schedule_rows_are_recognised_by_storage_and_version(KD):
+    """prefetch_schedule bookkeeping (host logic, no GPU): a model call is served from a schedule's scale table only when its sigma
+    argument IS a row of the hinted table -- same storage, same version counter, whole contiguous fp32 row."""
+    from importlib import import_module
+    mod = import_module(KD.__name__ + ".models.image_transformer_v2")
+    table = torch.linspace(80.0, 0.1, 6)[:, None].expand(6, 4).contiguous()
+    sch = mod._Schedule(table, (None, None, None), (None, None, None), torch.zeros(6, 4, 8), None)
+    assert [sch.row_of(table[i]) for i in range(6)] == list(range(6))
+    assert sch.row_of(table[2].clone()) is None                       # same values, other storage
+    assert sch.row_of(table[1, 1:]) is None and sch.row_of(table[:, 0]) is None and sch.row_of(table.view(-1)[2:6]) is None
+    assert sch.row_of(table[3].double()) is None and sch.row_of(table[0:2]) is None
+    other = torch.empty(7, 4)
+    assert sch.row_of(other[0]) is None
+    table[4] *= 0.5                                                   # in place: every row of the record is stale now
+    assert all(sch.row_of(table[i]) is None for i in range(6))
+    # the record keeps the hinted tensors alive (their addresses cannot be recycled while it exists)
+    assert sch.keep[0] is table
+
+
 def test_code_objects_end_with_the_text_pad():
     """Kernels that warm their own code read up to 32 KiB behind their entry point: every such code object must end with the
     36 KiB .kd_text_pad section right behind .text (csrc/check_code_objects.py, also run by every build)."""
