@@ -52,6 +52,30 @@ def test_schedule_rows_are_recognised_by_storage_and_version(KD):
     assert sch.keep[0] is table
 
 
+def test_every_option_name_used_in_the_sources_is_registered():
+    """kd_set_option refuses unknown names; every name the kernels' dispatch code reads (option("name", default)) and every name
+    the Python layer maps an environment variable to must therefore be in the library's table (checked in a child process: a set
+    option overrides the call sites' defaults for the rest of the process)."""
+    csrc = os.path.join(REPO, "k-diffusion_amd", "csrc")
+    names = set()
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".cpp", ".h")):
+            names |= set(re.findall(r'option\("([a-z0-9_]+)"', open(os.path.join(csrc, fn)).read()))
+    names.discard("name")                      # the usage example in kd_common.h
+    assert {"code_warm", "patch_fast", "ffn_fused", "wstat", "astat"} <= names
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import k_diffusion_amd as K\n"
+        "lib = K._native.lib()\n"
+        "names = %r + [v[0] for v in K._native._ENV_OPTIONS.values()]\n"
+        "bad = [n for n in names if lib.kd_set_option(n.encode(), 1) != 0]\n"
+        "assert not bad, bad\n"
+        "assert lib.kd_set_option(b'no_such_option', 1) == -1\n"
+    ) % (REPO, sorted(names))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+
 def test_code_objects_end_with_the_text_pad():
     """Kernels that warm their own code read up to 32 KiB behind their entry point: every such code object must end with the
     36 KiB .kd_text_pad section right behind .text (csrc/check_code_objects.py, also run by every build)."""
