@@ -42,6 +42,7 @@ const char* kd_last_error(void);
  *                  "code_warm" (8: the first wave of that many workgroups of a launch -- one per XCD -- reads the kernel's own code
  *                  range into L2 at entry, so that a kernel that has not run for a while does not walk its code through one
  *                  instruction-cache miss after the other; 0 = off.  Pure prefetch: results do not depend on it) */
+/* value == INT_MIN puts the option back to its built-in default. */
 int kd_set_option(const char* name, int value);
 int kd_get_option(const char* name, int dflt);
 

@@ -142,24 +142,45 @@ def lib():
 _ENV_OPTIONS = {"KDIFF_SKINNY": ("skinny", 1), "KDIFF_ASTAT": ("astat", 1), "KDIFF_KSPLIT": ("ksplit", 1), "KDIFF_ASTAT_MAXK": ("astat_max_k", 512),
                 "KDIFF_ASTAT_WAVES": ("astat_waves", 4), "KDIFF_ASTAT_STOREWAIT": ("astat_storewait", 0), "KD_GEMM_DEBUG": ("gemm_debug", 0),
                 "KDIFF_BF16_FAST": ("bf16_fast", 1)}
-_env_applied = None
+_env_applied = None       # (value of every mapped variable, {name: value} parsed from KDIFF_OPTIONS) as last applied
+_programmatic = set()     # option names set through set_option(): the environment sync leaves them alone
 option_epoch = 0          # bumped whenever a library option may have changed: captured launch graphs are bound to one epoch
 
 
+def _parse_options(text):
+    out = {}
+    for item in (text or "").split(","):
+        if item.strip():
+            name, _, val = item.partition("=")
+            out[name.strip()] = int(val)
+    return out
+
+
 def _sync_options(handle):
-    """KDIFF_* variables -> kd_set_option; KDIFF_OPTIONS="name=value,..." sets any library option by name (A-B runs of bench.py)."""
+    """KDIFF_* variables -> kd_set_option; KDIFF_OPTIONS="name=value,..." sets any library option by name (A-B runs of bench.py).
+    Only what CHANGED since the last call is re-applied: a variable that changed, a KDIFF_OPTIONS entry that changed or appeared,
+    and -- reset to the library default -- an entry that disappeared.  Options set through ``set_option`` are not touched unless
+    the environment names them anew."""
     global _env_applied, option_epoch
-    cur = tuple(os.environ.get(k) for k in _ENV_OPTIONS) + (os.environ.get("KDIFF_OPTIONS"),)
-    if cur != _env_applied:
-        for (env, (name, dflt)), val in zip(_ENV_OPTIONS.items(), cur):
-            handle.kd_set_option(name.encode(), dflt if val is None or val == "" else int(val))
-        for item in (cur[-1] or "").split(","):
-            if item.strip():
-                name, _, val = item.partition("=")
-                if handle.kd_set_option(name.strip().encode(), int(val)) != 0:
-                    raise ValueError(f"KDIFF_OPTIONS: unknown library option {name.strip()!r}")
-        _env_applied = cur
-        option_epoch += 1
+    raw = tuple(os.environ.get(k) for k in _ENV_OPTIONS) + (os.environ.get("KDIFF_OPTIONS"),)
+    if _env_applied is not None and raw == _env_applied[0]:
+        return
+    named = _parse_options(raw[-1])
+    old_raw, old_named = _env_applied[1:] if _env_applied is not None else ((None,) * len(_ENV_OPTIONS), {})
+    for (env, (name, dflt)), val, was in zip(_ENV_OPTIONS.items(), raw, old_raw):
+        if val != was and (val not in (None, "") or was not in (None, "")) and (name not in _programmatic or val not in (None, "")):
+            handle.kd_set_option(name.encode(), dflt if val in (None, "") else int(val))
+            _programmatic.discard(name)
+    for name, val in named.items():
+        if old_named.get(name) != val:
+            if handle.kd_set_option(name.encode(), val) != 0:
+                raise ValueError(f"KDIFF_OPTIONS: unknown library option {name!r}")
+            _programmatic.discard(name)
+    for name in old_named:
+        if name not in named and name not in _programmatic:
+            handle.kd_set_option(name.encode(), -0x7FFFFFFF - 1)           # INT_MIN: back to the built-in default (kd_set_option)
+    _env_applied = (raw, raw[:-1], named)
+    option_epoch += 1
 
 
 prof_active = False
@@ -177,6 +198,7 @@ def set_option(name, value):
     """Tuning / A-B switch of the library (include/kdiff_hip.h: kd_set_option)."""
     global option_epoch
     check(lib().kd_set_option(name.encode(), int(value)), "kd_set_option")
+    _programmatic.add(name)
     option_epoch += 1
 
 

@@ -626,7 +626,7 @@ using namespace kd::b16;
 
 extern "C" int kd_attn_global_bf16(const void* qkv, void* out, int batch, int T, int nh, void* stream) {
   if (!qkv || !out || batch <= 0 || nh <= 0 || T <= 0) return fail(KD_EINVAL, "kd_attn_global_bf16: bad arguments");
-  DArgs a{reinterpret_cast<const u16*>(qkv), reinterpret_cast<u16*>(out), batch, T, nh, 0, 0, 0, 0, option("code_warm", 8)};
+  DArgs a{reinterpret_cast<const u16*>(qkv), reinterpret_cast<u16*>(out), batch, T, nh, 0, 0, 0, 0, option("code_warm", KD_CODE_WARM_DEFAULT)};
   hipStream_t s = (hipStream_t)stream;
   const long nb = (long)batch * nh;
   if (T > 256) {
@@ -651,7 +651,7 @@ extern "C" int kd_attn_window_bf16(const void* qkv, void* out, int batch, int H,
   if (ws != 4 && ws != 8 && ws != 16) return fail(KD_EINVAL, "kd_attn_window_bf16: window_size %d unsupported (4, 8 or 16)", ws);
   if ((H % ws) || (W % ws)) return fail(KD_EINVAL, "kd_attn_window_bf16: grid %dx%d not divisible by the window", H, W);
   if (shift < 0 || shift >= ws) return fail(KD_EINVAL, "kd_attn_window_bf16: bad shift %d", shift);
-  DArgs a{reinterpret_cast<const u16*>(qkv), reinterpret_cast<u16*>(out), batch, H * W, nh, H, W, ws, shift, option("code_warm", 8)};
+  DArgs a{reinterpret_cast<const u16*>(qkv), reinterpret_cast<u16*>(out), batch, H * W, nh, H, W, ws, shift, option("code_warm", KD_CODE_WARM_DEFAULT)};
   const long nb = (long)batch * nh * (H / ws) * (W / ws);
   hipStream_t s = (hipStream_t)stream;
   if (ws == 8) return launch_dense<MODE_WINDOW, 2, 2>(a, nb, "attn_window_bf16", s);
@@ -663,7 +663,7 @@ extern "C" int kd_attn_na2d_bf16(const void* qkv, void* out, int batch, int H, i
   if (!qkv || !out || batch <= 0 || nh <= 0) return fail(KD_EINVAL, "kd_attn_na2d_bf16: bad arguments");
   if (ks < 3 || ks > 13 || !(ks & 1)) return fail(KD_EINVAL, "kd_attn_na2d_bf16: kernel_size %d unsupported (3, 5, 7, 9, 11 or 13)", ks);
   if (H < ks || W < ks) return fail(KD_EINVAL, "kd_attn_na2d_bf16: grid %dx%d smaller than the %dx%d neighbourhood", H, W, ks, ks);
-  NArgs a{reinterpret_cast<const u16*>(qkv), reinterpret_cast<u16*>(out), batch, H, W, nh, option("code_warm", 8)};
+  NArgs a{reinterpret_cast<const u16*>(qkv), reinterpret_cast<u16*>(out), batch, H, W, nh, option("code_warm", KD_CODE_WARM_DEFAULT)};
   hipStream_t s = (hipStream_t)stream;
   switch (ks) {
     case 3: return launch_na<3>(a, s);

@@ -1240,7 +1240,7 @@ extern "C" int kd_attn_global_f32(const float* qkv, float* out, int batch, int T
                                   const float* cos_t, const float* sin_t, float eps, int precision, void* stream) {
   if (!qkv || !out || batch <= 0 || nh <= 0 || T <= 0) return fail(KD_EINVAL, "kd_attn_global_f32: bad arguments");
   if (int e = check_prep(prep, scale_h, cos_t, sin_t, "kd_attn_global_f32")) return e;
-  DenseArgs a{qkv, out, scale_h, cos_t, sin_t, batch, T, nh, 0, 0, 0, 0, eps, option("code_warm", 8)};
+  DenseArgs a{qkv, out, scale_h, cos_t, sin_t, batch, T, nh, 0, 0, 0, 0, eps, option("code_warm", KD_CODE_WARM_DEFAULT)};
   const long nb = (long)batch * nh;
   hipStream_t s = (hipStream_t)stream;
   if (precision != KD_PREC_EXACT && precision != KD_PREC_SPLIT3) return fail(KD_EINVAL, "kd_attn_global_f32: precision must be KD_PREC_EXACT or KD_PREC_SPLIT3");
@@ -1267,7 +1267,7 @@ extern "C" int kd_attn_window_f32(const float* qkv, float* out, int batch, int H
   if ((H % ws) || (W % ws)) return fail(KD_EINVAL, "kd_attn_window_f32: grid %dx%d not divisible by the window", H, W);
   if (shift < 0 || shift >= ws) return fail(KD_EINVAL, "kd_attn_window_f32: bad shift %d", shift);
   if (int e = check_prep(prep, scale_h, cos_t, sin_t, "kd_attn_window_f32")) return e;
-  DenseArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H * W, nh, H, W, ws, shift, eps, option("code_warm", 8)};
+  DenseArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H * W, nh, H, W, ws, shift, eps, option("code_warm", KD_CODE_WARM_DEFAULT)};
   const long nb = (long)batch * nh * (H / ws) * (W / ws);
   if (precision != KD_PREC_EXACT && precision != KD_PREC_SPLIT3) return fail(KD_EINVAL, "kd_attn_window_f32: precision must be KD_PREC_EXACT or KD_PREC_SPLIT3");
   hipStream_t s = (hipStream_t)stream;
@@ -1289,7 +1289,7 @@ extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, 
   if (ks != NA_K) return fail(KD_EINVAL, "kd_attn_na2d_f32: kernel_size %d unsupported (only 7)", ks);
   if (H < ks || W < ks) return fail(KD_EINVAL, "kd_attn_na2d_f32: grid %dx%d smaller than the %dx%d neighbourhood", H, W, ks, ks);
   if (int e = check_prep(prep, scale_h, cos_t, sin_t, "kd_attn_na2d_f32")) return e;
-  NaArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H, W, nh, eps, option("code_warm", 8)};
+  NaArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H, W, nh, eps, option("code_warm", KD_CODE_WARM_DEFAULT)};
   const long nb = (long)batch * nh * ((H + NA_TH - 1) / NA_TH) * ((W + NA_TW - 1) / NA_TW);
   hipStream_t s = (hipStream_t)stream;
   char nm[64] = "attn_na2d";

@@ -16,6 +16,9 @@ import sys
 import tempfile
 
 LLVM = os.environ.get("KD_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+# toolchains on which the warm-up was validated on hardware (kd_common.h: KD_CODE_WARM_DEFAULT is 8 only for these; any other
+# compiler builds with the warm-up OFF by default).  The layout check below runs -- and must pass -- regardless.
+VALIDATED_CLANG = ("AMD clang version 22.0.0git", "roc-7.2.0")
 WARM_MAX = 32768          # KD_CODE_WARM_MAX
 TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 
@@ -54,6 +57,15 @@ def check(obj):
 
 
 def main(objs):
+    try:
+        ver = run(os.path.join(LLVM, "clang"), "--version").splitlines()[0]
+    except Exception as e:  # noqa: BLE001
+        ver = f"unknown ({e})"
+    if all(v in ver for v in VALIDATED_CLANG):
+        print(f"check_code_objects: toolchain validated for the code warm-up: {ver}")
+    else:
+        print(f"check_code_objects: WARNING: code warm-up not validated on this toolchain ({ver}): it builds with the warm-up OFF by "
+              "default (kd_common.h KD_CODE_WARM_DEFAULT); re-run profiles/r02_level_entry.md's A/B before enabling it")
     for obj in objs:
         tn, pn = check(obj)
         print(f"check_code_objects: {os.path.basename(obj)}: .text {tn} bytes, pad {pn} bytes behind it: ok")

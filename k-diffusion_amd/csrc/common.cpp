@@ -1,6 +1,7 @@
 // Error reporting + per-launch event timing shared by all entry points of libkdiff_hip.so.
 #include "kd_common.h"
 #include <atomic>
+#include <climits>
 #include <mutex>
 
 namespace kd {
@@ -16,21 +17,31 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-static bool g_prof = false;
+static std::atomic<bool> g_prof{false};
+static std::mutex g_rec_mutex;            // launches may come from several host threads (one stream each): the record list is shared
 static std::vector<ProfRec> g_recs;
 
-bool prof_on() { return g_prof; }
+bool prof_on() { return g_prof.load(std::memory_order_relaxed); }
 
-void prof_begin(const char* name, double flops, double bytes, hipStream_t s) {
+int prof_begin(const char* name, double flops, double bytes, hipStream_t s) {
   ProfRec r;
   r.name = name; r.flops = flops; r.bytes = bytes;
   (void)hipEventCreate(&r.e0);
   (void)hipEventCreate(&r.e1);
   (void)hipEventRecord(r.e0, s);
+  std::lock_guard<std::mutex> lock(g_rec_mutex);
   g_recs.push_back(r);
+  return (int)g_recs.size() - 1;
 }
 
-void prof_end(hipStream_t s) { (void)hipEventRecord(g_recs.back().e1, s); }
+void prof_end(int idx, hipStream_t s) {
+  hipEvent_t e1 = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_rec_mutex);
+    if (idx >= 0 && idx < (int)g_recs.size()) e1 = g_recs[idx].e1;      // (a kd_prof_reset between begin and end drops the record)
+  }
+  if (e1) (void)hipEventRecord(e1, s);
+}
 
 }  // namespace kd
 
@@ -64,6 +75,10 @@ extern "C" int kd_set_option(const char* name, int value) {
   if (!name) return fail(KD_EINVAL, "kd_set_option: null name");
   const int i = option_index(name);
   if (i < 0) return fail(KD_EINVAL, "kd_set_option: unknown option '%s'", name);
+  if (value == INT_MIN) {                 // back to the built-in default of every call site
+    g_opts[i].set.store(false, std::memory_order_relaxed);
+    return KD_OK;
+  }
   g_opts[i].value.store(value, std::memory_order_relaxed);
   g_opts[i].set.store(true, std::memory_order_relaxed);
   return KD_OK;
@@ -73,11 +88,18 @@ extern "C" int kd_get_option(const char* name, int dflt) { return name ? option_
 extern "C" int kd_version(void) { return 200; }
 extern "C" const char* kd_last_error(void) { return err_buf(); }
 
-extern "C" int kd_prof_enable(int on) { g_prof = on != 0; return KD_OK; }
-extern "C" int kd_prof_count(void) { return (int)g_recs.size(); }
+extern "C" int kd_prof_enable(int on) { g_prof.store(on != 0, std::memory_order_relaxed); return KD_OK; }
+extern "C" int kd_prof_count(void) {
+  std::lock_guard<std::mutex> lock(g_rec_mutex);
+  return (int)g_recs.size();
+}
 extern "C" int kd_prof_get(int i, char* name, int name_cap, float* ms, double* flops, double* bytes) {
-  if (i < 0 || i >= (int)g_recs.size()) return fail(KD_EINVAL, "kd_prof_get: index %d out of range", i);
-  ProfRec& r = g_recs[i];
+  ProfRec r;
+  {
+    std::lock_guard<std::mutex> lock(g_rec_mutex);
+    if (i < 0 || i >= (int)g_recs.size()) return fail(KD_EINVAL, "kd_prof_get: index %d out of range", i);
+    r = g_recs[i];
+  }
   if (hipEventSynchronize(r.e1) != hipSuccess) return fail(KD_ELAUNCH, "kd_prof_get: event sync failed");
   float t = 0.f;
   if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return fail(KD_ELAUNCH, "kd_prof_get: elapsed failed");
@@ -88,6 +110,7 @@ extern "C" int kd_prof_get(int i, char* name, int name_cap, float* ms, double* f
   return KD_OK;
 }
 extern "C" int kd_prof_reset(void) {
+  std::lock_guard<std::mutex> lock(g_rec_mutex);
   for (auto& r : g_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   g_recs.clear();
   return KD_OK;

@@ -395,7 +395,7 @@ extern "C" int kd_ffn_bf16(const KdFfn* dp, void* stream) {
   a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample; a.eps = d.eps;
   a.M = d.M; a.n_tiles = d.d_ff / 64;
   a.clk = g_clk;
-  a.warm = option("code_warm", 8);
+  a.warm = option("code_warm", KD_CODE_WARM_DEFAULT);
   if (d.K == 256) {
     constexpr int LDS256 = 9 * WBLK;
     static bool attr256 = false;

@@ -618,7 +618,7 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
   GemmP e;
   static_cast<KdGemm&>(e) = d;
   e.debug = option("gemm_debug", 0);
-  e.warm = option("code_warm", 8);
+  e.warm = option("code_warm", KD_CODE_WARM_DEFAULT);
   if (e.rows_per_sample <= 0) e.rows_per_sample = e.M;
   // all rows of a 128-row tile share their scale vector: stage it in LDS once per tile
   e.scale_tab = e.norm && e.a_mode == KD_A_PLAIN && e.K <= SCALE_TAB_MAX_K && (e.scale_stride == 0 || e.rows_per_sample % BM == 0);

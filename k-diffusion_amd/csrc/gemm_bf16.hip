@@ -337,7 +337,7 @@ int gemm_wstat_try(const KdGemm& d, hipStream_t s, int* rc) {
   a.M = d.M; a.N = d.N; a.n_tiles = n_tiles; a.tiles_per_slice = tps; a.n_slices = n_slices;
   a.n_heads = d.n_heads; a.qk_scale = d.qk_scale; a.pos = d.rope_pos; a.freq = d.rope_freq;
   a.clk = g_clk;
-  a.warm = option("code_warm", 8);
+  a.warm = option("code_warm", KD_CODE_WARM_DEFAULT);
   const int lds = tps * nk * WBLK;
   const double n_eff = geglu ? 2.0 * d.N : (double)d.N;
   const double flops = 2.0 * d.M * n_eff * d.K;
@@ -614,7 +614,7 @@ int gemm_tiled_try(const KdGemm& d, hipStream_t s, int* rc) {
   a.C = reinterpret_cast<u16*>(d.C); a.R = reinterpret_cast<const u16*>(d.R); a.fac = d.fac;
   a.M = d.M; a.N = d.N; a.K = d.K; a.n_tiles_n = (d.N + 127) / 128; a.nk = d.K / 64;
   a.gh = d.gh; a.gw = d.gw; a.cin = d.K >> 2;
-  a.warm = option("code_warm", 8);
+  a.warm = option("code_warm", KD_CODE_WARM_DEFAULT);
   const double flops = 2.0 * d.M * (double)d.N * d.K;
   const double bytes = 2.0 * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N) + (d.epi != KD_EPI_STORE ? 2.0 * d.M * d.N : 0.0);
   char nm[96] = "gemm_tiled";
@@ -966,7 +966,7 @@ int gemm_astat_try(const KdGemm& d, hipStream_t s, int* rc) {
   a.M = d.M; a.N = d.N; a.n_tiles = d.N / ncol;
   a.n_heads = d.n_heads; a.qk_scale = d.qk_scale; a.pos = d.rope_pos; a.freq = d.rope_freq;
   a.clk = g_clk;
-  a.warm = option("code_warm", 8);
+  a.warm = option("code_warm", KD_CODE_WARM_DEFAULT);
   const double n_eff = geglu ? 2.0 * d.N : (double)d.N;
   const double flops = 2.0 * d.M * n_eff * d.K;
   const double bytes = 2.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N);

@@ -34,15 +34,13 @@ int option_at(int idx, int dflt);
 // ---- per-launch profiling (bench.py): hipEvent pairs around launches when enabled ---------------
 struct ProfRec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
 bool prof_on();
-void prof_begin(const char* name, double flops, double bytes, hipStream_t s);
-void prof_end(hipStream_t s);
+int prof_begin(const char* name, double flops, double bytes, hipStream_t s);      // -> index of the record (thread-safe)
+void prof_end(int idx, hipStream_t s);
 
 struct LaunchScope {
-  hipStream_t s; bool on;
-  LaunchScope(const char* name, double flops, double bytes, hipStream_t st) : s(st), on(prof_on()) {
-    if (on) prof_begin(name, flops, bytes, s);
-  }
-  ~LaunchScope() { if (on) prof_end(s); }
+  hipStream_t s; int idx;
+  LaunchScope(const char* name, double flops, double bytes, hipStream_t st) : s(st), idx(prof_on() ? prof_begin(name, flops, bytes, st) : -1) {}
+  ~LaunchScope() { if (idx >= 0) prof_end(idx, s); }
 };
 
 inline int check_launch(const char* what) {
@@ -123,6 +121,16 @@ __device__ __forceinline__ f32x2 geglu_pair(f32x2 vh, f32x2 g) {
 // KD_CODE_WARM_MAX + 4 KiB of s_nop behind the last real kernel, so [entry, entry + BYTES) never leaves the loaded image;
 // csrc/check_code_objects.py verifies that layout at build time (Makefile, __graft_entry__.build).
 constexpr int KD_CODE_WARM_MAX = 32768;
+// Validated on: ROCm 7.2.0 (HIP 7.2.26015, AMD clang 22.0.0git roc-7.2.0) -- the code-object layout by check_code_objects.py at every
+// build, the behaviour (no result change, +9.4 % images/s) on MI355X with that toolchain (profiles/r02_level_entry.md).  The trick
+// rests on how THAT linker lays out a code object (.kd_text_pad directly behind .text in one executable segment) and on
+// s_getpc_b64 pointing into it; with any other compiler the default is OFF until someone re-validates (fail closed), and
+// check_code_objects.py refuses a layout it does not recognise whatever the version.
+#if defined(__clang_major__) && __clang_major__ == 22 && defined(HIP_VERSION_MAJOR) && HIP_VERSION_MAJOR == 7 && HIP_VERSION_MINOR == 2
+constexpr int KD_CODE_WARM_DEFAULT = 8;     // workgroups (one per XCD) whose first wave reads the kernel's code range into L2
+#else
+constexpr int KD_CODE_WARM_DEFAULT = 0;
+#endif
 template <int TAG>
 __global__ __attribute__((section(".kd_text_pad"))) void kd_text_pad_kernel() {            // its own section: the linker puts it
   asm volatile(".fill 9216, 4, 0xbf800000");                                              // behind .text, in the same segment

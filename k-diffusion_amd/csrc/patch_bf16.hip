@@ -267,7 +267,7 @@ int gemm_patch_try(const KdGemm& d, hipStream_t s, int* rc) {
   const int feat = 4 * d.ph * d.chan;
   PArgs a{};
   a.Wp = reinterpret_cast<const char*>(d.Wp);
-  a.warm = option("code_warm", 8);
+  a.warm = option("code_warm", KD_CODE_WARM_DEFAULT);
   a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample > 0 ? d.rows_per_sample : d.M; a.eps = d.eps;
   a.M = d.M; a.N = d.N; a.K = d.K; a.gh = d.gh; a.gw = d.gw; a.ph = d.ph; a.chan = d.chan;
   a.sigma = d.sigma; a.sigma_data = d.sigma_data;

@@ -44,6 +44,7 @@ D_HEAD = 64
 # Largest [steps, B, scale_width] scale table kept per sigma schedule (prefetch_schedule); longer schedules use the per-step chain.
 SCHEDULE_TABLE_MAX_BYTES = 1 << 30
 SCHEDULES_KEPT = 4            # a run of a two-stage solver hints two tables; older records (and their tensors) are dropped
+SCHEDULE_CHAINS_KEPT = 2      # conditioning workspaces kept per plan, by schedule length (least recently used dropped)
 
 
 def _graph_policy():
@@ -234,6 +235,7 @@ class _Plan:
         self.g_x = self.g_out = self.capture_stream = None   # their fixed input / output images
         self.direct_runs = self.direct_cond_runs = 0
         self.graph_epoch = nat.option_epoch
+        self.class_checked = self.class_keep = None         # identity of the last range-checked class_cond tensor (_plan_for)
         mw, mdff = m.mapping_spec.width, m.mapping_spec.d_ff
 
         # ---- static buffers -----------------------------------------------------------------
@@ -688,13 +690,16 @@ class ImageTransformerDenoiserModelV2(nn.Module):
             if self.patch_in.proj.weight.device != x.device:
                 raise RuntimeError(f"model weights are on {self.patch_in.proj.weight.device}, input on {x.device}")
             plan = self._plans[key] = _Plan(self, B, H, W, key[3], has_class, key[5], x.device)
-            if has_class:
-                # nn.Embedding raises on an out-of-range id; the HIP kernel would read past the table.  Checked once per plan
-                # (one device->host read), not per call: the per-step path stays sync-free.
-                lo, hi = int(class_cond.min()), int(class_cond.max())
+        if plan is not None and has_class and class_cond is not None:
+            # nn.Embedding raises on an out-of-range id (on every call); the HIP kernel would read past the table.  Checked whenever
+            # the ids are a tensor this plan has not seen in this state (address, version): one device->host read per new id
+            # tensor -- a sampling run passes the same tensor to every step, so the per-step path stays sync-free.
+            ident = (class_cond.data_ptr(), class_cond._version, tuple(class_cond.shape))
+            if plan.class_checked != ident:
+                lo, hi = (int(class_cond.min()), int(class_cond.max())) if class_cond.numel() else (0, 0)
                 if lo < 0 or hi >= self.class_emb.weight.shape[0]:
-                    del self._plans[key]
                     raise IndexError(f"class_cond ids must lie in [0, {self.class_emb.weight.shape[0] - 1}] (got {lo}..{hi})")
+                plan.class_checked, plan.class_keep = ident, class_cond      # (kept alive: the address cannot be recycled under the record)
         return plan
 
     # ---- conditioning ahead of time ---------------------------------------------------------------
@@ -721,9 +726,12 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         plan = self._plan_for(x_like, aug_cond, class_cond, create=True)
         if plan.use_graph or n * B * plan.scale_width * 4 > SCHEDULE_TABLE_MAX_BYTES:
             return False                          # (a captured main chain is bound to the address of its scale table)
-        chain = plan.schedule_chains.get(n)
+        chain = plan.schedule_chains.pop(n, None)
         if chain is None:
-            chain = plan.schedule_chains[n] = plan.build_cond(n * B)
+            chain = plan.build_cond(n * B)
+        plan.schedule_chains[n] = chain                   # most recently used last; older lengths (and their workspaces) are dropped
+        for old_n in list(plan.schedule_chains)[:-SCHEDULE_CHAINS_KEPT]:
+            del plan.schedule_chains[old_n]
         cur = torch.cuda.current_stream()
         for sch in plan.schedules:                # an earlier schedule's chain of the same length shares the work buffers
             cur.wait_event(sch.done)
@@ -735,7 +743,17 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         others = (aug_cond, class_cond, mapping_cond)
         plan.schedules.append(_Schedule(sigma_table, others, self._cond_identity(None, *others)[1:], tables, done))
         del plan.schedules[:-SCHEDULES_KEPT]
+        while len(plan.schedules) > 1 and sum(sc.tables.numel() * 4 for sc in plan.schedules) > SCHEDULE_TABLE_MAX_BYTES:
+            del plan.schedules[0]                          # all tables of a plan together stay below the bound of a single one
         return True
+
+    def release_schedules(self):
+        """Drop the scale tables (and the hinted tensors they keep alive) of finished runs: up to SCHEDULE_TABLE_MAX_BYTES of HBM
+        per plan otherwise stay allocated until the next run replaces them.  Safe at any time: calls no table covers use the
+        per-step chain, with the same bits."""
+        for plan in self._plans.values():
+            plan.schedules.clear()
+            plan.schedule_chains.clear()
 
     @torch.no_grad()
     def prefetch_conditioning(self, x_like, sigma, aug_cond=None, class_cond=None, mapping_cond=None):

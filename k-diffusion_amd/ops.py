@@ -452,5 +452,8 @@ def brownian_cached(out, w0, have0, w1, have1, seeds, T0, T1, t0, t1, mult, dept
 
 def to_uint8(x, out=None):
     out = torch.empty(x.shape, device=x.device, dtype=torch.uint8) if out is None else out
+    if x.numel() == 0:       # an empty shard (more ranks than images in a round): nothing to launch, and the other ranks still gather
+        _chk(x, "x"), _chk(out, "y", torch.uint8)
+        return out
     nat.check(nat.lib().kd_to_uint8(_p(_chk(x, "x")), _p(_chk(out, "y", torch.uint8)), x.numel(), _stream()), "kd_to_uint8")
     return out

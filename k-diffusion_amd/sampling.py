@@ -25,6 +25,10 @@ from . import ops, utils
 
 _COND_PREFETCH = os.environ.get('KDIFF_COND_PREFETCH', '1') != '0'      # A/B switch (benchmarks/): side-stream conditioning
 _COND_SCHEDULE = os.environ.get('KDIFF_COND_SCHEDULE', '1') != '0'      # A/B switch: conditioning of the whole sigma table at once
+# KDIFF_STRICT_RNG=1: euler / heun / dpm_2 draw ``randn_like(x)`` on every step even with s_churn == 0, exactly like the reference
+# (sampling.py:124,165,195), so that code reading the global generator AFTER a run sees the reference's stream position.  Off by
+# default: the draw is unused there and costs one launch + 25 MB of writes per step (documented in INTEGRATION.md).
+_STRICT_RNG = os.environ.get('KDIFF_STRICT_RNG', '0') == '1'
 
 # --------------------------------------------------------------------------------- schedules
 
@@ -250,8 +254,8 @@ def _apply_churn(lp, i, gamma, sigma_hat, s_noise, s_churn):
     uses it only where gamma > 0.  With churn requested the draw is made on every step too, so the generator advances exactly
     like the reference's (steps outside [s_tmin, s_tmax] included); with s_churn == 0 (the default) no noise is ever used and
     none is drawn -- the one deliberate deviation: code that reads the global generator AFTER such a run sees a stream that
-    is len(sigmas) - 1 draws behind the reference's."""
-    if s_churn > 0:
+    is len(sigmas) - 1 draws behind the reference's (KDIFF_STRICT_RNG=1 restores the reference's behaviour)."""
+    if s_churn > 0 or _STRICT_RNG:
         eps = torch.randn_like(lp.x)
         if gamma > 0:
             lp.add_noise(eps, s_noise, (sigma_hat ** 2 - lp.sig[i] ** 2) ** 0.5)

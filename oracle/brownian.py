@@ -103,3 +103,30 @@ def brownian_increment(seeds, per_sample, T0, T1, t0, t1, mult=1.0, depth=36):
     for b, s in enumerate(seeds):
         out[b] = (brownian_w(int(s), per_sample, t1, T0, T1, depth) - brownian_w(int(s), per_sample, t0, T0, T1, depth)) * np.float32(mult)
     return out
+
+
+class OracleBrownianTree:
+    """Stands in for ``torchsde.BrownianTree(t0, w0, t1, entropy=seed)`` (the constructor and call surface
+    k_diffusion/sampling.py:80,88 uses) with THIS package's stream: ``tree(ta, tb)`` -> W(tb) - W(ta) shaped like ``w0``,
+    element i of the flattened sample = element i of the virtual tree keyed by ``entropy``.  With it installed as
+    ``torchsde.BrownianTree`` the reference's own BatchedBrownianTree / BrownianTreeNoiseSampler (sampling.py:65-114: sorting,
+    signs, one tree per batch item, the 1 / sqrt|t1 - t0| normalisation) run unchanged on the CPU -- which is how
+    oracle/make_golden_r3.py records BASELINE configs[4] (flowers-NA, sample_dpmpp_sde, Brownian noise) from the reference."""
+
+    def __init__(self, t0, w0, t1, entropy=None, depth=36, **kwargs):
+        import torch
+        self.T0, self.T1, self.key, self.depth = float(t0), float(t1), int(entropy) & 0x7FFFFFFFFFFFFFFF, int(depth)
+        self.shape, self._torch = tuple(w0.shape), torch
+        self._points = {}
+
+    def _w(self, t):
+        t = min(max(float(t), self.T0), self.T1)
+        if t not in self._points:
+            if len(self._points) > 4:
+                self._points.pop(next(iter(self._points)))
+            n = int(np.prod(self.shape))
+            self._points[t] = brownian_w(self.key, n, t, self.T0, self.T1, self.depth)
+        return self._points[t]
+
+    def __call__(self, ta, tb):
+        return self._torch.from_numpy((self._w(tb) - self._w(ta)).reshape(self.shape).copy())

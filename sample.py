@@ -14,7 +14,9 @@ sample.py:59-60, and therefore cannot run its own class-conditional configs):
   --class-cond C       class id for every image (-1: image index mod num_classes) for class-conditional configs
   --random-weights     no checkpoint: synthetic weights (K.synth), for smoke runs and benchmarking
   --no-png             skip PNG encoding (timing runs)
-  --gather-uint8       8-bit conversion on the GPU before the all-gather of finished images (same PNG bytes, 4x less xGMI traffic)
+  --gather-uint8       8-bit conversion on the GPU before the all-gather of finished images (same PNG bytes, 4x less xGMI traffic).
+                       The DEFAULT whenever there is a gather (more than one process) and PNG files are written -- the writer needs
+                       nothing else; --gather-fp32 keeps the reference's fp32 gather (main() then returns fp32 images)
 With --seed the stochastic samplers are index-addressed too: one Brownian tree per global image index for the SDE samplers,
 a per-(index, call) stream for the ancestral ones (the reference draws both from rank-local global RNG state).
 """
@@ -44,7 +46,10 @@ def parse(argv=None):
     p.add_argument('--no-png', action='store_true', help='do not write PNG files')
     p.add_argument('--gather-uint8', action='store_true',
                    help='convert finished images to uint8 on the GPU before the all-gather (what the PNG writer needs; 4x less xGMI traffic)')
+    p.add_argument('--gather-fp32', action='store_true', help='all-gather the finished images as fp32 even when only PNG files are wanted')
     args = p.parse_args(argv)
+    if args.gather_uint8 and args.gather_fp32:
+        p.error('--gather-uint8 and --gather-fp32 exclude each other')
     if args.checkpoint is None and not args.random_weights:
         p.error('--checkpoint is required (or pass --random-weights)')
     if args.checkpoint is None and args.config is None:
@@ -160,7 +165,9 @@ def main(argv=None):
         t0 = time.perf_counter()
         # the reference's compute_features (evaluation.py:80-90) with images addressed by global index: out[i] is image i for
         # any batch size / GPU count (see compute_features_indexed)
-        post = K.ops.to_uint8 if args.gather_uint8 else None       # [-1, 1] fp32 -> uint8 on the device: 4x fewer bytes over xGMI
+        # [-1, 1] fp32 -> uint8 on the device before the gather: 4x fewer bytes over xGMI, the same PNG bytes
+        as_u8 = args.gather_uint8 or (accelerator.num_processes > 1 and not args.no_png and not args.gather_fp32)
+        post = K.ops.to_uint8 if as_u8 else None
         x_0 = K.evaluation.compute_features_indexed(accelerator, sample_fn, args.n, args.batch_size, post=post)
         torch.cuda.synchronize()
         accelerator.print(f'{args.n} images in {time.perf_counter() - t0:.2f} s')

@@ -90,6 +90,24 @@ BF16_SAMPLE_CASES = ["smp_tiny_global_euler", "smp_tiny_sw_heun", "smp_tiny_na_2
                      "smp_flowers_sw_2m50", "smp_flowers_na_2m50"]
 
 
+# round 3 ------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: flowers-NA, sample_dpmpp_sde x 50 with Brownian-tree noise (batch reduced to 1 for the CPU reference).
+# Recorded by oracle/make_golden_r3.py from the reference's own sampler + BrownianTreeNoiseSampler over this package's tree stream.
+SDE_FULL_CASE = ("smp_flowers_na_sde50", "flowers_na", "sample_dpmpp_sde", 50, 1)
+SDE_SEED = 5
+# 5-step DPM++2M at the full per-GPU batch (the batch the benchmark runs at); the golden file keeps images B32_KEEP
+SAMPLE_B32_CASES = [
+    ("smp32_flowers_na_2m5", "flowers_na", "sample_dpmpp_2m", 5, 32),
+    ("smp32_flowers_sw_2m5", "flowers_sw", "sample_dpmpp_2m", 5, 32),
+]
+
+
+def sde_brownian_seeds(batch, seed=SDE_SEED):
+    """One Brownian-tree seed per global image index: the rule of sample.py --seed (sample.brownian_seeds), restated here so that
+    the golden script and the tests do not import the CLI."""
+    return [((int(seed) * 0x9E3779B97F4A7C15) ^ (int(g) * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D)) & 0x7FFFFFFFFFFFFFFF for g in range(batch)]
+
+
 def raw_config(name):
     c = CONFIGS[name]
     if isinstance(c, str):

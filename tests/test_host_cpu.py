@@ -365,3 +365,62 @@ def test_two_rank_gather_over_gloo(KD, tmp_path):
     expect = torch.stack(expect)[:n]
     assert got.shape == (n, *shape)
     assert torch.equal(got, expect)
+
+
+def test_option_sync_is_incremental():
+    """KDIFF_* / KDIFF_OPTIONS -> kd_set_option (round-2 advisor): only what changed is re-applied, an entry that disappears from
+    KDIFF_OPTIONS goes back to the built-in default, and a value set through set_option survives changes of OTHER variables.
+    Runs in a child process: options are process-global."""
+    code = (
+        "import os, sys; sys.path.insert(0, %r)\n"
+        "import k_diffusion_amd as K\n"
+        "nat = K._native\n"
+        "get = lambda n, d: nat.lib().kd_get_option(n.encode(), d)\n"
+        "os.environ['KDIFF_OPTIONS'] = 'wstat=0,tiled_bm=256'\n"
+        "assert get('wstat', 1) == 0 and get('tiled_bm', 0) == 256\n"
+        "nat.set_option('ffn_fused', 0)\n"
+        "os.environ['KDIFF_OPTIONS'] = 'tiled_bm=128'\n"          # wstat disappears: default again; ffn_fused (programmatic) untouched
+        "assert get('wstat', 1) == 1 and get('wstat', 5) == 5 and get('tiled_bm', 0) == 128 and get('ffn_fused', 1) == 0\n"
+        "os.environ['KDIFF_SKINNY'] = '0'\n"
+        "assert get('skinny', 1) == 0 and get('ffn_fused', 1) == 0 and get('tiled_bm', 0) == 128\n"
+        "del os.environ['KDIFF_SKINNY']\n"
+        "assert get('skinny', 1) == 1\n"
+        "os.environ['KDIFF_OPTIONS'] = 'ffn_fused=1'\n"          # the environment names it anew: it wins again
+        "assert get('ffn_fused', 0) == 1 and get('tiled_bm', 7) == 7\n"
+        "e = nat.option_epoch; nat.lib(); nat.lib(); assert nat.option_epoch == e\n"     # nothing changed: nothing re-applied
+        "os.environ['KDIFF_OPTIONS'] = 'no_such=1'\n"
+        "try:\n    nat.lib(); raise SystemExit('accepted an unknown option')\nexcept ValueError:\n    pass\n"
+        "print('ok')\n") % REPO
+    env = {k: v for k, v in os.environ.items() if not k.startswith("KDIFF_") and k != "KD_GEMM_DEBUG"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_oracle_brownian_tree_stands_in_for_torchsde():
+    """oracle.brownian.OracleBrownianTree (what make_golden_r3.py installs as torchsde.BrownianTree under the REFERENCE's
+    BatchedBrownianTree): call surface, additivity over adjacent intervals, unit variance per unit time, determinism per seed."""
+    from oracle import brownian as ob
+    w0 = torch.zeros(3, 64, 64)
+    tree = ob.OracleBrownianTree(0.01, w0, 160.0, entropy=1234)
+    ab, bc, ac = tree(1.0, 2.0), tree(2.0, 5.5), tree(1.0, 5.5)
+    assert ab.shape == w0.shape and ab.dtype == torch.float32
+    assert (ab + bc - ac).abs().max() < 1e-5
+    assert abs(float(ac.var()) / 4.5 - 1.0) < 0.08 and abs(float(tree(0.02, 0.03).var()) / 0.01 - 1.0) < 0.08
+    assert torch.equal(ob.OracleBrownianTree(0.01, w0, 160.0, entropy=1234)(1.0, 2.0), ab)
+    assert not torch.equal(ob.OracleBrownianTree(0.01, w0, 160.0, entropy=1235)(1.0, 2.0), ab)
+    assert torch.equal(tree(2.0, 1.0), -ab)
+    if ob_ref_available():
+        from oracle import ref_import
+        K = ref_import.load()
+        K.sampling.torchsde.BrownianTree = ob.OracleBrownianTree
+        x = torch.zeros(2, 3, 8, 8)
+        ns = K.sampling.BrownianTreeNoiseSampler(x, 0.01, 160.0, seed=[7, 8])            # the reference's own class
+        n = ns(torch.tensor(4.0), torch.tensor(1.0))                                      # descending sigmas, as the samplers ask
+        inc = ob.brownian_increment([7, 8], 192, 0.01, 160.0, 1.0, 4.0)
+        want = -torch.from_numpy(inc).view(2, 3, 8, 8) / (torch.tensor(1.0) - torch.tensor(4.0)).abs().sqrt()
+        assert torch.allclose(n, want, atol=1e-4)          # (the reference hands the tree fp32 end points: 0.01 -> 0.0099999998)
+
+
+def ob_ref_available():
+    from oracle import ref_import
+    return ref_import.available()
