@@ -592,6 +592,7 @@ static int launch(const GemmP& d, hipStream_t s) {
 }  // namespace kd
 
 namespace kd { int gemm_astat_try(const GemmP& d, hipStream_t s, int* rc); }    // gemm_astat.hip
+namespace kd { int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc); }       // gemm_x3.hip
 namespace kd { int gemm_skinny_try(const GemmP& d, hipStream_t s, int* rc); }   // gemm_skinny.hip
 
 using namespace kd;
@@ -631,7 +632,8 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
   {
     const bool astat_on = option("astat", 1) != 0;
     int rc = 0;
-    if (astat_on && !gemm_astat_try(e, s, &rc)) return rc;     // wide K <= 256 projections: A-stationary kernel
+    if (astat_on && !gemm_x3_try(e, s, &rc)) return rc;        // norm -> wide projection, split3: round-3 A-stationary kernel (gemm_x3.hip)
+    if (astat_on && !gemm_astat_try(e, s, &rc)) return rc;     // ... and its round-1 predecessor (RoPE tables instead of positions; A/B runs)
   }
   if (e.precision != KD_PREC_EXACT && e.precision != KD_PREC_SPLIT3) return fail(KD_EINVAL, "kd_gemm_f32: unknown precision %d", e.precision);
   if (e.precision == KD_PREC_SPLIT3 && !e.Wp) return fail(KD_EINVAL, "kd_gemm_f32: split3 needs the packed weight image Wp (kd_pack_weight_bf16x3)");

@@ -1287,8 +1287,11 @@ int gemm_patch_try(const KdGemm& d, hipStream_t s, int* rc);      // patch_bf16.
 
 using namespace kd;
 
+namespace kd { void x3_set_clock_buffer(unsigned long long* p); }     // gemm_x3.hip
+
 extern "C" int kd_prof_clock_buffer(void* dev_ptr) {
   b16::g_clk = reinterpret_cast<unsigned long long*>(dev_ptr);
+  x3_set_clock_buffer(reinterpret_cast<unsigned long long*>(dev_ptr));
   return KD_OK;
 }
 

@@ -1,0 +1,418 @@
+// fp32-parity ("split3") projections in the round-2 kernel shape: AdaRMSNorm -> wide projection (qkv + cosine-sim + RoPE, up-projection +
+// GEGLU, plain store) with fp32 activations in HBM and every product as three bf16 MFMA terms (hi*hi + hi*lo + lo*hi, fp32 accumulate).
+//
+// Replaces gemm_astat.hip (round 1) for these shapes.  What changed, and why (profiles/r03_issue_model.md):
+//   * swapped product D = W_frag x act_frag: a lane owns ONE activation row, so the whole epilogue (row factor, cosine-sim norm, RoPE
+//     pairs, GEGLU, hi / lo split of the qkv operands) is in-lane arithmetic and every store is the lane's own 16 bytes (4 consecutive
+//     features of its row) -- no transposing LDS strips, no cross-lane traffic but one half-wave sum;
+//   * the wave's 32 rows come in through LDS as WHOLE rows (global_load_lds, fully coalesced, chunk-swizzled on the source side) and
+//     are normalised, scaled and split ONCE into register fragments (a_hi / a_lo);
+//   * the packed weight (kd_pack_weight_bf16x3: [n-tile][32-k stage][hi | lo][128 rows][32 k], 16 KiB per stage) streams through a
+//     4- or 8-slot LDS ring, requested NSTG - 1 stages ahead with counted vmcnt (the epilogue's stores stay outstanding);
+//   * the K loop is software-pipelined across stages: the fragment reads of the NEXT 16-k chunk -- also across the stage boundary, whose
+//     wait + barrier sits in the MIDDLE of a stage -- are issued before the 12 MFMAs of the current chunk, so no MFMA waits for an LDS
+//     round trip even with one wave per SIMD (K >= 256: the fragments of a row take 128 / 256 registers).  A stage is 16 ds_read_b128
+//     per 24 MFMAs: inside the 6-issue-slot shadow of an MFMA measured in r03_issue_model.md;
+//   * RoPE angles from the token's axial position and the head's frequencies (hardware sin / cos in revolutions) instead of cos / sin
+//     tables: no vector loads inside the ring loop (hipcc waits vmcnt(0) for an ordinary load issued beside LDS-DMA, draining the ring).
+#include "bf16_common.h"
+
+namespace kd {
+namespace x3 {
+
+using b16::bf16x8;
+using b16::u32x2;
+using b16::u32x4;
+using b16::pack_bf16;
+
+constexpr int STG = 16384, IMG = 8192;      // one ring stage: [hi image | lo image] of [128 W rows][32 k] bf16
+
+// byte offset of (row, 16-byte chunk c in 0..3) inside a [128][32] bf16 image (kd_pack_weight_bf16x3's swizzle)
+__device__ __forceinline__ int swz64(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+
+struct XArgs {
+  const float* A; const char* Wp; float* C;
+  const float* scale; int scale_stride, rows_per_sample; float eps;
+  int M, N, n_tiles, n_splits;
+  int n_heads; const float* qk_scale; const float* pos; const float* freq; int qkv_packed;
+  float out_add;
+  int warm;
+  unsigned long long* clk;
+};
+
+#define KD_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+// s_waitcnt vmcnt(n) for a run-time n (6-bit counter: anything above 60 waits for 60 outstanding, which is only more conservative)
+__device__ __forceinline__ void wait_vm(int n) {
+  switch (n < 60 ? n : 60) {
+#define KD_C(v) case v: asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); break;
+    KD_C(0) KD_C(1) KD_C(2) KD_C(3) KD_C(4) KD_C(5) KD_C(6) KD_C(7) KD_C(8) KD_C(9) KD_C(10) KD_C(11) KD_C(12) KD_C(13) KD_C(14) KD_C(15)
+    KD_C(16) KD_C(17) KD_C(18) KD_C(19) KD_C(20) KD_C(21) KD_C(22) KD_C(23) KD_C(24) KD_C(25) KD_C(26) KD_C(27) KD_C(28) KD_C(29) KD_C(30) KD_C(31)
+    KD_C(32) KD_C(33) KD_C(34) KD_C(35) KD_C(36) KD_C(37) KD_C(38) KD_C(39) KD_C(40) KD_C(41) KD_C(42) KD_C(43) KD_C(44) KD_C(45) KD_C(46) KD_C(47)
+    KD_C(48) KD_C(49) KD_C(50) KD_C(51) KD_C(52) KD_C(53) KD_C(54) KD_C(55) KD_C(56) KD_C(57) KD_C(58) KD_C(59) KD_C(60)
+#undef KD_C
+  }
+}
+
+// 8 consecutive fp32 (two float4) -> hi / lo bf16 fragments: hi = bf16_rne(x), lo = bf16_rne(x - hi)
+__device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, u32x4& hi, u32x4& lo) {
+  hi = u32x4{pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+  lo = u32x4{pack_bf16(v0[0] - b16::bf_lo(hi[0]), v0[1] - b16::bf_hi(hi[0])), pack_bf16(v0[2] - b16::bf_lo(hi[1]), v0[3] - b16::bf_hi(hi[1])),
+             pack_bf16(v1[0] - b16::bf_lo(hi[2]), v1[1] - b16::bf_hi(hi[2])), pack_bf16(v1[2] - b16::bf_lo(hi[3]), v1[3] - b16::bf_hi(hi[3]))};
+}
+// 4 consecutive fp32 -> the 16 bytes [hi: 4 x bf16][lo: 4 x bf16] (KdGemm.qkv_packed: the operand format of the split attention cores)
+__device__ __forceinline__ f32x4 pack_split4(const f32x4 v) {
+  const unsigned h0 = pack_bf16(v[0], v[1]), h1 = pack_bf16(v[2], v[3]);
+  const unsigned l0 = pack_bf16(v[0] - b16::bf_lo(h0), v[1] - b16::bf_hi(h0)), l1 = pack_bf16(v[2] - b16::bf_lo(h1), v[3] - b16::bf_hi(h1));
+  return f32x4{__uint_as_float(h0), __uint_as_float(h1), __uint_as_float(l0), __uint_as_float(l1)};
+}
+
+// K = 512 is NOT served here: a lane's row would take 256 registers (hi + lo) next to 64 accumulators and the weight fragments, and
+// hipcc -- which will not park long-lived MFMA operands in the AccVGPR half of the file, with builtins or with "a"-constrained asm --
+// spills ~150 of them to scratch, whose reloads also sit in the vmcnt queue the ring's counted waits assume to be theirs.  Level 2 goes
+// through the row pre-pass + tiled form instead (gemm_x3t.hip).
+__device__ __forceinline__ void mfma_a(f32x16& acc, const bf16x8 w, const bf16x8 a) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, acc, 0, 0, 0);
+}
+
+template <int NC /* K / 16 */, int EPI>
+__global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(const XArgs p) {
+  constexpr int K = NC * 16, NK = NC / 2;                       // ring stages per n-tile
+  constexpr int NSTG = NC <= 8 ? 4 : 8, PDIST = NSTG - 1, PB = 4;   // PB: 1 KiB pieces of a stage per wave
+  constexpr bool GEGLU = EPI == KD_EPI_GEGLU;
+  constexpr int NCOL = GEGLU ? 64 : 128;
+  constexpr int NST = GEGLU ? 8 : 16;                           // 16-byte stores per lane per n-tile
+  constexpr int WAREA = (NSTG / 4) * STG;                       // row staging bytes per wave (the ring slots it borrows)
+  constexpr int RPR = WAREA / (K * 4) >= 32 ? 32 : WAREA / (K * 4);   // rows per staging round: 32 at K = 128 and 256
+  constexpr int NR = 32 / RPR, CPR = K / 4;                     // rounds; 16-byte chunks per row
+  constexpr int PIECES = RPR * CPR / 64;                        // 1 KiB pieces per round
+  constexpr int SCL = K * 4 < 1024 ? 1024 : K * 4;              // bytes of a wave's scale vector area
+  static_assert(NK % NSTG == 0 || NSTG % NK == 0, "ring slot of a stage must be a compile-time constant");
+  static_assert(RPR >= 16, "source-side chunk swizzle covers 16 rows");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const auto warm = code_warm_begin<16384>((int)blockIdx.x < p.warm && tid < 64);
+  // workgroup -> (row panel, n-split): the splits of one panel get ids 8 apart, i.e. the same XCD (one L2 fetches the panel's rows once)
+  int panel, split;
+  const int n_splits = p.n_splits, n_panels = gridDim.x / n_splits;
+  if ((n_panels & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    panel = (j / n_splits) * 8 + xcd;
+    split = j % n_splits;
+  } else {
+    panel = blockIdx.x % n_panels;
+    split = blockIdx.x / n_panels;
+  }
+  const int nt_begin = (int)((long)p.n_tiles * split / n_splits), nt_end = (int)((long)p.n_tiles * (split + 1) / n_splits);
+  const int n_tiles = nt_end - nt_begin, total = n_tiles * NK;
+  const int m0 = panel * 128;
+  const bool probe = p.clk && blockIdx.x == 0 && tid == 0;
+  if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
+
+  const char* wp = p.Wp + (size_t)nt_begin * NK * STG + wid * (PB * 1024) + lane * 16;
+  auto issue = [&](int s) {
+    const char* src = wp + (size_t)s * STG;
+    char* dst = smem + (s % NSTG) * STG + wid * (PB * 1024);
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+  };
+
+  // ---- this wave's 32 rows -> a_hi / a_lo: chunk c of the lane's row holds k = 16 c + 8 lh .. + 7 -----------------------------------
+  const int row = m0 + wid * 32 + l31;
+  const bool ok = row < p.M;
+  const int rowc = ok ? row : p.M - 1;
+  bf16x8 a_hi[NC], a_lo[NC];
+  float rs;
+  {
+    char* stage = smem + wid * WAREA;
+    char* scl = smem + NSTG * STG + wid * SCL;
+    const int r_first = min(m0 + wid * 32, p.M - 1), r_last = min(m0 + wid * 32 + 31, p.M - 1);
+    const bool uni = p.scale_stride == 0 || r_first / p.rows_per_sample == r_last / p.rows_per_sample;
+    if (uni) {     // the sample's scale vector -> LDS (K * 4 bytes; lanes past the vector re-read its start: a whole 1 KiB piece lands)
+      const char* ssrc = reinterpret_cast<const char*>(p.scale + (size_t)(r_first / p.rows_per_sample) * p.scale_stride);
+#pragma unroll
+      for (int i = 0; i < SCL / 1024; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc + (i * 1024 + lane * 16) % (K * 4)),
+                                         (__attribute__((address_space(3))) void*)(scl + i * 1024), 16, 0, 0);
+    }
+    const float* sp = p.scale + (size_t)(rowc / p.rows_per_sample) * p.scale_stride + 8 * lh;     // (not uni: straight from memory)
+    const float* spl = reinterpret_cast<const float*>(scl) + 8 * lh;
+    float ssq = 0.f;
+#pragma unroll 1
+    for (int r = 0; r < NR; ++r) {
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) {
+        const int ci = i * 64 + lane, rr = ci / CPR, qs = ci % CPR;
+        const int grow = min(m0 + wid * 32 + r * RPR + rr, p.M - 1);
+        const char* src = reinterpret_cast<const char*>(p.A + (size_t)grow * K) + ((qs ^ (rr & 15)) << 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + i * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // wave-private area: no barrier
+      if (NR == 1 || (l31 / RPR) == r) {
+        const int rr = l31 % RPR;
+        const char* rowp = stage + rr * (K * 4);
+#pragma unroll
+        for (int c0 = 0; c0 < NC; c0 += 4) {
+          f32x4 x0[4], x1[4], s0[4], s1[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int q = 4 * (c0 + u) + 2 * lh;
+            x0[u] = *reinterpret_cast<const f32x4*>(rowp + ((q ^ (rr & 15)) << 4));
+            x1[u] = *reinterpret_cast<const f32x4*>(rowp + (((q + 1) ^ (rr & 15)) << 4));
+            if (uni) {
+              s0[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
+              s1[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
+            } else {
+              s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
+              s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ssq = fmaf(x0[u][e], x0[u][e], fmaf(x1[u][e], x1[u][e], ssq));
+            u32x4 hi, lo;
+            split8(x0[u] * s0[u], x1[u] * s1[u], hi, lo);
+            asm volatile("" : "+v"(hi), "+v"(lo));     // materialise the fragments here (keeps x / scale registers short-lived)
+            a_hi[c0 + u] = __builtin_bit_cast(bf16x8, hi);
+            a_lo[c0 + u] = __builtin_bit_cast(bf16x8, lo);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (NR > 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the area is overwritten by the next round
+    }
+    ssq += __shfl_xor(ssq, 32, 64);
+    rs = rsqrtf(ssq / (float)K + p.eps);
+  }
+  float py = 0.f, px = 0.f;
+  if (EPI == KD_EPI_QKV) {
+    const int tok = rowc % p.rows_per_sample;
+    py = p.pos[2 * tok];
+    px = p.pos[2 * tok + 1];
+    asm volatile("" : "+v"(py), "+v"(px));            // consumed HERE as far as the compiler knows: its wait for the two loads lands before
+  }                                                   // the ring starts, not as a vmcnt(0) in the first epilogue
+  code_warm_end(warm);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  KD_BARRIER();                                        // every wave has taken its rows out of the slots it borrowed
+  const bool full_panel = m0 + 128 <= p.M;
+#pragma unroll
+  for (int s = 0; s < PDIST; ++s)
+    if (s < total) issue(s);
+  if (probe) p.clk[4] = __builtin_amdgcn_s_memtime();          // end of the row prologue
+
+  const int o0 = swz64(l31, lh), o1 = swz64(l31, 2 + lh);      // fragment offsets of the two 16-k chunks of a stage
+  float* crow = p.C + (size_t)rowc * p.N;
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  bf16x8 wh[2][4], wl[2][4];
+  auto read_frags = [&](int slot, int h, bf16x8 (&fh)[4], bf16x8 (&fl)[4]) {
+    const char* st = smem + slot * STG + (h ? o1 : o0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fh[j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 64);
+      fl[j] = *reinterpret_cast<const bf16x8*>(st + IMG + j * 32 * 64);
+    }
+  };
+  // stage 0 in: its first chunk's fragments
+  wait_vm(PB * min(PDIST - 1, total - 1));
+  KD_BARRIER();
+  read_frags(0, 0, wh[0], wl[0]);
+
+  for (int nt = 0; nt < n_tiles; ++nt) {
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const int s = nt * NK + ks;
+      // ---- chunk 0 of stage s (fragments in wh[0] / wl[0]); chunk 1's fragments requested first -------------------------------------
+      read_frags(ks % NSTG, 1, wh[1], wl[1]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mfma_a(acc[j], wl[0][j], a_hi[2 * ks]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mfma_a(acc[j], wh[0][j], a_lo[2 * ks]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mfma_a(acc[j], wh[0][j], a_hi[2 * ks]);
+      // issue order: ONE MFMA first, then the 8 fragment reads of the next chunk, then the other 11 MFMAs.  hipcc's wait for this
+      // chunk's fragments is an lgkmcnt(0) (it does not count across the stage's branches): in front of the first MFMA it only sees
+      // reads that have had 12 MFMAs to land; behind the new reads it would wait for them as well
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- stage s + 1 in (everyone is past stage s - 1: its slot is refilled), its first chunk's fragments requested ----------------
+      if (s + 1 < total) {
+        // behind stage s + 1 in this wave's queue: the stages requested after it and the stores of an epilogue that ran since its request
+        int allow = PB * min(PDIST - 2, total - 2 - s);
+        if (full_panel && nt > 0 && ks + 2 <= PDIST) allow += NST;
+        wait_vm(allow);
+        KD_BARRIER();
+        if (s + PDIST < total) issue(s + PDIST);
+      }
+      // (outside the branch: the same LDS operations on every path, so that hipcc's lgkmcnt bookkeeping stays exact and the wait in
+      // front of the next MFMAs is a counted one that leaves these 8 reads in flight; past the last stage the data is never used)
+      read_frags((ks + 1) % NSTG, 0, wh[0], wl[0]);
+      // ---- chunk 1 of stage s ------------------------------------------------------------------------------------------------------------
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mfma_a(acc[j], wl[1][j], a_hi[2 * ks + 1]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mfma_a(acc[j], wh[1][j], a_lo[2 * ks + 1]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mfma_a(acc[j], wh[1][j], a_hi[2 * ks + 1]);
+      // issue order: ONE MFMA first, then the 8 fragment reads of the next chunk, then the other 11 MFMAs.  hipcc's wait for this
+      // chunk's fragments is an lgkmcnt(0) (it does not count across the stage's branches): in front of the first MFMA it only sees
+      // reads that have had 12 MFMAs to land; behind the new reads it would wait for them as well
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (probe && nt == 0) p.clk[5] = __builtin_amdgcn_s_memtime();    // end of the first tile's K loop
+
+    // ---- epilogue of n-tile nt, in the lane that owns the row: features n0 + 32 j + 8 g + 4 lh + (0..3) per accumulator group g -------
+    const int n0 = (nt_begin + nt) * NCOL;
+    if (GEGLU) {
+      const float rsh = 0.5f * rs;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x2 a = geglu_pair(f32x2{acc[2 * jj][4 * g], acc[2 * jj][4 * g + 1]} * rsh, f32x2{acc[2 * jj + 1][4 * g], acc[2 * jj + 1][4 * g + 1]} * rs);
+          const f32x2 b = geglu_pair(f32x2{acc[2 * jj][4 * g + 2], acc[2 * jj][4 * g + 3]} * rsh, f32x2{acc[2 * jj + 1][4 * g + 2], acc[2 * jj + 1][4 * g + 3]} * rs);
+          if (ok) *reinterpret_cast<f32x4*>(crow + n0 + 32 * jj + 8 * g + 4 * lh) = f32x4{a.x, a.y, b.x, b.y};
+        }
+    } else if (EPI == KD_EPI_QKV) {
+#pragma unroll
+      for (int vv = 0; vv < 2; ++vv) {
+        const int vec = (n0 >> 6) + vv;                       // (q | k | v, head) vector index of these 64 columns
+        const int which = vec / p.n_heads, head = vec - which * p.n_heads;
+        f32x16& a0 = acc[2 * vv];
+        f32x16& a1 = acc[2 * vv + 1];
+        if (which < 2) {
+          // the head's 8 RoPE frequencies and its cosine-sim scale through the scalar cache (no vector load beside the LDS-DMA ring)
+          typedef float f32x8s __attribute__((ext_vector_type(8)));
+          f32x8s fq;
+          float qsc;
+          asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                       : "=s"(fq), "=s"(qsc) : "s"(p.freq + head * 8), "s"(p.qk_scale + head) : "memory");
+          float fr[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) fr[u] = lh ? fq[4 + u] : fq[u];
+          b16::qk_prep_blocks(a0, a1, rs, sqrtf(qsc), p.eps, py, px, fr);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { a0[r] *= rs; a1[r] *= rs; }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x16& a = jj ? a1 : a0;
+            f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+            if (p.qkv_packed) v = pack_split4(v);
+            if (ok) *reinterpret_cast<f32x4*>(crow + n0 + 64 * vv + 32 * jj + 8 * g + 4 * lh) = v;
+          }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]} * rs + p.out_add;
+          if (ok) *reinterpret_cast<f32x4*>(crow + n0 + 32 * j + 8 * g + 4 * lh) = v;
+        }
+    }
+    if (probe && nt == 0) p.clk[6] = __builtin_amdgcn_s_memtime();    // end of the first tile's epilogue
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  }
+  if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)total; }
+}
+
+unsigned long long* g_clk = nullptr;
+
+static int cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int NC, int EPI>
+static int launch(const XArgs& a0, const char* nm, double flops, double bytes, hipStream_t s) {
+  auto kern = gemm_x3_astat_kernel<NC, EPI>;
+  constexpr int K = NC * 16, NSTG = NC <= 8 ? 4 : 8;
+  constexpr int LDS = NSTG * STG + 4 * (K * 4 < 1024 ? 1024 : K * 4);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  // n-splits of a panel: every workgroup pays the row prologue (about one n-tile's K loop) and then its share of the n-tiles; the grid
+  // runs in ceil(workgroups / resident slots) rounds.  The divisor of n_tiles with the smallest rounds x (1 + tiles per split) wins
+  // (ties: fewer splits = fewer redundant prologues).
+  const int panels = (a0.M + 127) / 128, slots = (NC <= 8 ? 2 : 1) * cu_count();
+  int best = 1;
+  long best_cost = -1;
+  for (int sp = 1; sp <= a0.n_tiles; ++sp) {
+    if (a0.n_tiles % sp) continue;
+    const long rounds = ((long)panels * sp + slots - 1) / slots;
+    const long cost = rounds * (1 + a0.n_tiles / sp);
+    if (best_cost < 0 || cost < best_cost) { best = sp; best_cost = cost; }
+  }
+  const int forced = option("x3_splits", 0);
+  XArgs a = a0;
+  a.n_splits = forced > 0 && forced <= a0.n_tiles ? forced : best;
+  LaunchScope prof(nm, flops, bytes, s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(panels * a.n_splits)), dim3(256), LDS, s, a);
+  return check_launch("kd_gemm_f32(x3 astat)");
+}
+
+}  // namespace x3
+
+// Eligibility + dispatch (called by kd_gemm_f32 ahead of the round-1 A-stationary kernel).  Returns 1 if the descriptor was not taken.
+int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc) {
+  using namespace x3;
+  if (!option("x3", 1)) return 1;
+  if (d.precision != KD_PREC_SPLIT3 || d.a_mode != KD_A_PLAIN || !d.norm || !d.Wp || d.debug) return 1;
+  if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_QKV && d.epi != KD_EPI_GEGLU) return 1;
+  if (d.K != 128 && d.K != 256) return 1;
+  const int ncol = d.epi == KD_EPI_GEGLU ? 64 : 128;
+  if (d.N % ncol || d.M < 512 || d.rows_per_sample <= 0) return 1;
+  if (d.epi == KD_EPI_QKV && (!d.rope_pos || !d.rope_freq || (reinterpret_cast<uintptr_t>(d.rope_freq) & 31))) return 1;   // tables only: round-1 kernel
+  XArgs a{};
+  a.A = d.A; a.Wp = reinterpret_cast<const char*>(d.Wp); a.C = d.C;
+  a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample; a.eps = d.eps;
+  a.M = d.M; a.N = d.N; a.n_tiles = d.N / ncol; a.n_splits = 1;
+  a.n_heads = d.n_heads; a.qk_scale = d.qk_scale; a.pos = d.rope_pos; a.freq = d.rope_freq; a.qkv_packed = d.qkv_packed;
+  a.out_add = d.out_add;
+  a.warm = d.warm;
+  a.clk = g_clk;
+  const double n_eff = d.epi == KD_EPI_GEGLU ? 2.0 * d.N : (double)d.N;
+  const double flops = 2.0 * d.M * n_eff * d.K;
+  const double bytes = 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N);
+  char nm[96] = "gemm_x3_astat";
+  if (prof_on()) snprintf(nm, sizeof(nm), "gemm_x3_astat<e%d> M=%d N=%d K=%d", d.epi, d.M, d.N, d.K);
+#define KD_X3(NCV, EP) if (d.K == NCV * 16 && d.epi == EP) { *rc = launch<NCV, EP>(a, nm, flops, bytes, s); return 0; }
+  KD_X3(8, KD_EPI_STORE) KD_X3(8, KD_EPI_QKV) KD_X3(8, KD_EPI_GEGLU)
+  KD_X3(16, KD_EPI_STORE) KD_X3(16, KD_EPI_QKV) KD_X3(16, KD_EPI_GEGLU)
+#undef KD_X3
+  return 1;
+}
+
+void x3_set_clock_buffer(unsigned long long* p) { x3::g_clk = p; }
+
+}  // namespace kd
+
+KD_TEXT_PAD(gemm_x3)      // last function of this code object: kd_common.h, code warm-up

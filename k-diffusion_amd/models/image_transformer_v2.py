@@ -290,6 +290,8 @@ class _Plan:
                 d.qk_scale, d.rope_pos, d.rope_freq, d.n_heads = qk[0].data_ptr(), qk[1].data_ptr(), qk[2].data_ptr(), qk[3]
             elif qk is not None:
                 d.qk_scale, d.rope_cos, d.rope_sin, d.n_heads = qk[0].data_ptr(), qk[1].data_ptr(), qk[2].data_ptr(), qk[3]
+                if len(qk) >= 6:                                     # split3: positions / frequencies for the round-3 kernels (gemm_x3*.hip)
+                    d.rope_pos, d.rope_freq = qk[4].data_ptr(), qk[5].data_ptr()
             (self.keep if main else chain.keep).append(d)
             target.append(_Launch(lib.kd_gemm_bf16 if d.precision == nat.PREC_BF16 else lib.kd_gemm_f32, (C.byref(d),), what))
             return d
@@ -375,13 +377,19 @@ class _Plan:
                 else:
                     cos_t, sin_t = m._rope_tables(li, grids, sa, device)
                 self.keep += [cos_t, sin_t]
+                qk = (sa.scale, cos_t, sin_t, nh)
+                if precision == nat.PREC_SPLIT3:
+                    # the split3 projections of round 3 evaluate the angles like the bf16 ones (no table loads beside their LDS-DMA ring);
+                    # the tables stay for the round-1 kernels they fall back to (ragged shapes) and for the exact mode
+                    pos_t, freq_t = m._rope_pos_freq(li, grids, sa, device)
+                    self.keep += [pos_t, freq_t]
+                    qk += (pos_t, freq_t)
                 # q, k leave the qkv GEMM already prepared (cosine-sim scale + RoPE in its epilogue): every halo /
                 # window / key tile of the attention cores would otherwise redo that work per use
                 # ... and, for the split-bf16x3 cores, already SPLIT (hi / lo bf16 chunks in the fp32 slots): the cores take
                 # their operands as stored instead of converting every halo / window / key-block element again
                 dq = gemm(prefix + "qkv_proj", x, sa.qkv_proj.weight, qkv, T, 3 * d, d, epi=nat.EPI_QKV,
-                          scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps,
-                          qk=(sa.scale, cos_t, sin_t, nh))
+                          scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps, qk=qk)
                 dq.qkv_packed = 1 if packed_qkv else 0
                 prep = (2 if packed_qkv else 0, None, None, None, C.c_float(1e-6), precision)
                 shift = 0

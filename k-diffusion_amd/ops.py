@@ -114,6 +114,8 @@ def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scal
     elif qk is not None:        # EPI_QKV: (scale_h [nh], cos [T, nh, 16], sin [T, nh, 16], nh)
         d.qk_scale, d.rope_cos, d.rope_sin = (_chk(t, n).data_ptr() for t, n in zip(qk[:3], ("qk_scale", "cos", "sin")))
         d.n_heads = qk[3]
+        if len(qk) >= 6:        # + (rope_pos [T, 2], rope_freq [nh, 8] in revolutions): the round-3 split3 kernel evaluates the angles itself
+            d.rope_pos, d.rope_freq = _chk(qk[4], "rope_pos").data_ptr(), _chk(qk[5], "rope_freq").data_ptr()
         d.qkv_packed = 1 if qkv_packed else 0      # q, k, v stored as split-bf16 chunks for the attention cores (prep="packed")
     if bf:
         nat.check(nat.lib().kd_gemm_bf16(C.byref(d), _stream()), "kd_gemm_bf16")

@@ -658,6 +658,50 @@ def test_bf16_qkv_epilogue(ops, H, W, nh, B, K):
     assert relerr(qkv[..., 2, :, :], ref[..., 2, :, :]) < 1.2e-2
 
 
+@pytest.mark.parametrize("H,W,nh,B,K", [(64, 64, 2, 2, 128), (32, 32, 4, 2, 256), (32, 16, 4, 3, 256), (24, 24, 2, 1, 128), (20, 20, 2, 2, 128), (16, 16, 8, 4, 512)])
+def test_split3_projections_round3(KD, ops, monkeypatch, H, W, nh, B, K):
+    """The round-3 fp32-parity projections (gemm_x3.hip / gemm_x3t.hip: lane-owns-row epilogues, RoPE angles from positions /
+    frequencies, qkv operands stored split for the attention cores) against the oracle's separate steps, and against the
+    round-1 kernels they replace (option x3 = 0) at split-bf16x3 accuracy.  Full panels, ragged panels (24 x 24 tokens) and rows of
+    several samples inside one 128-row panel."""
+    from k_diffusion_amd import _native as nat
+    monkeypatch.setenv("KDIFF_GEMM", "split3")
+    T, d = H * W, nh * 64
+    x, scale = rn(B, T, K, seed=8), 1 + 0.2 * rn(B, K, seed=9)
+    w = rn(3 * d, K, seed=10, scale=K ** -0.5)
+    qs = torch.linspace(5.0, 12.0, nh)
+    pos, freqs = hdit.axial_pos(H, W).reshape(T, 2), hdit.rope_freqs(nh)
+    cos, sin = _tables(H, W, nh)
+    qk = (g(qs), g(cos), g(sin), nh, g(pos.contiguous()), g((freqs / (2 * np.pi)).contiguous()))
+    qkv = ops.norm_linear(g(x), g(scale), g(w), rows_per_sample=T, epi=nat.EPI_QKV, qk=qk).cpu().view(B, H, W, 3, nh, 64)
+    ref = (hdit.rms_norm(x, scale[:, None, :]) @ w.T).view(B, H, W, 3, nh, 64)
+    theta = hdit.rope_theta(hdit.axial_pos(H, W), freqs)
+    q_ref, k_ref = hdit.cosine_sim_scale(ref[..., 0, :, :], ref[..., 1, :, :], qs)
+    assert relerr(qkv[..., 0, :, :], hdit.apply_rope(q_ref, theta)) < 1e-4
+    assert relerr(qkv[..., 1, :, :], hdit.apply_rope(k_ref, theta)) < 1e-4
+    assert relerr(qkv[..., 2, :, :], ref[..., 2, :, :]) < 1e-4
+    # the split-stored form is the same numbers as (hi, hi, lo, lo) bf16 pairs
+    packed = ops.norm_linear(g(x), g(scale), g(w), rows_per_sample=T, epi=nat.EPI_QKV, qk=qk, qkv_packed=True)
+    pw = packed.view(torch.int32).view(-1, 4)
+    hi = torch.stack([(pw[:, 0] << 16), (pw[:, 0] & -65536), (pw[:, 1] << 16), (pw[:, 1] & -65536)], dim=1).view(torch.float32)
+    lo = torch.stack([(pw[:, 2] << 16), (pw[:, 2] & -65536), (pw[:, 3] << 16), (pw[:, 3] & -65536)], dim=1).view(torch.float32)
+    assert relerr((hi + lo).cpu().view_as(qkv), qkv) < 2.0 ** -15
+    # GEGLU and plain store
+    wg = rn(2 * 3 * K, K, seed=11, scale=K ** -0.5)
+    y = ops.norm_linear(g(x), g(scale), g(wg), rows_per_sample=T, epi=nat.EPI_GEGLU)
+    assert relerr(y, hdit.linear_geglu(hdit.rms_norm(x, scale[:, None, :]), wg)) < 1e-4
+    ws = rn(256, K, seed=12, scale=K ** -0.5)
+    y = ops.norm_linear(g(x), g(scale[0].contiguous()), g(ws), rows_per_sample=T)            # shared gain
+    assert relerr(y, hdit.rms_norm(x, scale[0]) @ ws.T) < 1e-4
+    # against the round-1 kernels
+    nat.set_option("x3", 0)
+    try:
+        old = ops.norm_linear(g(x), g(scale), g(w), rows_per_sample=T, epi=nat.EPI_QKV, qk=qk).cpu().view(B, H, W, 3, nh, 64)
+    finally:
+        nat.set_option("x3", 1)
+    assert relerr(qkv, old) < 1e-4 and (B * T < 512 or K >= 512 or not torch.equal(qkv, old))      # (another kernel really ran)
+
+
 def test_bf16_attention_cores(ops, golden):
     """bf16 global / window / neighbourhood cores against the reference's op goldens (prepared q, k) and the oracle."""
     o = golden["ops"]
