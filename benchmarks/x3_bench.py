@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Per-shape timing of the fp32-parity (split3) projections of the headline config through the C ABI, with the in-kernel time line of
+workgroup 0 (kd_prof_clock_buffer: prologue / first tile's K loop / its epilogue, shader clocks) and an A/B against the round-1
+kernels (option x3 = 0).     python benchmarks/x3_bench.py [iters]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["KDIFF_GEMM"] = "split3"
+import k_diffusion_amd as K  # noqa: E402
+from oracle import hdit  # noqa: E402
+
+nat, ops = K._native, K.ops
+dev = "cuda"
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+
+# (name, batch, H, W, nh, K, d_ff)
+LEVELS = [("L0", 32, 64, 64, 2, 128, 384), ("L1", 32, 32, 32, 4, 256, 768), ("L2", 32, 16, 16, 8, 512, 1536)]
+
+
+def timed(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def timeline(fn):
+    clk = torch.zeros(8, dtype=torch.int64, device=dev)
+    nat.lib().kd_prof_clock_buffer(C.c_void_p(clk.data_ptr()))
+    fn()
+    torch.cuda.synchronize()
+    nat.lib().kd_prof_clock_buffer(None)
+    c = clk.cpu().tolist()
+    if c[3] <= c[1] or not c[4]:
+        return ""
+    ghz = (c[2] - c[0]) / (c[3] - c[1]) * 0.1
+    return (f"  wg0 {c[2] - c[0]} clk @ {ghz:.2f} GHz: prologue {c[4] - c[0]}, tile0 K loop {c[5] - c[4]}, tile0 epilogue {c[6] - c[5]}, stages {c[7]}")
+
+
+for name, B, H, W, nh, Kd, dff in LEVELS:
+    T, d = H * W, nh * 64
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, T, Kd, generator=g).to(dev)
+    scale = (1 + 0.2 * torch.randn(B, Kd, generator=g)).to(dev)
+    wq = (torch.randn(3 * d, Kd, generator=g) * Kd ** -0.5).to(dev)
+    wg = (torch.randn(2 * dff, Kd, generator=g) * Kd ** -0.5).to(dev)
+    qs = torch.linspace(5.0, 12.0, nh).to(dev)
+    pos, freqs = hdit.axial_pos(H, W).reshape(T, 2), hdit.rope_freqs(nh)
+    theta = hdit.rope_theta(hdit.axial_pos(H, W), freqs).reshape(T, nh, 16)
+    qk = (qs, torch.cos(theta).to(dev), torch.sin(theta).to(dev), nh, pos.contiguous().to(dev), (freqs / (2 * np.pi)).contiguous().to(dev))
+    oq, og = torch.empty(B, T, 3 * d, device=dev), torch.empty(B, T, dff, device=dev)
+    cases = {
+        "qkv": lambda: ops.norm_linear(x, scale, wq, rows_per_sample=T, epi=nat.EPI_QKV, qk=qk, qkv_packed=True, out=oq),
+        "geglu": lambda: ops.norm_linear(x, scale, wg, rows_per_sample=T, epi=nat.EPI_GEGLU, out=og),
+    }
+    for cname, fn in cases.items():
+        nw = 3 * d if cname == "qkv" else 2 * dff
+        flops = 2.0 * B * T * nw * Kd
+        byts = 4.0 * (B * T * Kd + B * T * (3 * d if cname == "qkv" else dff))
+        line = f"{name} {cname:6s} M={B * T:6d} N={nw:4d} K={Kd:3d}"
+        for opt in (1, 0):
+            nat.set_option("x3", opt)
+            us = timed(fn)
+            line += f" | x3={opt}: {us:7.1f} us {flops / us * 1e-6:6.1f} TF/s (x3 executed {3 * flops / us * 1e-6 / 2500:.2f} of peak) {byts / us * 1e-3:5.0f} GB/s"
+            if opt == 1:
+                tl = timeline(fn)
+        nat.set_option("x3", 1)
+        print(line)
+        if tl:
+            print(tl)

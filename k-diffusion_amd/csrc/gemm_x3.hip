@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
   static_assert(NK % NSTG == 0 || NSTG % NK == 0, "ring slot of a stage must be a compile-time constant");
   static_assert(RPR >= 16, "source-side chunk swizzle covers 16 rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform, and provably so: LDS-DMA bases (M0) and W addresses stay scalar
   const auto warm = code_warm_begin<16384>((int)blockIdx.x < p.warm && tid < 64);
   // workgroup -> (row panel, n-split): the splits of one panel get ids 8 apart, i.e. the same XCD (one L2 fetches the panel's rows once)
   int panel, split;
@@ -103,20 +104,31 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
     panel = blockIdx.x % n_panels;
     split = blockIdx.x / n_panels;
   }
-  const int nt_begin = (int)((long)p.n_tiles * split / n_splits), nt_end = (int)((long)p.n_tiles * (split + 1) / n_splits);
+  // (integer division by a run-time value goes through the vector unit: hand the uniform results back to scalar registers, or every
+  // address and per-head constant derived from them is vector arithmetic, and the s_load operands below become waterfall loops)
+  panel = __builtin_amdgcn_readfirstlane(panel);
+  split = __builtin_amdgcn_readfirstlane(split);
+  const int nt_begin = __builtin_amdgcn_readfirstlane((int)((long)p.n_tiles * split / n_splits));
+  const int nt_end = __builtin_amdgcn_readfirstlane((int)((long)p.n_tiles * (split + 1) / n_splits));
   const int n_tiles = nt_end - nt_begin, total = n_tiles * NK;
   const int m0 = panel * 128;
   const bool probe = p.clk && blockIdx.x == 0 && tid == 0;
   if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
 
   const char* wp = p.Wp + (size_t)nt_begin * NK * STG + wid * (PB * 1024) + lane * 16;
-  auto issue = [&](int s) {
+  // stage s of this workgroup's W stream -> ring slot s % NSTG.  Stages past the end re-request the last one (into a slot nobody reads
+  // any more): every wave then issues exactly PB pieces per stage, which keeps the vmcnt arithmetic uniform and lets the requests sit
+  // INSIDE the MFMA group of a stage instead of behind a branch
+  auto issue_piece = [&](int s_, int j) {
+    const int s = min(s_, total - 1);
     const char* src = wp + (size_t)s * STG;
-    char* dst = smem + (s % NSTG) * STG + wid * (PB * 1024);
+    char* dst = smem + (s_ % NSTG) * STG + wid * (PB * 1024);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 1024),
+                                     (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+  };
+  auto issue = [&](int s_) {
 #pragma unroll
-    for (int j = 0; j < PB; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 1024),
-                                       (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+    for (int j = 0; j < PB; ++j) issue_piece(s_, j);
   };
 
   // ---- this wave's 32 rows -> a_hi / a_lo: chunk c of the lane's row holds k = 16 c + 8 lh .. + 7 -----------------------------------
@@ -191,6 +203,9 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
   }
   float py = 0.f, px = 0.f;
   if (EPI == KD_EPI_QKV) {
+    float* qk_tab = reinterpret_cast<float*>(smem + NSTG * STG + 4 * SCL + 4 * 2048);
+    if (tid < p.n_heads * 8) qk_tab[tid] = p.freq[tid];
+    if (tid < p.n_heads) qk_tab[128 + tid] = sqrtf(p.qk_scale[tid]);
     const int tok = rowc % p.rows_per_sample;
     py = p.pos[2 * tok];
     px = p.pos[2 * tok + 1];
@@ -201,12 +216,20 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
   KD_BARRIER();                                        // every wave has taken its rows out of the slots it borrowed
   const bool full_panel = m0 + 128 <= p.M;
 #pragma unroll
-  for (int s = 0; s < PDIST; ++s)
-    if (s < total) issue(s);
+  for (int s = 0; s < PDIST; ++s) issue(s);
   if (probe) p.clk[4] = __builtin_amdgcn_s_memtime();          // end of the row prologue
 
   const int o0 = swz64(l31, lh), o1 = swz64(l31, 2 + lh);      // fragment offsets of the two 16-k chunks of a stage
-  float* crow = p.C + (size_t)rowc * p.N;
+  char* strip = smem + NSTG * STG + 4 * SCL + wid * 2048;      // this wave's [32 rows][16 floats] store strip
+  const char* qkc = smem + NSTG * STG + 4 * SCL + 4 * 2048;    // [n_heads <= 16][8] RoPE frequencies, then [16] sqrt(cosine-sim scale)
+  float* st_row[2];                                            // the two rows this lane STORES (lane = 4 * row + 16-byte piece), + its piece
+  bool st_ok[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int r = m0 + wid * 32 + 16 * it + (lane >> 2);
+    st_ok[it] = r < p.M;
+    st_row[it] = p.C + (size_t)min(r, p.M - 1) * p.N + 4 * (lane & 3);
+  }
   f32x16 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -223,7 +246,7 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
     }
   };
   // stage 0 in: its first chunk's fragments
-  wait_vm(PB * min(PDIST - 1, total - 1));
+  wait_vm(PB * (PDIST - 1));
   KD_BARRIER();
   read_frags(0, 0, wh[0], wl[0]);
 
@@ -247,86 +270,118 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
       __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
       __builtin_amdgcn_sched_barrier(0);
       // ---- stage s + 1 in (everyone is past stage s - 1: its slot is refilled), its first chunk's fragments requested ----------------
-      if (s + 1 < total) {
-        // behind stage s + 1 in this wave's queue: the stages requested after it and the stores of an epilogue that ran since its request
-        int allow = PB * min(PDIST - 2, total - 2 - s);
+      {
+        // behind stage s + 1 in this wave's queue: the PDIST - 2 stages requested after it and the stores of an epilogue that ran since
+        // its request (stage s + 1 was requested in the middle of stage s + 1 - PDIST; tile nt - 1's epilogue ran after stage nt NK - 1)
+        int allow = PB * (PDIST - 2);
         if (full_panel && nt > 0 && ks + 2 <= PDIST) allow += NST;
         wait_vm(allow);
         KD_BARRIER();
-        if (s + PDIST < total) issue(s + PDIST);
       }
-      // (outside the branch: the same LDS operations on every path, so that hipcc's lgkmcnt bookkeeping stays exact and the wait in
-      // front of the next MFMAs is a counted one that leaves these 8 reads in flight; past the last stage the data is never used)
+      // ---- chunk 1 of stage s.  Issue order pinned block by block: one MFMA, the 8 fragment reads of the next stage's first chunk, then
+      // the 4 LDS-DMA requests of stage s + PDIST one at a time between the remaining MFMAs (an LDS-DMA instruction costs 60 - 180
+      // issue cycles: in MFMA shadows instead of in front of the group) --------------------------------------------------------------
+      mfma_a(acc[0], wl[1][0], a_hi[2 * ks + 1]);
       read_frags((ks + 1) % NSTG, 0, wh[0], wl[0]);
-      // ---- chunk 1 of stage s ------------------------------------------------------------------------------------------------------------
-#pragma unroll
-      for (int j = 0; j < 4; ++j) mfma_a(acc[j], wl[1][j], a_hi[2 * ks + 1]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) mfma_a(acc[j], wh[1][j], a_lo[2 * ks + 1]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) mfma_a(acc[j], wh[1][j], a_hi[2 * ks + 1]);
-      // issue order: ONE MFMA first, then the 8 fragment reads of the next chunk, then the other 11 MFMAs.  hipcc's wait for this
-      // chunk's fragments is an lgkmcnt(0) (it does not count across the stage's branches): in front of the first MFMA it only sees
-      // reads that have had 12 MFMAs to land; behind the new reads it would wait for them as well
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_a(acc[1], wl[1][1], a_hi[2 * ks + 1]);
+      mfma_a(acc[2], wl[1][2], a_hi[2 * ks + 1]);
+      issue_piece(s + PDIST, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_a(acc[3], wl[1][3], a_hi[2 * ks + 1]);
+      mfma_a(acc[0], wh[1][0], a_lo[2 * ks + 1]);
+      mfma_a(acc[1], wh[1][1], a_lo[2 * ks + 1]);
+      issue_piece(s + PDIST, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_a(acc[2], wh[1][2], a_lo[2 * ks + 1]);
+      mfma_a(acc[3], wh[1][3], a_lo[2 * ks + 1]);
+      mfma_a(acc[0], wh[1][0], a_hi[2 * ks + 1]);
+      issue_piece(s + PDIST, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_a(acc[1], wh[1][1], a_hi[2 * ks + 1]);
+      mfma_a(acc[2], wh[1][2], a_hi[2 * ks + 1]);
+      issue_piece(s + PDIST, 3);
+      mfma_a(acc[3], wh[1][3], a_hi[2 * ks + 1]);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (probe && nt == 0) p.clk[5] = __builtin_amdgcn_s_memtime();    // end of the first tile's K loop
 
     // ---- epilogue of n-tile nt, in the lane that owns the row: features n0 + 32 j + 8 g + 4 lh + (0..3) per accumulator group g -------
     const int n0 = (nt_begin + nt) * NCOL;
+    // One 32-feature block of the wave's 32 rows -> memory.  Stored straight from the accumulator layout a wave-instruction writes 32
+    // rows x 32 bytes: 64 separate 16-byte requests, and the epilogue waits on the address path (7 000 of a 16 000-clock tile at level 1,
+    // benchmarks/x3_bench.py time line).  Through a wave-private LDS strip ([32 rows][16 floats], two passes per block, chunk position
+    // XOR (row >> 2) & 1: conflict-free both ways) four consecutive lanes hold 64 contiguous bytes of ONE row, so an instruction writes
+    // 16 rows x 64 bytes as 16 requests.  LDS executes a wave's operations in order: no wait between the strip writes and reads.
+    auto store_block = [&](const f32x4 (&v)[4], int col) {
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg)
+          *reinterpret_cast<f32x4*>(strip + l31 * 64 + (((2 * gg + lh) ^ ((l31 >> 2) & 1)) << 4)) = v[2 * hb + gg];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int r16 = 16 * it + (lane >> 2), c = lane & 3;
+          const f32x4 o = *reinterpret_cast<const f32x4*>(strip + r16 * 64 + ((c ^ ((r16 >> 2) & 1)) << 4));
+          if (st_ok[it]) *reinterpret_cast<f32x4*>(st_row[it] + col + 16 * hb) = o;
+        }
+      }
+    };
     if (GEGLU) {
       const float rsh = 0.5f * rs;
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
+      for (int jj = 0; jj < 2; ++jj) {
+        f32x4 blk[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x2 a = geglu_pair(f32x2{acc[2 * jj][4 * g], acc[2 * jj][4 * g + 1]} * rsh, f32x2{acc[2 * jj + 1][4 * g], acc[2 * jj + 1][4 * g + 1]} * rs);
           const f32x2 b = geglu_pair(f32x2{acc[2 * jj][4 * g + 2], acc[2 * jj][4 * g + 3]} * rsh, f32x2{acc[2 * jj + 1][4 * g + 2], acc[2 * jj + 1][4 * g + 3]} * rs);
-          if (ok) *reinterpret_cast<f32x4*>(crow + n0 + 32 * jj + 8 * g + 4 * lh) = f32x4{a.x, a.y, b.x, b.y};
+          blk[g] = f32x4{a.x, a.y, b.x, b.y};
         }
+        store_block(blk, n0 + 32 * jj);
+      }
     } else if (EPI == KD_EPI_QKV) {
 #pragma unroll
       for (int vv = 0; vv < 2; ++vv) {
         const int vec = (n0 >> 6) + vv;                       // (q | k | v, head) vector index of these 64 columns
-        const int which = vec / p.n_heads, head = vec - which * p.n_heads;
+        const int which = vec >= 2 * p.n_heads ? 2 : (vec >= p.n_heads ? 1 : 0), head = vec - which * p.n_heads;     // (no division: scalar)
         f32x16& a0 = acc[2 * vv];
         f32x16& a1 = acc[2 * vv + 1];
         if (which < 2) {
-          // the head's 8 RoPE frequencies and its cosine-sim scale through the scalar cache (no vector load beside the LDS-DMA ring)
-          typedef float f32x8s __attribute__((ext_vector_type(8)));
-          f32x8s fq;
-          float qsc;
-          asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                       : "=s"(fq), "=s"(qsc) : "s"(p.freq + head * 8), "s"(p.qk_scale + head) : "memory");
-          float fr[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) fr[u] = lh ? fq[4 + u] : fq[u];
-          b16::qk_prep_blocks(a0, a1, rs, sqrtf(qsc), p.eps, py, px, fr);
+          // the head's RoPE frequencies (this lane's four: 4 lh ..) and sqrt(cosine-sim scale) from the table parked in LDS by the prologue:
+          // one ds_read_b128 + one ds_read_b32, no vector-memory load beside the LDS-DMA ring and no per-element selects
+          const f32x4 fv = *reinterpret_cast<const f32x4*>(qkc + (head * 8 + 4 * lh) * 4);
+          const float qsc = *reinterpret_cast<const float*>(qkc + 512 + head * 4);
+          const float fr[4] = {fv[0], fv[1], fv[2], fv[3]};
+          b16::qk_prep_blocks(a0, a1, rs, qsc, p.eps, py, px, fr);
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) { a0[r] *= rs; a1[r] *= rs; }
         }
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < 2; ++jj) {
+          f32x4 blk[4];
+          const f32x16& a = jj ? a1 : a0;
+          if (p.qkv_packed) {                   // (one uniform branch per block, not a select per element)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x16& a = jj ? a1 : a0;
-            f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
-            if (p.qkv_packed) v = pack_split4(v);
-            if (ok) *reinterpret_cast<f32x4*>(crow + n0 + 64 * vv + 32 * jj + 8 * g + 4 * lh) = v;
+            for (int g = 0; g < 4; ++g) blk[g] = pack_split4(f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]});
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) blk[g] = f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
           }
+          store_block(blk, n0 + 64 * vv + 32 * jj);
+        }
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
+        f32x4 blk[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 v = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]} * rs + p.out_add;
-          if (ok) *reinterpret_cast<f32x4*>(crow + n0 + 32 * j + 8 * g + 4 * lh) = v;
-        }
+        for (int g = 0; g < 4; ++g) blk[g] = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]} * rs + p.out_add;
+        store_block(blk, n0 + 32 * j);
+      }
     }
     if (probe && nt == 0) p.clk[6] = __builtin_amdgcn_s_memtime();    // end of the first tile's epilogue
 #pragma unroll
@@ -334,6 +389,7 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail requests still target this workgroup's LDS
   if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)total; }
 }
 
@@ -353,7 +409,7 @@ template <int NC, int EPI>
 static int launch(const XArgs& a0, const char* nm, double flops, double bytes, hipStream_t s) {
   auto kern = gemm_x3_astat_kernel<NC, EPI>;
   constexpr int K = NC * 16, NSTG = NC <= 8 ? 4 : 8;
-  constexpr int LDS = NSTG * STG + 4 * (K * 4 < 1024 ? 1024 : K * 4);
+  constexpr int LDS = NSTG * STG + 4 * (K * 4 < 1024 ? 1024 : K * 4) + 4 * 2048 + 1024;     // ring + scale vectors + store strips + per-head constants
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -390,7 +446,7 @@ int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc) {
   if (d.K != 128 && d.K != 256) return 1;
   const int ncol = d.epi == KD_EPI_GEGLU ? 64 : 128;
   if (d.N % ncol || d.M < 512 || d.rows_per_sample <= 0) return 1;
-  if (d.epi == KD_EPI_QKV && (!d.rope_pos || !d.rope_freq || (reinterpret_cast<uintptr_t>(d.rope_freq) & 31))) return 1;   // tables only: round-1 kernel
+  if (d.epi == KD_EPI_QKV && (!d.rope_pos || !d.rope_freq || d.n_heads > 16)) return 1;   // tables only / many heads: round-1 kernel
   XArgs a{};
   a.A = d.A; a.Wp = reinterpret_cast<const char*>(d.Wp); a.C = d.C;
   a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample; a.eps = d.eps;
