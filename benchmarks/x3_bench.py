@@ -64,6 +64,39 @@ for name, B, H, W, nh, Kd, dff in LEVELS:
         "qkv": lambda: ops.norm_linear(x, scale, wq, rows_per_sample=T, epi=nat.EPI_QKV, qk=qk, qkv_packed=True, out=oq),
         "geglu": lambda: ops.norm_linear(x, scale, wg, rows_per_sample=T, epi=nat.EPI_GEGLU, out=og),
     }
+    # the pre-split operand path: norm -> planes (one launch) + tiled GEMM (gemm_x3t.hip); down projection on hidden planes vs on fp32
+    xh, xl = ops.norm_split(x, scale, rows_per_sample=T)
+    hh, hl = (torch.empty(B, T, dff, device=dev, dtype=torch.bfloat16) for _ in range(2))
+    wd = (torch.randn(Kd, dff, generator=g) * dff ** -0.5).to(dev)
+    res, yo = torch.randn(B, T, Kd, generator=g).to(dev), torch.empty(B, T, Kd, device=dev)
+    hid32 = torch.randn(B, T, dff, generator=g).to(dev)
+
+    def qkv_tiled():
+        a = ops.norm_split(x, scale, rows_per_sample=T)
+        ops.gemm(None, wq, oq, M=B * T, N=3 * d, K=Kd, epi=nat.EPI_QKV, rows_per_sample=T, qk=qk, qkv_packed=True, a_planes=a)
+
+    def geglu_tiled():
+        a = ops.norm_split(x, scale, rows_per_sample=T)
+        ops.gemm(None, wg, None, M=B * T, N=dff, K=Kd, epi=nat.EPI_GEGLU, a_planes=a, c_planes=(hh, hl))
+    extra = {
+        "norm_split": (lambda: ops.norm_split(x, scale, rows_per_sample=T), 0.0, 8.0 * B * T * Kd),
+        "qkv tiled (+split)": (qkv_tiled, 2.0 * B * T * 3 * d * Kd, 4.0 * (B * T * Kd + B * T * 3 * d)),
+        "geglu tiled (+split)": (geglu_tiled, 2.0 * B * T * 2 * dff * Kd, 4.0 * (B * T * Kd + B * T * dff)),
+        "qkv tiled alone": (lambda: ops.gemm(None, wq, oq, M=B * T, N=3 * d, K=Kd, epi=nat.EPI_QKV, rows_per_sample=T, qk=qk, qkv_packed=True, a_planes=(xh, xl)),
+                            2.0 * B * T * 3 * d * Kd, 4.0 * (B * T * Kd + B * T * 3 * d)),
+        "geglu tiled alone": (lambda: ops.gemm(None, wg, None, M=B * T, N=dff, K=Kd, epi=nat.EPI_GEGLU, a_planes=(xh, xl), c_planes=(hh, hl)),
+                              2.0 * B * T * 2 * dff * Kd, 4.0 * (B * T * Kd + B * T * dff)),
+        "down planes": (lambda: ops.gemm(None, wd, yo, M=B * T, N=Kd, K=dff, epi=nat.EPI_RESIDUAL, residual=res, a_planes=(hh, hl)),
+                        2.0 * B * T * Kd * dff, 4.0 * (B * T * dff + 2 * B * T * Kd)),
+        "down fp32 (round 1)": (lambda: ops.gemm(hid32, wd, yo, M=B * T, N=Kd, K=dff, epi=nat.EPI_RESIDUAL, residual=res),
+                                2.0 * B * T * Kd * dff, 4.0 * (B * T * dff + 2 * B * T * Kd)),
+    }
+    if Kd <= 256:
+        extra["geglu fused -> planes"] = (lambda: ops.gemm(x, wg, None, M=B * T, N=dff, K=Kd, epi=nat.EPI_GEGLU, norm_scale=scale, scale_stride=Kd,
+                                                           rows_per_sample=T, c_planes=(hh, hl)), 2.0 * B * T * 2 * dff * Kd, 4.0 * (B * T * Kd + B * T * dff))
+    for ename, (fn, flops, byts) in extra.items():
+        us = timed(fn)
+        print(f"{name} {ename:22s} {us:7.1f} us {flops / us * 1e-6:6.1f} TF/s (x3 executed {3 * flops / us * 1e-6 / 2500:.2f} of peak) {byts / us * 1e-3:5.0f} GB/s")
     for cname, fn in cases.items():
         nw = 3 * d if cname == "qkv" else 2 * dff
         flops = 2.0 * B * T * nw * Kd

@@ -94,6 +94,14 @@ typedef struct {
                            split-bf16x3 attention cores, which then take it as stored (their prep = 2)        */
   const float* rope_pos;  /* kd_gemm_bf16 + KD_EPI_QKV: [rows_per_sample, 2] axial position (y, x) of every token       */
   const float* rope_freq; /* kd_gemm_bf16 + KD_EPI_QKV: [n_heads, 8] AxialRoPE freqs / (2 pi) (angles in revolutions); 32-byte aligned */
+  /* ---- KD_PREC_SPLIT3 with PRE-SPLIT operands (round 3; kd_gemm_f32 only, norm must be 0, a_mode KD_A_PLAIN) ---------------------
+   * a_split: A is not fp32 but two bf16 planes [M, K] (2 bytes per element): `A` = hi = bf16_rne(a), `A_lo` = bf16_rne(a - hi), as
+   *          written by kd_norm_split_f32 or by a producer GEMM with c_split.  Both operands then move by LDS-DMA (gemm_x3t.hip).
+   * c_split: the result is stored as two such planes ([M, N]: `C` = hi, `C_lo` = lo) instead of fp32 -- the A operand of the next
+   *          a_split GEMM (KD_EPI_GEGLU -> down projection).  Not with KD_EPI_QKV (its split form is qkv_packed).                 */
+  int a_split, c_split;
+  const void* A_lo;
+  void* C_lo;
   int per_row;          /* kd_gemm_f32, products with one row per SAMPLE (the conditioning chain): always use the per-row fp32 FMA
                            kernel, also above its 128-row default limit.  A row's result then does not depend on how many rows
                            share the launch, so the conditioning of a whole sigma schedule (steps x batch rows in one launch)
@@ -141,6 +149,13 @@ int kd_ffn_bf16(const KdFfn* desc, void* stream);
  * kernel's swizzled LDS order, zero-padded.  N is the OUTPUT width (GEGLU: d_ff, W has 2*d_ff rows). */
 long long kd_packed_weight_bytes(int N, int K, int geglu);
 int kd_pack_weight_bf16x3(const float* W, void* out, int N, int K, int geglu, void* stream);
+
+/* AdaRMSNorm / RMSNorm (image_transformer_v2.py:98-103, :155-166) of fp32 rows, written as the two bf16 planes of an a_split GEMM
+ * operand: y[m, :] = x[m, :] * (scale[b(m) * scale_stride + :] * rsqrt(mean(x[m, :]^2) + eps)), hi = bf16_rne(y), lo = bf16_rne(y - hi);
+ * b(m) = m / rows_per_sample.  scale == NULL: plain split of x (no norm).  K % 8 == 0, K <= 2048.  Used where a row's fragments do not
+ * fit the register file of the fused norm -> projection kernel (K = 512: the level-2 qkv / up projections of the headline config). */
+int kd_norm_split_f32(const float* x, const float* scale, int scale_stride, int rows_per_sample, void* hi, void* lo, int M, int K,
+                      float eps, void* stream);
 
 /* Stand-alone RMS norm over the last dim (mapping network, image_transformer_v2.py:142-152):
  * y[m,:] = x[m,:] * scale[:] * rsqrt(mean(x[m,:]^2) + eps).  d <= 4096, d % 4 == 0. */

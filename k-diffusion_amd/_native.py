@@ -47,6 +47,7 @@ class KdGemm(C.Structure):
         ("precision", C.c_int), ("Wp", C.c_void_p),
         ("n_heads", C.c_int), ("qk_scale", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
         ("qkv_packed", C.c_int), ("rope_pos", C.c_void_p), ("rope_freq", C.c_void_p),
+        ("a_split", C.c_int), ("c_split", C.c_int), ("A_lo", C.c_void_p), ("C_lo", C.c_void_p),
         ("per_row", C.c_int),
     ]
 
@@ -101,6 +102,7 @@ SIGNATURES = {
     "kd_brownian_f32": [_vp, _vp, _i, _ll, _d, _d, _d, _d, _f, _i, _vp],
     "kd_brownian_cached_f32": [_vp, _vp, _vp, _i, _i, _vp, _i, _ll, _d, _d, _d, _d, _f, _i, _vp],
     "kd_to_uint8": [_vp, _vp, _ll, _vp],
+    "kd_norm_split_f32": [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _f, _vp],
     "kd_prof_enable": [_i],
     "kd_prof_count": [],
     "kd_prof_get": [_i, C.c_char_p, _i, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double)],

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(QW * 64, (QW <= 4 && MODE != MODE_WINDOW16) ? 2 : 1
   constexpr int TP = NT * 32;
   char* Kimg = smem;
   char* Vimg = smem + TP * 128;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h2 = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h2 = lane >> 5;
   const auto warm = code_warm_begin<(MODE == MODE_WINDOW16 ? 16 : 10) * 1024>((int)blockIdx.x < a.warm && tid < 64);
   constexpr int NQB = (NT + QW - 1) / QW;            // query blocks per problem
   int r = blockIdx.x;
@@ -233,7 +233,7 @@ constexpr int GL_IMG = GL_KB * 128, GL_BUF = 2 * GL_IMG, GL_LDS = 2 * GL_BUF;
 
 __global__ __launch_bounds__(GL_QW * 64) void attn_long_bf16_kernel(const DArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h2 = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h2 = lane >> 5;
   const auto warm = code_warm_begin<6144>((int)blockIdx.x < a.warm && tid < 64);
   const int T = a.T, nqb = (T + GL_QW * 32 - 1) / (GL_QW * 32);
   int r = blockIdx.x;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, (NaGeo<KS>::LDS <= 80 * 1024) ? 2 : 1) void at
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kimg = smem;
   char* Vimg = smem + ROWS * 128;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h2 = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h2 = lane >> 5;
   const auto warm = code_warm_begin<7168>((int)blockIdx.x < a.warm && tid < 64);
   const int wy_ = wid >> 1, wx_ = wid & 1;
   const int tiles_x = (a.W + NA_TW - 1) / NA_TW, tiles_y = (a.H + NA_TH - 1) / NA_TH;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void attn_na2d_wide_bf16_kernel(const NArgs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kimg = smem;
   char* Vimg = smem + ROWS * 128;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h2 = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h2 = lane >> 5;
   const auto warm = code_warm_begin<24576>((int)blockIdx.x < a.warm && tid < 64);
   const int wy_ = wid >> 1, wx_ = wid & 1;
   const int tiles_x = (a.W + NA_TW - 1) / NA_TW, tiles_y = (a.H + NA_TH - 1) / NA_TH;

@@ -106,6 +106,13 @@ __device__ __forceinline__ void block_from_raw(u32x4 (&qq)[2], float (&r)[16]) {
   }
 }
 
+// lane half lh picks 4 of a head's 8 RoPE frequencies held in SCALAR registers (s_load).  Written as `lh ? f[4 + u] : f[u]` hipcc turns the
+// choice into an indexed extract from the 8-vector: seven v_cmp / v_cndmask pairs (plus their hazard s_nops) per element, 56 pairs per
+// head vector in every qkv epilogue.  As a bit select it is one v_bfi_b32 per element.
+__device__ __forceinline__ float pick_half(float f_lo, float f_hi, unsigned hi_mask /* 0 or ~0u */) {
+  return __uint_as_float((__float_as_uint(f_hi) & hi_mask) | (__float_as_uint(f_lo) & ~hi_mask));
+}
+
 // ---- q / k preparation of one 64-dim head vector held as two C-layout blocks (dims 0..31 in a0, 32..63 in a1) -----------
 // scale_for_cosine_sim (image_transformer_v2.py:106-114) + _apply_rotary_emb_inplace (:187-199) on the RAW accumulators of the
 // row (true value = acc * rs, rs = the RMS-norm row factor): q <- rope(acc * g), g = rs * sqrt(scale_h) * rsqrt(rs^2 * sum acc^2 + eps).

@@ -15,7 +15,7 @@
 //     are ALREADY the B operand of the down-projection: accumulator registers 8u .. 8u+7 of a 32-feature block are the 8 k-slots
 //     of lane-half lh for the hidden features {16u + 4 lh + 0..3, 16u + 8 + 4 lh + 0..3}.  The down-projection weight is packed
 //     with that k order inside every group of 16 (kd_pack_weight_bf16 layout 2), so its fragments stay one ds_read_b128;
-//   * epilogue: + x (re-read: the panel's rows are still in L2), bf16, 16-byte stores.
+//   * epilogue: + x (from the raw row chunks kept in registers, one half-wave exchange per dword pair), bf16, 16-byte stores.
 #include "bf16_common.h"
 
 namespace kd {
@@ -53,7 +53,8 @@ __global__ __launch_bounds__(FF_NW * 64) void ffn_kernel(const FArgs p) {
   constexpr int PCS = UNIT / 1024 / FF_NW;            // 1 KiB pieces per wave per tile
   static_assert(K % 128 == 0 && (UNIT / 1024) % FF_NW == 0, "unit = whole pieces per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wid = SKEW ? tid >> 6 : __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar branches on `late` cost the skewed variant 130 spilled registers)
   const auto warm = code_warm_begin<(SKEW ? 12 : 9) * 1024>((int)blockIdx.x < p.warm && tid < 64);     // kd_common.h
   const int row = blockIdx.x * (FF_NW * 32) + wid * 32 + l31;
   const bool ok = row < p.M;
@@ -187,14 +188,35 @@ __global__ __launch_bounds__(FF_NW * 64) void ffn_kernel(const FArgs p) {
   }
   if (probe) { p.clk[5] = __builtin_amdgcn_s_memtime(); p.clk[6] = p.clk[5]; }       // tiles done
   // ---- + skip, store -------------------------------------------------------------------------------------------------------------
-  const u16* xrow = p.X + (size_t)rowc * K;
+  // The skip operand is the row this lane read in the prologue: its raw bf16 chunks are still in registers, only in the B-operand
+  // order (chunk c: k = 16 c + 8 lh .. + 7) where the accumulators want the C-layout (features 8 g + 4 lh .. + 3 of a 32-block).
+  // One half-wave exchange per dword pair puts them there -- lanes 0-31 keep their first 4 k of a chunk and get the partner's first 4,
+  // lanes 32-63 get the partner's last 4 and keep their own -- instead of reading the row a second time (round 2 did: 94.8 MB per
+  // launch for 67 MB of algorithmic traffic, half of the re-reads missed L2).
   u16* yrow = p.Y + (size_t)rowc * K;
+  if (SKEW) {        // the skewed variant (on request only) has no registers to spare for the raw row: it reads it again
+    const u16* xrow = p.X + (size_t)rowc * K;
+#pragma unroll
+    for (int ob = 0; ob < KB; ++ob) {
+      float sk[16], v[16];
+      load_block_bf16(xrow + 32 * ob, sk, lh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc_o[ob][r] + sk[r];
+      store_block_bf16(yrow + 32 * ob, v, lh, ok);
+    }
+  } else
 #pragma unroll
   for (int ob = 0; ob < KB; ++ob) {
-    float sk[16], v[16];
-    load_block_bf16(xrow + 32 * ob, sk, lh);
+    float v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc_o[ob][r] + sk[r];
+    for (int cc = 0; cc < 2; ++cc) {
+      unsigned x0 = raw[2 * ob + cc][0], x1 = raw[2 * ob + cc][1], y0 = raw[2 * ob + cc][2], y1 = raw[2 * ob + cc][3];
+      half_swap(x0, y0);
+      half_swap(x1, y1);
+      const float sk[8] = {bf_lo(x0), bf_hi(x0), bf_lo(x1), bf_hi(x1), bf_lo(y0), bf_hi(y0), bf_lo(y1), bf_hi(y1)};
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[8 * cc + r] = acc_o[ob][8 * cc + r] + sk[r];
+    }
     store_block_bf16(yrow + 32 * ob, v, lh, ok);
   }
   if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)T; }
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(F2_NW * 64) void ffn256_kernel(const FArgs p) {
   constexpr int HU = 3 * WBLK;                        // half unit: 2 up-projection blocks + 1 down-projection block
   constexpr int PCS = HU / 1024 / F2_NW;              // 12 pieces per wave per half unit
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   const int row = blockIdx.x * (F2_NW * 32) + wid * 32 + l31;
   const bool ok = row < p.M;
   const int rowc = ok ? row : p.M - 1;

@@ -593,6 +593,7 @@ static int launch(const GemmP& d, hipStream_t s) {
 
 namespace kd { int gemm_astat_try(const GemmP& d, hipStream_t s, int* rc); }    // gemm_astat.hip
 namespace kd { int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc); }       // gemm_x3.hip
+namespace kd { int gemm_x3t_try(const GemmP& d, hipStream_t s, int* rc); }      // gemm_x3t.hip
 namespace kd { int gemm_skinny_try(const GemmP& d, hipStream_t s, int* rc); }   // gemm_skinny.hip
 
 using namespace kd;
@@ -616,6 +617,9 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
     return fail(KD_EINVAL, "kd_gemm_f32: qkv epilogue needs N == 3*n_heads*64, rows_per_sample, qk_scale, rope_cos, rope_sin");
   if (d.qkv_packed && (d.epi != KD_EPI_QKV || d.precision != KD_PREC_SPLIT3))
     return fail(KD_EINVAL, "kd_gemm_f32: qkv_packed needs the qkv epilogue and split3 precision");
+  if ((d.a_split || d.c_split) && d.precision != KD_PREC_SPLIT3) return fail(KD_EINVAL, "kd_gemm_f32: a_split / c_split are KD_PREC_SPLIT3 operand formats");
+  if (d.a_split && (d.norm || d.a_mode != KD_A_PLAIN || !d.A_lo)) return fail(KD_EINVAL, "kd_gemm_f32: a_split needs A_lo, a_mode KD_A_PLAIN and no norm prologue (kd_norm_split_f32 does the norm)");
+  if (d.c_split && !d.C_lo) return fail(KD_EINVAL, "kd_gemm_f32: c_split needs C_lo");
   GemmP e;
   static_cast<KdGemm&>(e) = d;
   e.debug = option("gemm_debug", 0);
@@ -624,6 +628,12 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
   // all rows of a 128-row tile share their scale vector: stage it in LDS once per tile
   e.scale_tab = e.norm && e.a_mode == KD_A_PLAIN && e.K <= SCALE_TAB_MAX_K && (e.scale_stride == 0 || e.rows_per_sample % BM == 0);
 
+  if (e.a_split) {
+    if (e.rows_per_sample <= 0) e.rows_per_sample = e.M;
+    int rc = 0;
+    if (!gemm_x3t_try(e, s, &rc)) return rc;
+    return fail(KD_EINVAL, "kd_gemm_f32: no kernel for pre-split A with epi=%d M=%d N=%d K=%d (K %% 32, N %% 128 (GEGLU: 64))", d.epi, d.M, d.N, d.K);
+  }
   {
     const bool skinny_on = option("skinny", 1) != 0;
     int rc = 0;
@@ -633,6 +643,7 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
     const bool astat_on = option("astat", 1) != 0;
     int rc = 0;
     if (astat_on && !gemm_x3_try(e, s, &rc)) return rc;        // norm -> wide projection, split3: round-3 A-stationary kernel (gemm_x3.hip)
+    if (e.c_split) return fail(KD_EINVAL, "kd_gemm_f32: c_split is produced by the GEGLU projections of gemm_x3.hip (K = 128 / 256, norm) and gemm_x3t.hip (a_split) only");
     if (astat_on && !gemm_astat_try(e, s, &rc)) return rc;     // ... and its round-1 predecessor (RoPE tables instead of positions; A/B runs)
   }
   if (e.precision != KD_PREC_EXACT && e.precision != KD_PREC_SPLIT3) return fail(KD_EINVAL, "kd_gemm_f32: unknown precision %d", e.precision);

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
                          : "=s"(fq), "=s"(qsc) : "s"(p.freq + head * 8), "s"(p.qk_scale + head) : "memory");
             float fr[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) fr[u] = lh ? fq[4 + u] : fq[u];
+            for (int u = 0; u < 4; ++u) fr[u] = pick_half(fq[u], fq[4 + u], 0u - (unsigned)lh);
             qk_prep_blocks(acc[2 * vv], acc[2 * vv + 1], rs, sqrtf(qsc), p.eps, py, px, fr);
           } else {
 #pragma unroll
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256 * BMT, (BMT == 1 && !DEEP) ? 2 : 1) void gemm_t
   constexpr int A_IMG = BMR * 128, STG = A_IMG + WBLK, NSTG = BMT == 1 ? (DEEP ? 4 : 2) : 3;
   constexpr int WPC = 16 / NWV;                      // weight pieces (1 KiB) per wave per step
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   const auto warm = code_warm_begin<(EPI == KD_EPI_SPLIT_LERP ? 6 : 4) * 1024>((int)blockIdx.x < p.warm && tid < 64);
   const int wc = wid & 1, wr = wid >> 1;
   int tile;
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_astat_kernel(
   constexpr int NCOL = GEGLU ? 64 : 128;
   constexpr int NST = GEGLU ? 4 : 8;                 // 16-byte stores per lane per n-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   const auto warm = code_warm_begin<(NC == 32 ? 26 : 16) * 1024>((int)blockIdx.x < p.warm && tid < 64);   // kd_common.h: this kernel's code -> L2
   // workgroup -> (row panel, n-split).  Workgroups go to the 8 XCDs round-robin by id: with the panel count a multiple of 8 the
   // splits of ONE panel are given ids 8 apart, i.e. they run on one XCD at about the same time and its L2 fetches the panel's rows
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void gemm_astat_kernel(
                        : "=s"(fq), "=s"(qsc) : "s"(p.freq + head * 8), "s"(p.qk_scale + head) : "memory");
           float fr[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) fr[u] = lh ? fq[4 + u] : fq[u];
+          for (int u = 0; u < 4; ++u) fr[u] = pick_half(fq[u], fq[4 + u], 0u - (unsigned)lh);
           qk_prep_blocks(acc[2 * vv], acc[2 * vv + 1], rs, sqrtf(qsc), p.eps, py, px, fr);
         } else {
 #pragma unroll
@@ -994,7 +994,7 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_bf16_kernel(const KdGemm 
   char* Aimg = smem;
   char* Wimg = smem + WBLK;
   float* rs_tab = reinterpret_cast<float*>(smem + 2 * WBLK);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   const int wc = wid & 1, wr = wid >> 1;
   const int n_tiles = (p.N + NCOL - 1) / NCOL;
   const int nt = blockIdx.x % n_tiles, mt = blockIdx.x / n_tiles;

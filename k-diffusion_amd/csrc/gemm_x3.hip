@@ -16,6 +16,7 @@
 //   * RoPE angles from the token's axial position and the head's frequencies (hardware sin / cos in revolutions) instead of cos / sin
 //     tables: no vector loads inside the ring loop (hipcc waits vmcnt(0) for an ordinary load issued beside LDS-DMA, draining the ring).
 #include "bf16_common.h"
+#include <utility>
 
 namespace kd {
 namespace x3 {
@@ -32,6 +33,7 @@ __device__ __forceinline__ int swz64(int row, int c) { return row * 64 + ((c ^ (
 
 struct XArgs {
   const float* A; const char* Wp; float* C;
+  b16::u16* Cl; int c_split;        // GEGLU: result as bf16 hi (C) / lo (Cl) planes for an a_split down projection (gemm_x3t.hip)
   const float* scale; int scale_stride, rows_per_sample; float eps;
   int M, N, n_tiles, n_splits;
   int n_heads; const float* qk_scale; const float* pos; const float* freq; int qkv_packed;
@@ -67,12 +69,39 @@ __device__ __forceinline__ f32x4 pack_split4(const f32x4 v) {
   return f32x4{__uint_as_float(h0), __uint_as_float(h1), __uint_as_float(l0), __uint_as_float(l1)};
 }
 
-// K = 512 is NOT served here: a lane's row would take 256 registers (hi + lo) next to 64 accumulators and the weight fragments, and
-// hipcc -- which will not park long-lived MFMA operands in the AccVGPR half of the file, with builtins or with "a"-constrained asm --
-// spills ~150 of them to scratch, whose reloads also sit in the vmcnt queue the ring's counted waits assume to be theirs.  Level 2 goes
-// through the row pre-pass + tiled form instead (gemm_x3t.hip).
+// (K = 512: a lane's row takes 256 registers (hi + lo) next to 64 accumulators and the weight fragments, and hipcc -- which will not park
+// long-lived MFMA operands in the AccVGPR half of the file, with builtins or with "a"-constrained asm -- spills ~150 of them to scratch, whose
+// reloads also sit in the vmcnt queue the ring's counted waits assume to be theirs.  That width uses the named-AccVGPR path below.)
 __device__ __forceinline__ void mfma_a(f32x16& acc, const bf16x8 w, const bf16x8 a) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, acc, 0, 0, 0);
+}
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
+
+// ---- K = 512: the activation fragments live in NAMED AccVGPRs ------------------------------------------------------------------------------
+// A lane's row takes 256 registers there (32 chunks x (hi + lo) x 4): exactly the AccVGPR half of the unified file, which leaves all 256
+// ArchVGPRs to accumulators, weight fragments and the prologue / epilogue arithmetic.  hipcc will not make that assignment itself (see the
+// note above mfma_a), so the kernel does it by hand: chunk c's hi fragment is a[8c .. 8c+3], its lo fragment a[8c+4 .. 8c+7], written with
+// v_accvgpr_write_b32 in the prologue and named literally as the B operand of asm MFMAs.  Every statement that writes them lists all 256
+// as clobbers (the compiler keeps nothing of its own there and the kernel descriptor allocates them); the build is audited for compiler
+// v_accvgpr_* / scratch use (csrc/Makefile: check_x3_agpr).  Asm MFMAs get no hazard padding from the compiler: accumulate chains need
+// none, the epilogue's first read of the accumulators is padded by hand.
+#define KD_A16(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+#define KD_AGPR_ALL                                                                                                                        \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", KD_A16(1), KD_A16(2), KD_A16(3), KD_A16(4), KD_A16(5), KD_A16(6), KD_A16(7),    \
+      KD_A16(8), KD_A16(9), KD_A16(10), KD_A16(11), KD_A16(12), KD_A16(13), KD_A16(14), KD_A16(15), KD_A16(16), KD_A16(17), KD_A16(18),       \
+      KD_A16(19), KD_A16(20), KD_A16(21), KD_A16(22), KD_A16(23), KD_A16(24), "a250", "a251", "a252", "a253", "a254", "a255"
+template <int IDX>
+__device__ __forceinline__ void areg_write4(const u32x4 v) {
+  asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
+               :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "i"(IDX), "i"(IDX + 1), "i"(IDX + 2), "i"(IDX + 3) : KD_AGPR_ALL);
+}
+template <int IDX>
+__device__ __forceinline__ void mfma_ag(f32x16& acc, const bf16x8 w) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(w), "i"(IDX), "i"(IDX + 3));
 }
 
 template <int NC /* K / 16 */, int EPI>
@@ -83,7 +112,8 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
   constexpr int NCOL = GEGLU ? 64 : 128;
   constexpr int NST = GEGLU ? 8 : 16;                           // 16-byte stores per lane per n-tile
   constexpr int WAREA = (NSTG / 4) * STG;                       // row staging bytes per wave (the ring slots it borrows)
-  constexpr int RPR = WAREA / (K * 4) >= 32 ? 32 : WAREA / (K * 4);   // rows per staging round: 32 at K = 128 and 256
+  constexpr int RPR = WAREA / (K * 4) >= 32 ? 32 : WAREA / (K * 4);   // rows per staging round: 32 at K = 128 and 256, 16 at K = 512
+  constexpr bool AG = NC >= 32;                                 // activation fragments in named AccVGPRs (see areg_write4)
   constexpr int NR = 32 / RPR, CPR = K / 4;                     // rounds; 16-byte chunks per row
   constexpr int PIECES = RPR * CPR / 64;                        // 1 KiB pieces per round
   constexpr int SCL = K * 4 < 1024 ? 1024 : K * 4;              // bytes of a wave's scale vector area
@@ -92,7 +122,7 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform, and provably so: LDS-DMA bases (M0) and W addresses stay scalar
-  const auto warm = code_warm_begin<16384>((int)blockIdx.x < p.warm && tid < 64);
+  const auto warm = code_warm_begin<(NC <= 8 ? 14 : 24) * 1024>((int)blockIdx.x < p.warm && tid < 64);
   // workgroup -> (row panel, n-split): the splits of one panel get ids 8 apart, i.e. the same XCD (one L2 fetches the panel's rows once)
   int panel, split;
   const int n_splits = p.n_splits, n_panels = gridDim.x / n_splits;
@@ -135,7 +165,7 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
   const int row = m0 + wid * 32 + l31;
   const bool ok = row < p.M;
   const int rowc = ok ? row : p.M - 1;
-  bf16x8 a_hi[NC], a_lo[NC];
+  bf16x8 a_hi[AG ? 1 : NC], a_lo[AG ? 1 : NC];
   float rs;
   {
     char* stage = smem + wid * WAREA;
@@ -166,8 +196,8 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
       if (NR == 1 || (l31 / RPR) == r) {
         const int rr = l31 % RPR;
         const char* rowp = stage + rr * (K * 4);
-#pragma unroll
-        for (int c0 = 0; c0 < NC; c0 += 4) {
+        static_for<NC / 4>([&](auto c4_) {
+          constexpr int c0 = 4 * decltype(c4_)::value;
           f32x4 x0[4], x1[4], s0[4], s1[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -183,18 +213,23 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
             }
           }
           __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          static_for<4>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
 #pragma unroll
             for (int e = 0; e < 4; ++e) ssq = fmaf(x0[u][e], x0[u][e], fmaf(x1[u][e], x1[u][e], ssq));
             u32x4 hi, lo;
             split8(x0[u] * s0[u], x1[u] * s1[u], hi, lo);
-            asm volatile("" : "+v"(hi), "+v"(lo));     // materialise the fragments here (keeps x / scale registers short-lived)
-            a_hi[c0 + u] = __builtin_bit_cast(bf16x8, hi);
-            a_lo[c0 + u] = __builtin_bit_cast(bf16x8, lo);
-          }
+            if constexpr (AG) {
+              areg_write4<8 * (c0 + u)>(hi);
+              areg_write4<8 * (c0 + u) + 4>(lo);
+            } else {
+              asm volatile("" : "+v"(hi), "+v"(lo));     // materialise the fragments here (keeps x / scale registers short-lived)
+              a_hi[c0 + u] = __builtin_bit_cast(bf16x8, hi);
+              a_lo[c0 + u] = __builtin_bit_cast(bf16x8, lo);
+            }
+          });
           __builtin_amdgcn_sched_barrier(0);
-        }
+        });
       }
       if (NR > 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the area is overwritten by the next round
     }
@@ -251,25 +286,44 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
   read_frags(0, 0, wh[0], wl[0]);
 
   for (int nt = 0; nt < n_tiles; ++nt) {
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
+    static_for<NK>([&](auto ks_) {
+      constexpr int ks = decltype(ks_)::value;
       const int s = nt * NK + ks;
-      // ---- chunk 0 of stage s (fragments in wh[0] / wl[0]); chunk 1's fragments requested first -------------------------------------
-      read_frags(ks % NSTG, 1, wh[1], wl[1]);
+      // acc[j] += W fragment (hi / lo of buffer b, block j) x activation fragment (hi / lo) of chunk 2 ks + b
+      auto mm = [&](auto b_, int j, bool w_lo, auto a_lo_) {
+        constexpr int b = decltype(b_)::value, al = decltype(a_lo_)::value, c = 2 * ks + b;
+        const bf16x8& w = w_lo ? wl[b][j] : wh[b][j];
+        if constexpr (AG) mfma_ag<8 * c + 4 * al>(acc[j], w);
+        else mfma_a(acc[j], w, al ? a_lo[c] : a_hi[c]);
+      };
+      constexpr std::integral_constant<int, 0> I0{};
+      constexpr std::integral_constant<int, 1> I1{};
+      // ---- chunk 0 of stage s (fragments in wh[0] / wl[0]): ONE MFMA, then the 8 fragment reads of chunk 1, then the other 11 MFMAs.
+      // hipcc's wait for this chunk's fragments is an lgkmcnt(0) (it does not count across the stage's branches): in front of the first
+      // MFMA it only sees reads that have had 12 MFMAs to land; behind the new reads it would wait for them as well --------------------
+      if constexpr (AG) {
+        mm(I0, 0, true, I0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(ks % NSTG, 1, wh[1], wl[1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mfma_a(acc[j], wl[0][j], a_hi[2 * ks]);
+        for (int j = 1; j < 4; ++j) mm(I0, j, true, I0);
+      } else {
+        read_frags(ks % NSTG, 1, wh[1], wl[1]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mfma_a(acc[j], wh[0][j], a_lo[2 * ks]);
+        for (int j = 0; j < 4; ++j) mm(I0, j, true, I0);
+      }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mfma_a(acc[j], wh[0][j], a_hi[2 * ks]);
-      // issue order: ONE MFMA first, then the 8 fragment reads of the next chunk, then the other 11 MFMAs.  hipcc's wait for this
-      // chunk's fragments is an lgkmcnt(0) (it does not count across the stage's branches): in front of the first MFMA it only sees
-      // reads that have had 12 MFMAs to land; behind the new reads it would wait for them as well
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+      for (int j = 0; j < 4; ++j) mm(I0, j, false, I1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mm(I0, j, false, I0);
+      if constexpr (!AG) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      // ---- stage s + 1 in (everyone is past stage s - 1: its slot is refilled), its first chunk's fragments requested ----------------
+      // ---- stage s + 1 in (everyone is past stage s - 1: its slot is refilled) -----------------------------------------------------------
       {
         // behind stage s + 1 in this wave's queue: the PDIST - 2 stages requested after it and the stores of an epilogue that ran since
         // its request (stage s + 1 was requested in the middle of stage s + 1 - PDIST; tile nt - 1's epilogue ran after stage nt NK - 1)
@@ -281,31 +335,36 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
       // ---- chunk 1 of stage s.  Issue order pinned block by block: one MFMA, the 8 fragment reads of the next stage's first chunk, then
       // the 4 LDS-DMA requests of stage s + PDIST one at a time between the remaining MFMAs (an LDS-DMA instruction costs 60 - 180
       // issue cycles: in MFMA shadows instead of in front of the group) --------------------------------------------------------------
-      mfma_a(acc[0], wl[1][0], a_hi[2 * ks + 1]);
+      mm(I1, 0, true, I0);
+      if constexpr (AG) __builtin_amdgcn_sched_barrier(0);
       read_frags((ks + 1) % NSTG, 0, wh[0], wl[0]);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      if constexpr (!AG) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      mfma_a(acc[1], wl[1][1], a_hi[2 * ks + 1]);
-      mfma_a(acc[2], wl[1][2], a_hi[2 * ks + 1]);
+      mm(I1, 1, true, I0);
+      mm(I1, 2, true, I0);
       issue_piece(s + PDIST, 0);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_a(acc[3], wl[1][3], a_hi[2 * ks + 1]);
-      mfma_a(acc[0], wh[1][0], a_lo[2 * ks + 1]);
-      mfma_a(acc[1], wh[1][1], a_lo[2 * ks + 1]);
+      mm(I1, 3, true, I0);
+      mm(I1, 0, false, I1);
+      mm(I1, 1, false, I1);
       issue_piece(s + PDIST, 1);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_a(acc[2], wh[1][2], a_lo[2 * ks + 1]);
-      mfma_a(acc[3], wh[1][3], a_lo[2 * ks + 1]);
-      mfma_a(acc[0], wh[1][0], a_hi[2 * ks + 1]);
+      mm(I1, 2, false, I1);
+      mm(I1, 3, false, I1);
+      mm(I1, 0, false, I0);
       issue_piece(s + PDIST, 2);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_a(acc[1], wh[1][1], a_hi[2 * ks + 1]);
-      mfma_a(acc[2], wh[1][2], a_hi[2 * ks + 1]);
+      mm(I1, 1, false, I0);
+      mm(I1, 2, false, I0);
       issue_piece(s + PDIST, 3);
-      mfma_a(acc[3], wh[1][3], a_hi[2 * ks + 1]);
+      mm(I1, 3, false, I0);
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
+    // asm MFMAs: 16-pass XDL write -> vector read of the accumulators needs 18 wait states the compiler does not know about
+    if constexpr (AG) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
     if (probe && nt == 0) p.clk[5] = __builtin_amdgcn_s_memtime();    // end of the first tile's K loop
 
     // ---- epilogue of n-tile nt, in the lane that owns the row: features n0 + 32 j + 8 g + 4 lh + (0..3) per accumulator group g -------
@@ -340,7 +399,26 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
           const f32x2 b = geglu_pair(f32x2{acc[2 * jj][4 * g + 2], acc[2 * jj][4 * g + 3]} * rsh, f32x2{acc[2 * jj + 1][4 * g + 2], acc[2 * jj + 1][4 * g + 3]} * rs);
           blk[g] = f32x4{a.x, a.y, b.x, b.y};
         }
-        store_block(blk, n0 + 32 * jj);
+        if (p.c_split) {            // (uniform branch) the down projection's A operand: bf16 hi / lo planes, 16-byte stores after a half-wave exchange
+          float v[16], hi[16], lo[16];
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[4 * g + q] = blk[g][q];
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const unsigned h = pack_bf16(v[r], v[r + 1]);
+            hi[r] = b16::bf_lo(h);
+            hi[r + 1] = b16::bf_hi(h);
+            lo[r] = v[r] - hi[r];
+            lo[r + 1] = v[r + 1] - hi[r + 1];
+          }
+          const size_t off = (size_t)rowc * p.N + n0 + 32 * jj;
+          b16::store_block_bf16(reinterpret_cast<b16::u16*>(p.C) + off, hi, lh, ok);
+          b16::store_block_bf16(p.Cl + off, lo, lh, ok);
+        } else {
+          store_block(blk, n0 + 32 * jj);
+        }
       }
     } else if (EPI == KD_EPI_QKV) {
 #pragma unroll
@@ -443,16 +521,18 @@ int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc) {
   if (!option("x3", 1)) return 1;
   if (d.precision != KD_PREC_SPLIT3 || d.a_mode != KD_A_PLAIN || !d.norm || !d.Wp || d.debug) return 1;
   if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_QKV && d.epi != KD_EPI_GEGLU) return 1;
-  if (d.K != 128 && d.K != 256) return 1;
+  if (d.K != 128 && d.K != 256 && d.K != 512) return 1;
   const int ncol = d.epi == KD_EPI_GEGLU ? 64 : 128;
   if (d.N % ncol || d.M < 512 || d.rows_per_sample <= 0) return 1;
   if (d.epi == KD_EPI_QKV && (!d.rope_pos || !d.rope_freq || d.n_heads > 16)) return 1;   // tables only / many heads: round-1 kernel
+  if (d.c_split && (d.epi != KD_EPI_GEGLU || !d.C_lo || (d.N & 31))) return 1;
   XArgs a{};
   a.A = d.A; a.Wp = reinterpret_cast<const char*>(d.Wp); a.C = d.C;
   a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample; a.eps = d.eps;
   a.M = d.M; a.N = d.N; a.n_tiles = d.N / ncol; a.n_splits = 1;
   a.n_heads = d.n_heads; a.qk_scale = d.qk_scale; a.pos = d.rope_pos; a.freq = d.rope_freq; a.qkv_packed = d.qkv_packed;
   a.out_add = d.out_add;
+  a.Cl = reinterpret_cast<b16::u16*>(d.C_lo); a.c_split = d.c_split;
   a.warm = d.warm;
   a.clk = g_clk;
   const double n_eff = d.epi == KD_EPI_GEGLU ? 2.0 * d.N : (double)d.N;
@@ -463,6 +543,7 @@ int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc) {
 #define KD_X3(NCV, EP) if (d.K == NCV * 16 && d.epi == EP) { *rc = launch<NCV, EP>(a, nm, flops, bytes, s); return 0; }
   KD_X3(8, KD_EPI_STORE) KD_X3(8, KD_EPI_QKV) KD_X3(8, KD_EPI_GEGLU)
   KD_X3(16, KD_EPI_STORE) KD_X3(16, KD_EPI_QKV) KD_X3(16, KD_EPI_GEGLU)
+  KD_X3(32, KD_EPI_STORE) KD_X3(32, KD_EPI_QKV) KD_X3(32, KD_EPI_GEGLU)
 #undef KD_X3
   return 1;
 }

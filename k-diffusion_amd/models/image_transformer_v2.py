@@ -246,6 +246,16 @@ class _Plan:
         qkv = torch.empty(max(t * 3 * lv.width for t, lv in zip(toks, levels)), **act)
         att = torch.empty(max(t * lv.width for t, lv in zip(toks, levels)), **act)
         hid = torch.empty(max(t * lv.d_ff for t, lv in zip(toks, levels)), **act)
+        # fp32-parity mode, round 3: GEMM operands that a producer can split once travel as two bf16 planes (hi, lo: the same bytes as
+        # fp32) and the consumer GEMM moves them by LDS-DMA (csrc/gemm_x3t.hip).  Planes of the FF hidden activation live in `hid`
+        # (hi in its first half, lo in the second); the normalised rows of the levels whose width exceeds the fused norm -> projection
+        # kernel's register budget (> 256) get planes of their own (`xn`, written by kd_norm_split_f32).
+        planes = precision == nat.PREC_SPLIT3 and os.environ.get("KDIFF_X3_PLANES", "1") != "0"
+        def prepass(width):                                  # widths the fused norm -> projection kernel (gemm_x3.hip) does not take
+            return planes and width not in (128, 256, 512) and width > 256 and width % 128 == 0 and width <= 2048    # (tiles of 128 features)
+        wide = [t * lv.width for t, lv in zip(toks, levels) if prepass(lv.width)]
+        xn = torch.empty(max(wide), **f32) if wide else None
+        self.keep.append(xn)
         norm_mods = m._ada_norm_modules()
         offsets, total = {}, 0
         for name, mod in norm_mods:
@@ -263,7 +273,8 @@ class _Plan:
         self.xs = xs
 
         def gemm(what, A, Wt, Cc, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, scale_ptr=None, scale_stride=0,
-                 rows_per_sample=0, R=None, grid=(0, 0), patch=(0, 0, 0), out_add=0.0, sigma=None, fac=None, qk=None):
+                 rows_per_sample=0, R=None, grid=(0, 0), patch=(0, 0, 0), out_add=0.0, sigma=None, fac=None, qk=None,
+                 a_planes=None, c_planes=None):
             d = nat.KdGemm()
             d.M, d.N, d.K, d.a_mode, d.epi = M, N, K, a_mode, epi
             main = target is self.launches
@@ -280,6 +291,10 @@ class _Plan:
             d.eps, d.out_add, d.sigma_data = 1e-6, out_add, 1.0
             d.A = None if A is None else A.data_ptr()
             d.W, d.C = Wt.data_ptr(), (None if Cc is None else Cc.data_ptr())
+            if a_planes is not None:                        # (hi address, lo address): pre-split bf16 planes instead of fp32 A
+                d.a_split, d.A, d.A_lo = 1, a_planes[0], a_planes[1]
+            if c_planes is not None:
+                d.c_split, d.C, d.C_lo = 1, c_planes[0], c_planes[1]
             d.R = None if R is None else R.data_ptr()
             d.scale = scale_ptr if not isinstance(scale_ptr, tuple) else None
             if isinstance(scale_ptr, tuple):                # ("table", byte offset): patched per run to the live scale table
@@ -361,6 +376,19 @@ class _Plan:
         def scale_ptr(name):
             return ("table", 4 * offsets[name])
 
+        class _ScaleRef:                                    # patched per run like the descriptors in norm_descs
+            scale = None
+
+        def norm_split(what, x_t, table_off, T_, d_, rps_):
+            """AdaRMSNorm of the fp32 rows of ``x_t`` -> (hi, lo) bf16 planes in ``xn`` (kd_norm_split_f32)."""
+            ref = _ScaleRef()
+            self.norm_descs.append((ref, table_off))
+            hi_p, lo_p = xn.data_ptr(), xn.data_ptr() + 2 * T_ * d_
+            xp = x_t.data_ptr()
+            target.append(_Launch(lambda stream, ref=ref: lib.kd_norm_split_f32(xp, ref.scale, total, rps_, hi_p, lo_p, T_, d_, 1e-6, stream),
+                                  (), what + " (split)"))
+            return (hi_p, lo_p)
+
         packed_qkv = precision == nat.PREC_SPLIT3 and os.environ.get("KDIFF_QKV_PACKED", "1") != "0"
 
         def add_layer(li, prefix, mod, index):
@@ -388,8 +416,14 @@ class _Plan:
                 # window / key tile of the attention cores would otherwise redo that work per use
                 # ... and, for the split-bf16x3 cores, already SPLIT (hi / lo bf16 chunks in the fp32 slots): the cores take
                 # their operands as stored instead of converting every halo / window / key-block element again
-                dq = gemm(prefix + "qkv_proj", x, sa.qkv_proj.weight, qkv, T, 3 * d, d, epi=nat.EPI_QKV,
-                          scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps, qk=qk)
+                if xn is not None and prepass(d):
+                    # AdaRMSNorm -> planes once, then a GEMM whose two operands both move by LDS-DMA
+                    xn_planes = norm_split(prefix + "self_attn.norm", x, scale_ptr(prefix + "self_attn.norm")[1], T, d, rps)
+                    dq = gemm(prefix + "qkv_proj", None, sa.qkv_proj.weight, qkv, T, 3 * d, d, epi=nat.EPI_QKV, rows_per_sample=rps, qk=qk,
+                              a_planes=xn_planes)
+                else:
+                    dq = gemm(prefix + "qkv_proj", x, sa.qkv_proj.weight, qkv, T, 3 * d, d, epi=nat.EPI_QKV,
+                              scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps, qk=qk)
                 dq.qkv_packed = 1 if packed_qkv else 0
                 prep = (2 if packed_qkv else 0, None, None, None, C.c_float(1e-6), precision)
                 shift = 0
@@ -420,9 +454,23 @@ class _Plan:
                 self.keep.append(fd)
                 target.append(_Launch(lib.kd_ffn_bf16, (C.byref(fd),), prefix + "ff"))
             else:
-                gemm(prefix + "up_proj", x, mod.ff.up_proj.weight, hid, T, lv.d_ff, d, epi=nat.EPI_GEGLU,
-                     scale_ptr=scale_ptr(prefix + "ff.norm"), scale_stride=total, rows_per_sample=rps)
-                gemm(prefix + "down_proj", hid, mod.ff.down_proj.weight, x, T, d, lv.d_ff, epi=nat.EPI_RESIDUAL, R=x)
+                # hidden activation as planes when the down projection's tiled form fills the chip (256-row x 128-feature tiles)
+                hid_planes = None
+                if planes and target is self.launches and d % 128 == 0 and lv.d_ff % 64 == 0 and d in (128, 256, 512) \
+                        and -(-T // 256) * (d // 128) >= 192 and os.environ.get("KDIFF_X3_DOWN", "0") == "1":     # measured level with the fp32 form: on request
+                    hid_planes = (hid.data_ptr(), hid.data_ptr() + 2 * T * lv.d_ff)
+                if xn is not None and target is self.launches and prepass(d) and lv.d_ff % 64 == 0:
+                    xn_planes = norm_split(prefix + "ff.norm", x, scale_ptr(prefix + "ff.norm")[1], T, d, rps)
+                    gemm(prefix + "up_proj", None, mod.ff.up_proj.weight, hid, T, lv.d_ff, d, epi=nat.EPI_GEGLU, a_planes=xn_planes,
+                         c_planes=hid_planes)
+                else:
+                    gemm(prefix + "up_proj", x, mod.ff.up_proj.weight, hid, T, lv.d_ff, d, epi=nat.EPI_GEGLU,
+                         scale_ptr=scale_ptr(prefix + "ff.norm"), scale_stride=total, rows_per_sample=rps,
+                         c_planes=hid_planes if (d in (128, 256) and T >= 512) else None)
+                    if not (d in (128, 256) and T >= 512):
+                        hid_planes = None
+                gemm(prefix + "down_proj", None if hid_planes else hid, mod.ff.down_proj.weight, x, T, d, lv.d_ff, epi=nat.EPI_RESIDUAL, R=x,
+                     a_planes=hid_planes)
 
         for li in range(n_lv - 1):
             for i, mod in enumerate(m.down_levels[li]):

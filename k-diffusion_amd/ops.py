@@ -79,12 +79,15 @@ def pack_weight(W, N, K, geglu, cache=True, bf16=False):
 
 def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scale=None, scale_stride=0,
          rows_per_sample=0, residual=None, grid=(0, 0), patch=(0, 0, 0), eps=1e-6, out_add=0.0,
-         sigma=None, sigma_data=1.0, fac=None, scale_ptr=None, precision=None, qk=None, qkv_packed=False, per_row=False):
+         sigma=None, sigma_data=1.0, fac=None, scale_ptr=None, precision=None, qk=None, qkv_packed=False, per_row=False,
+         a_planes=None, c_planes=None):
     """Fused GEMM (see KdGemm in include/kdiff_hip.h).  ``norm_scale`` may be a tensor or, with
     ``scale_ptr``, a raw device address inside a larger scale table.  ``precision``: nat.PREC_EXACT /
     nat.PREC_SPLIT3 / nat.PREC_BF16 (default: KDIFF_GEMM env, split3).  In bf16 mode A, out and residual are bf16 tensors
     (except the fp32 image side of the patch modes) and ``qk`` = (scale_h, rope_pos [T, 2], rope_freq [nh, 8], nh).
-    ``per_row`` (fp32 modes): the per-row FMA kernel of the conditioning chain whatever M (KdGemm.per_row)."""
+    ``per_row`` (fp32 modes): the per-row FMA kernel of the conditioning chain whatever M (KdGemm.per_row).
+    ``a_planes`` / ``c_planes`` (split3): (hi, lo) bf16 tensors instead of the fp32 ``A`` / ``out`` (KdGemm.a_split / c_split; ``A`` / ``out``
+    are then ignored and may be None)."""
     d = nat.KdGemm()
     d.per_row = 1 if per_row else 0
     d.precision = nat.default_precision() if precision is None else precision
@@ -103,7 +106,16 @@ def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scal
     d.gh, d.gw = grid
     d.ph, d.pw, d.chan = patch
     d.eps, d.out_add, d.sigma_data = eps, out_add, sigma_data
-    d.A, d.W, d.C = _chk(A, "A", a_dt).data_ptr(), _chk(W, "W").data_ptr(), _chk(out, "C", c_dt).data_ptr()
+    d.W = _chk(W, "W").data_ptr()
+    if a_planes is not None:
+        d.a_split, d.A, d.A_lo = 1, _chk(a_planes[0], "A hi", torch.bfloat16).data_ptr(), _chk(a_planes[1], "A lo", torch.bfloat16).data_ptr()
+    else:
+        d.A = _chk(A, "A", a_dt).data_ptr()
+    if c_planes is not None:
+        d.c_split, d.C, d.C_lo = 1, _chk(c_planes[0], "C hi", torch.bfloat16).data_ptr(), _chk(c_planes[1], "C lo", torch.bfloat16).data_ptr()
+        out = c_planes
+    else:
+        d.C = _chk(out, "C", c_dt).data_ptr()
     d.R = None if residual is None else _chk(residual, "R", c_dt).data_ptr()
     d.scale = scale_ptr if scale_ptr is not None else (None if norm_scale is None else _chk(norm_scale, "scale").data_ptr())
     d.sigma = None if sigma is None else _chk(sigma, "sigma").data_ptr()
@@ -149,6 +161,18 @@ def linear_geglu(x, weight, out=None):
     d_ff = weight.shape[0] // 2
     out = torch.empty(*x.shape[:-1], d_ff, device=x.device, dtype=x.dtype) if out is None else out
     return gemm(x, weight, out, M=M, N=d_ff, K=K, epi=nat.EPI_GEGLU, precision=_prec_of(x))
+
+
+def norm_split(x, scale=None, *, rows_per_sample=0, eps=1e-6):
+    """AdaRMSNorm / RMSNorm (:98-103, :155-166) of fp32 rows -> (hi, lo) bf16 planes, the A operand of an ``a_planes`` GEMM.
+    ``scale``: [B, K] per-sample, [K] shared, or None (plain split of ``x``)."""
+    K = x.shape[-1]
+    M = x.numel() // K
+    hi, lo = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16), torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    stride = 0 if scale is None or scale.dim() == 1 else K
+    nat.check(nat.lib().kd_norm_split_f32(_p(_chk(x, "x")), None if scale is None else _p(_chk(scale, "scale")), stride, rows_per_sample or M,
+                                          _p(hi), _p(lo), M, K, eps, _stream()), "kd_norm_split_f32")
+    return hi, lo
 
 
 def rms_norm(x, scale, eps=1e-6, out=None):

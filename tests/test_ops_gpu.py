@@ -693,6 +693,29 @@ def test_split3_projections_round3(KD, ops, monkeypatch, H, W, nh, B, K):
     ws = rn(256, K, seed=12, scale=K ** -0.5)
     y = ops.norm_linear(g(x), g(scale[0].contiguous()), g(ws), rows_per_sample=T)            # shared gain
     assert relerr(y, hdit.rms_norm(x, scale[0]) @ ws.T) < 1e-4
+    # the pre-split operand path (csrc/gemm_x3t.hip): norm -> bf16 hi / lo planes once, then GEMMs that move both operands by LDS-DMA
+    xh, xl = ops.norm_split(g(x), g(scale), rows_per_sample=T)
+    xn = hdit.rms_norm(x, scale[:, None, :])
+    assert torch.equal(xh.float().cpu(), xn.to(torch.bfloat16).float()) or relerr(xh.float(), xn) < 2.0 ** -8
+    assert relerr(xh.float().cpu() + xl.float().cpu(), xn) < 2.0 ** -15
+    o = torch.empty(B, T, 3 * d, device="cuda")
+    ops.gemm(None, g(w), o, M=B * T, N=3 * d, K=K, epi=nat.EPI_QKV, rows_per_sample=T, qk=qk, a_planes=(xh, xl))
+    assert relerr(o.cpu().view(B, H, W, 3, nh, 64), qkv) < 1e-4
+    hh, hl = torch.empty(B, T, 3 * K, device="cuda", dtype=torch.bfloat16), torch.empty(B, T, 3 * K, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(None, g(wg), None, M=B * T, N=3 * K, K=K, epi=nat.EPI_GEGLU, a_planes=(xh, xl), c_planes=(hh, hl))
+    hid_ref = hdit.linear_geglu(xn, wg)
+    assert relerr(hh.float().cpu() + hl.float().cpu(), hid_ref) < 1e-4
+    if K <= 256 and B * T >= 512:        # the fused norm -> GEGLU kernel writing planes itself
+        h2, l2 = torch.empty_like(hh), torch.empty_like(hl)
+        ops.gemm(g(x), g(wg), None, M=B * T, N=3 * K, K=K, epi=nat.EPI_GEGLU, norm_scale=g(scale), scale_stride=K, rows_per_sample=T, c_planes=(h2, l2))
+        assert relerr(h2.float().cpu() + l2.float().cpu(), hid_ref) < 1e-4
+    wd = rn(128, 3 * K, seed=13, scale=(3 * K) ** -0.5)
+    res = rn(B, T, 128, seed=14)
+    y = torch.empty(B, T, 128, device="cuda")
+    ops.gemm(None, g(wd), y, M=B * T, N=128, K=3 * K, epi=nat.EPI_RESIDUAL, residual=g(res), a_planes=(hh, hl))
+    assert relerr(y, hid_ref @ wd.T + res) < 1e-4
+    ops.gemm(None, g(wd), y, M=B * T, N=128, K=3 * K, a_planes=(hh, hl))
+    assert relerr(y, hid_ref @ wd.T) < 1e-4
     # against the round-1 kernels
     nat.set_option("x3", 0)
     try:
