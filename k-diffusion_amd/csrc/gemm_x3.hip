@@ -112,13 +112,16 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
   constexpr int NCOL = GEGLU ? 64 : 128;
   constexpr int NST = GEGLU ? 8 : 16;                           // 16-byte stores per lane per n-tile
   constexpr int WAREA = (NSTG / 4) * STG;                       // row staging bytes per wave (the ring slots it borrows)
-  constexpr int RPR = WAREA / (K * 4) >= 32 ? 32 : WAREA / (K * 4);   // rows per staging round: 32 at K = 128 and 256, 16 at K = 512
+  // staging rounds: ALL 32 rows of the wave, KH of their K floats per round (K = 512: two rounds of 256).  Every lane then converts
+  // its own row in every round; staging whole rows of half the lanes instead (round 3's first form) ran the conversion code twice with
+  // half the lanes masked: 23 000 clocks of prologue at K = 512 (benchmarks/x3_bench.py time line) against 9 000 at K = 256
+  constexpr int KH = WAREA / 128 >= K ? K : WAREA / 128;        // floats of a row per round: 128, 256, 256 at K = 128, 256, 512
   constexpr bool AG = NC >= 32;                                 // activation fragments in named AccVGPRs (see areg_write4)
-  constexpr int NR = 32 / RPR, CPR = K / 4;                     // rounds; 16-byte chunks per row
-  constexpr int PIECES = RPR * CPR / 64;                        // 1 KiB pieces per round
+  constexpr int NR = K / KH, CPR = KH / 4;                      // rounds; 16-byte chunks of a row per round
+  constexpr int PIECES = 32 * CPR / 64;                         // 1 KiB pieces per round
   constexpr int SCL = K * 4 < 1024 ? 1024 : K * 4;              // bytes of a wave's scale vector area
   static_assert(NK % NSTG == 0 || NSTG % NK == 0, "ring slot of a stage must be a compile-time constant");
-  static_assert(RPR >= 16, "source-side chunk swizzle covers 16 rows");
+  static_assert(CPR >= 16 && NC % NR == 0, "source-side chunk swizzle spans 16 chunk positions");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform, and provably so: LDS-DMA bases (M0) and W addresses stay scalar
@@ -182,57 +185,54 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
     const float* sp = p.scale + (size_t)(rowc / p.rows_per_sample) * p.scale_stride + 8 * lh;     // (not uni: straight from memory)
     const float* spl = reinterpret_cast<const float*>(scl) + 8 * lh;
     float ssq = 0.f;
-#pragma unroll 1
-    for (int r = 0; r < NR; ++r) {
+    static_for<NR>([&](auto r_) {
+      constexpr int r = decltype(r_)::value;
 #pragma unroll
       for (int i = 0; i < PIECES; ++i) {
         const int ci = i * 64 + lane, rr = ci / CPR, qs = ci % CPR;
-        const int grow = min(m0 + wid * 32 + r * RPR + rr, p.M - 1);
-        const char* src = reinterpret_cast<const char*>(p.A + (size_t)grow * K) + ((qs ^ (rr & 15)) << 4);
+        const int grow = min(m0 + wid * 32 + rr, p.M - 1);
+        const char* src = reinterpret_cast<const char*>(p.A + (size_t)grow * K + r * KH) + ((qs ^ (rr & 15)) << 4);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(stage + i * 1024), 16, 0, 0);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // wave-private area: no barrier
-      if (NR == 1 || (l31 / RPR) == r) {
-        const int rr = l31 % RPR;
-        const char* rowp = stage + rr * (K * 4);
-        static_for<NC / 4>([&](auto c4_) {
-          constexpr int c0 = 4 * decltype(c4_)::value;
-          f32x4 x0[4], x1[4], s0[4], s1[4];
+      const char* rowp = stage + l31 * (KH * 4);
+      static_for<NC / NR / 4>([&](auto c4_) {
+        constexpr int c0 = r * (NC / NR) + 4 * decltype(c4_)::value;       // first of four 16-k chunks of the row
+        f32x4 x0[4], x1[4], s0[4], s1[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int q = 4 * (c0 + u) + 2 * lh;
-            x0[u] = *reinterpret_cast<const f32x4*>(rowp + ((q ^ (rr & 15)) << 4));
-            x1[u] = *reinterpret_cast<const f32x4*>(rowp + (((q + 1) ^ (rr & 15)) << 4));
-            if (uni) {
-              s0[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
-              s1[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
-            } else {
-              s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
-              s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
-            }
+        for (int u = 0; u < 4; ++u) {
+          const int q = 4 * (c0 - r * (NC / NR) + u) + 2 * lh;             // 16-byte chunk inside this round's part of the row
+          x0[u] = *reinterpret_cast<const f32x4*>(rowp + ((q ^ (l31 & 15)) << 4));
+          x1[u] = *reinterpret_cast<const f32x4*>(rowp + (((q + 1) ^ (l31 & 15)) << 4));
+          if (uni) {
+            s0[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
+            s1[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
+          } else {
+            s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
+            s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
           }
-          __builtin_amdgcn_sched_barrier(0);
-          static_for<4>([&](auto u_) {
-            constexpr int u = decltype(u_)::value;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<4>([&](auto u_) {
+          constexpr int u = decltype(u_)::value;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ssq = fmaf(x0[u][e], x0[u][e], fmaf(x1[u][e], x1[u][e], ssq));
-            u32x4 hi, lo;
-            split8(x0[u] * s0[u], x1[u] * s1[u], hi, lo);
-            if constexpr (AG) {
-              areg_write4<8 * (c0 + u)>(hi);
-              areg_write4<8 * (c0 + u) + 4>(lo);
-            } else {
-              asm volatile("" : "+v"(hi), "+v"(lo));     // materialise the fragments here (keeps x / scale registers short-lived)
-              a_hi[c0 + u] = __builtin_bit_cast(bf16x8, hi);
-              a_lo[c0 + u] = __builtin_bit_cast(bf16x8, lo);
-            }
-          });
-          __builtin_amdgcn_sched_barrier(0);
+          for (int e = 0; e < 4; ++e) ssq = fmaf(x0[u][e], x0[u][e], fmaf(x1[u][e], x1[u][e], ssq));
+          u32x4 hi, lo;
+          split8(x0[u] * s0[u], x1[u] * s1[u], hi, lo);
+          if constexpr (AG) {
+            areg_write4<8 * (c0 + u)>(hi);
+            areg_write4<8 * (c0 + u) + 4>(lo);
+          } else {
+            asm volatile("" : "+v"(hi), "+v"(lo));     // materialise the fragments here (keeps x / scale registers short-lived)
+            a_hi[c0 + u] = __builtin_bit_cast(bf16x8, hi);
+            a_lo[c0 + u] = __builtin_bit_cast(bf16x8, lo);
+          }
         });
-      }
-      if (NR > 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the area is overwritten by the next round
-    }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (NR > 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the area is overwritten by the next round
+    });
     ssq += __shfl_xor(ssq, 32, 64);
     rs = rsqrtf(ssq / (float)K + p.eps);
   }
