@@ -129,9 +129,17 @@ def family_roofline(name, g, mode, total_ms):
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), **common,
                 "note": "algorithmic bytes (inputs once + outputs once at their storage width, DESIGN.md section 4) of every launch of this "
                         "family in the profiled pass / sum of their HIP-event durations"}
+    if mult > 1:
+        # fp32-parity kernels: one fp32 product = 3 bf16 MFMA terms, so the roof of THIS arithmetic is the bf16 dense peak / 3 (833 TFLOP/s
+        # of fp32-grade products; the fp32-input MFMA the dtype would otherwise use peaks at 157.3 TFLOP/s).  `frac` = achieved / that roof
+        # = the fraction of the matrix pipe's cycles the kernel keeps busy (mfma_executed_frac); against the raw bf16 peak: mfma_useful_frac
+        roof = peak / mult
+        return {"bound": "mfma", "achieved": round(tfl_alg, 2), "peak": round(roof, 1), "unit": "TFLOP/s", "frac": round(tfl_alg / roof, 4), **common,
+                "frac_of_f32_mfma_peak": round(tfl_alg / FP32_MFMA_PEAK_TFLOPS, 3),
+                "note": f"algorithmic matrix flops 2*M*N*K (fp32-grade products) / sum of HIP-event durations; peak = {peak:g} TFLOP/s dense bf16 MFMA / "
+                        f"{mult:g} MFMA terms per product (split-bf16x3); fp32-input MFMA peak {FP32_MFMA_PEAK_TFLOPS} TFLOP/s for comparison"}
     return {"bound": "mfma", "achieved": round(tfl_alg, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tfl_alg / peak, 4), **common,
-            "note": "algorithmic matrix flops 2*M*N*K / sum of HIP-event durations against the dense MFMA peak of the instruction issued"
-                    + (f"; the kernel executes {mult:g} MFMA products per algorithmic product (mfma_executed_frac)" if mult > 1 else "")}
+            "note": "algorithmic matrix flops 2*M*N*K / sum of HIP-event durations against the dense MFMA peak of the instruction issued"}
 
 
 def pmc_traffic(kernel_family):
