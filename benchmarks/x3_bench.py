@@ -94,9 +94,22 @@ for name, B, H, W, nh, Kd, dff in LEVELS:
     if Kd <= 256:
         extra["geglu fused -> planes"] = (lambda: ops.gemm(x, wg, None, M=B * T, N=dff, K=Kd, epi=nat.EPI_GEGLU, norm_scale=scale, scale_stride=Kd,
                                                            rows_per_sample=T, c_planes=(hh, hl)), 2.0 * B * T * 2 * dff * Kd, 4.0 * (B * T * Kd + B * T * dff))
+    if Kd <= 256:
+        wup2, wdn2 = wg, wd
+        xf = x.clone()
+        extra["ffn fused (x3)"] = (lambda: ops.ffn(xf, scale, wup2, wdn2, out=xf, rows_per_sample=T), 2.0 * B * T * 3 * dff * Kd, 8.0 * B * T * Kd)
+
+        def ffn_pair():
+            h = ops.norm_linear(x, scale, wg, rows_per_sample=T, epi=nat.EPI_GEGLU, out=og)
+            ops.gemm(h, wd, yo, M=B * T, N=Kd, K=dff, epi=nat.EPI_RESIDUAL, residual=res)
+        extra["ffn as two GEMMs"] = (ffn_pair, 2.0 * B * T * 3 * dff * Kd, 8.0 * B * T * Kd)
     for ename, (fn, flops, byts) in extra.items():
         us = timed(fn)
         print(f"{name} {ename:22s} {us:7.1f} us {flops / us * 1e-6:6.1f} TF/s (x3 executed {3 * flops / us * 1e-6 / 2500:.2f} of peak) {byts / us * 1e-3:5.0f} GB/s")
+        if ename.startswith("ffn fused"):
+            tl = timeline(fn)
+            if tl:
+                print(tl.replace("tile0 K loop", "tile0 up").replace("tile0 epilogue", "tile0 GEGLU + down"))
     for cname, fn in cases.items():
         nw = 3 * d if cname == "qkv" else 2 * dff
         flops = 2.0 * B * T * nw * Kd

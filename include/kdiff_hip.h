@@ -143,10 +143,18 @@ typedef struct KdFfn {
 } KdFfn;
 int kd_ffn_bf16_supported(int M, int K, int d_ff);
 int kd_ffn_bf16(const KdFfn* desc, void* stream);
+/* The same block in fp32-parity arithmetic (KD_PREC_SPLIT3: fp32 x / out, three split-bf16 MFMA terms per product, fp32 accumulate):
+ * Wp_up = kd_pack_weight_bf16x3(up_proj.weight, N = d_ff, K, geglu = 1), Wp_down = kd_pack_weight_bf16x3(down_proj.weight [K, d_ff],
+ * N = K, K = d_ff, geglu = 2).  K == 128 or 256, d_ff % 64 == 0; out may be x.  kd_ffn_f32_supported says where it is the faster form
+ * (M >= 2048; option "ffn_x3" = 0 answers no). */
+int kd_ffn_f32_supported(int M, int K, int d_ff);
+int kd_ffn_f32(const KdFfn* desc, void* stream);
 
-/* One-off packing of a weight for KD_PREC_SPLIT3 (weights are static during sampling): W [N or 2N (geglu), K]
+/* One-off packing of a weight for KD_PREC_SPLIT3 (weights are static during sampling): W [N or 2N (geglu == 1), K]
  * fp32 -> `out`, kd_packed_weight_bytes(N, K, geglu) bytes: [n-tile][k-step][hi|lo][128 rows][32 bf16] in the
- * kernel's swizzled LDS order, zero-padded.  N is the OUTPUT width (GEGLU: d_ff, W has 2*d_ff rows). */
+ * kernel's swizzled LDS order, zero-padded.  N is the OUTPUT width (GEGLU: d_ff, W has 2*d_ff rows).
+ * `geglu`: 0 plain, 1 GEGLU (value / gate rows interleaved per 32 outputs), 2 plain rows with the k order of kd_ffn_f32's down
+ * projection (inside every group of 16 k: 0-3, 8-11, 4-7, 12-15). */
 long long kd_packed_weight_bytes(int N, int K, int geglu);
 int kd_pack_weight_bf16x3(const float* W, void* out, int N, int K, int geglu, void* stream);
 

@@ -76,6 +76,8 @@ SIGNATURES = {
     "kd_pack_weight_bf16": [_vp, _vp, _i, _i, _i, _vp],
     "kd_ffn_bf16_supported": [_i, _i, _i],
     "kd_ffn_bf16": [_vp, _vp],
+    "kd_ffn_f32_supported": [_i, _i, _i],
+    "kd_ffn_f32": [_vp, _vp],
     "kd_attn_global_bf16": [_vp, _vp, _i, _i, _i, _vp],
     "kd_attn_window_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "kd_attn_na2d_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -4,7 +4,7 @@
 Those kernels keep a row's activation fragments in AccVGPRs a0..a255 that the kernel names literally inside inline asm.  That is only
 sound while the COMPILER keeps nothing of its own there and spills nothing (a spill reload is a vector-memory load inside the ring's
 counted vmcnt waits).  This script compiles the file to assembly and fails the build if, in any gemm_x3_astat_kernel<32, *>, an AccVGPR
-or a scratch access appears outside an ;;#ASMSTART / ;;#ASMEND block.
+or a scratch access appears outside an ;;#ASMSTART / ;;#ASMEND block (also every ffn_x3_kernel of ffn_x3.hip).
 
     python check_x3_agpr.py gemm_x3.hip
 """
@@ -26,7 +26,7 @@ def main(src):
     pos = [(m.start(), m.group(1)) for m in re.finditer(r"\n(_ZN2kd2x3[A-Za-z0-9_]+):", txt)]
     checked = 0
     for (st, name), (en, _) in zip(pos, pos[1:] + [(len(txt), "")]):
-        if "gemm_x3_astat_kernelILi32E" not in name:
+        if "gemm_x3_astat_kernelILi32E" not in name and "ffn_x3_kernel" not in name:
             continue
         body = txt[st:en].split(".end_amdhsa_kernel")[0]
         if not re.search(r"\.vgpr_spill_count:\s*0", txt[st:]) and "vgpr_spill_count" in txt[st:en]:
@@ -48,9 +48,10 @@ def main(src):
             raise SystemExit(f"check_x3_agpr: {name}: no asm MFMA found (did the kernel change?)")
         checked += 1
     if checked == 0:
-        raise SystemExit("check_x3_agpr: no K = 512 kernel found in " + src)
-    print(f"check_x3_agpr: {checked} K = 512 kernels: AccVGPRs a0..a255 are the kernel's alone, no scratch: ok")
+        raise SystemExit("check_x3_agpr: no named-AccVGPR kernel found in " + src)
+    print(f"check_x3_agpr: {os.path.basename(src)}: {checked} named-AccVGPR kernels: a0..a255 are the kernel's alone, no scratch: ok")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    for f in sys.argv[1:]:
+        main(f)

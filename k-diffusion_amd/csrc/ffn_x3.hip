@@ -1,0 +1,404 @@
+// Fused feed-forward block in fp32-parity ("split3") arithmetic:  out = x + down_proj( GEGLU( up_proj( AdaRMSNorm(x, cond) ) ) )
+// (image_transformer_v2.py:479-493; norm :155-166, LinearGEGLU :132-139 + :89-95, Linear :126-129).  fp32 activations in HBM, every product
+// as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation, and the d_ff-wide hidden activation never leaves the chip: as separate
+// kernels the level-0 block of the headline config writes and re-reads 2 x 201 MB of it per layer, next to 134 MB for x in and out.
+//
+// Built on the A-stationary projection of gemm_x3.hip (same prologue, same stage-pipelined K loop, same ring):
+//   * a 4-wave workgroup owns 128 rows; a lane owns ONE row: its normalised, scaled, split row (a_hi / a_lo) stays in registers
+//     (K = 128: 64 VGPRs; K = 256: the 128 AccVGPRs a0..a127, named by hand -- x3_common.h) for all of d_ff;
+//   * per 64-feature d_ff tile the packed weights stream through the LDS ring as 16 KiB stages: K / 32 stages of the up projection's
+//     GEGLU tile (32 value rows + 32 gate rows, twice), then 2 K / 128 stages of the down projection's k-steps for those 64 features
+//     (pack layout 2: inside a group of 16 the k order of the GEGLU accumulators, so its outputs ARE the down projection's B operand);
+//   * GEGLU in the lane that owns the row, split into hi / lo fragments in registers, then straight into the down projection's MFMAs;
+//   * the K-wide fp32 output accumulators of a row block live in named AccVGPRs for the whole kernel (64 at K = 128, 128 at K = 256):
+//     they are the C operand of asm MFMAs and never compete with the up projection's accumulators for ArchVGPRs;
+//   * epilogue: + x (re-read: 512 / 1024 bytes per row, the only second touch of x), fp32, through the wave's LDS strip.
+// One workgroup per CU (the register file is the wave's): the GEGLU phase of a tile (packed fp32 math, no MFMA in flight: v_pk_* beside
+// an MFMA costs 20 cycles each, profiles/r03_issue_model.md) is the only part of a tile the matrix pipe sits out.
+#include "x3_common.h"
+
+namespace kd {
+namespace x3 {
+
+struct FArgs3 {
+  const float* X; float* Y;
+  const char* Wu; const char* Wd;
+  const float* scale; int scale_stride, rows_per_sample; float eps;
+  int M, d_ff, n_tiles;
+  int warm;
+  unsigned long long* clk;
+};
+
+// acc_o block ob (32 output features) of this lane's row: AccVGPRs AO + 16 ob .. + 15
+template <int IDX>
+__device__ __forceinline__ void mfma_acc_ag(const bf16x8 w, const bf16x8 h) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(w), "v"(h), "i"(IDX), "i"(IDX + 15) : KD_AGPR_ALL);
+}
+template <int IDX>
+__device__ __forceinline__ void areg_zero16() {
+  static_for<16>([&](auto i_) { asm volatile("v_accvgpr_write_b32 a[%c0], 0" :: "i"(IDX + decltype(i_)::value) : KD_AGPR_ALL); });
+}
+template <int IDX>
+__device__ __forceinline__ f32x4 areg_read4() {
+  f32x4 v;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+               : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "i"(IDX), "i"(IDX + 1), "i"(IDX + 2), "i"(IDX + 3));
+  return v;
+}
+
+template <int NC /* K / 16: 8 or 16 */>
+__global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
+  constexpr int K = NC * 16, NKU = NC / 2;                      // ring stages of a tile's up projection
+  constexpr int NOB = K / 32, NKD = 2 * (K / 128);              // output blocks of a row; ring stages of a tile's down-projection k-steps
+  constexpr int UNIT = NKU + NKD;                               // stages per d_ff tile
+  constexpr int NSTG = 8, PDIST = NSTG - 1, PB = 4;
+  constexpr bool AG = NC >= 16;                                 // activation fragments in a0 .. a(8 NC - 1)
+  constexpr int AO = AG ? 8 * NC : 0;                           // first AccVGPR of the output accumulators
+  constexpr int WAREA = (NSTG / 4) * STG;
+  constexpr int KH = WAREA / 128 >= K ? K : WAREA / 128, NR = K / KH, CPR = KH / 4, PIECES = 32 * CPR / 64;
+  constexpr int SCL = K * 4 < 1024 ? 1024 : K * 4;
+  static_assert(NR == 1 && (K == 128 || K == 256), "widths 128 and 256");
+  static_assert(UNIT <= 2 * NSTG, "slot arithmetic below assumes at most two trips round the ring per tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const auto warm = code_warm_begin<(NC <= 8 ? 16 : 28) * 1024>((int)blockIdx.x < p.warm && tid < 64);
+  const int m0 = blockIdx.x * 128;
+  const int T = p.n_tiles, total = T * UNIT;
+  const bool probe = p.clk && blockIdx.x == 0 && tid == 0;
+  if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
+
+  // The weight stream: tile t contributes UNIT stages -- u < NKU: up block (t, u); else down block (n-tile (u - NKU) / 2, k-step
+  // 2 t + (u - NKU) % 2).  Stage (t, u) sits in ring slot (t UNIT + u) % NSTG.  Requests past the end re-request the last stage (uniform
+  // 4 pieces per wave per stage: gemm_x3.hip).  `off` (compile-time where it matters) is relative to tile t's first stage, so that no
+  // run-time division is needed.
+  auto issue_rel = [&](int t, int off, int j) {
+    int tt = t + off / UNIT, u = off % UNIT;
+    if (tt >= T) { tt = T - 1; u = UNIT - 1; }
+    const char* src = (u < NKU ? p.Wu + ((size_t)tt * NKU + u) * STG
+                               : p.Wd + ((size_t)((u - NKU) >> 1) * (2 * T) + 2 * tt + ((u - NKU) & 1)) * STG) + wid * (PB * 1024) + lane * 16;
+    char* dst = smem + ((t * UNIT + off) % NSTG) * STG + wid * (PB * 1024);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 1024),
+                                     (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+  };
+
+  // ---- this wave's 32 rows -> a_hi / a_lo (the prologue of gemm_x3.hip) ---------------------------------------------------------------
+  const int row = m0 + wid * 32 + l31;
+  const bool ok = row < p.M;
+  const int rowc = ok ? row : p.M - 1;
+  bf16x8 a_hi[AG ? 1 : NC], a_lo[AG ? 1 : NC];
+  float rs;
+  {
+    char* stage = smem + wid * WAREA;
+    char* scl = smem + NSTG * STG + wid * SCL;
+    const int r_first = min(m0 + wid * 32, p.M - 1), r_last = min(m0 + wid * 32 + 31, p.M - 1);
+    const bool uni = p.scale_stride == 0 || r_first / p.rows_per_sample == r_last / p.rows_per_sample;
+    if (uni) {
+      const char* ssrc = reinterpret_cast<const char*>(p.scale + (size_t)(r_first / p.rows_per_sample) * p.scale_stride);
+#pragma unroll
+      for (int i = 0; i < SCL / 1024; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc + (i * 1024 + lane * 16) % (K * 4)),
+                                         (__attribute__((address_space(3))) void*)(scl + i * 1024), 16, 0, 0);
+    }
+    const float* sp = p.scale + (size_t)(rowc / p.rows_per_sample) * p.scale_stride + 8 * lh;
+    const float* spl = reinterpret_cast<const float*>(scl) + 8 * lh;
+    float ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int ci = i * 64 + lane, rr = ci / CPR, qs = ci % CPR;
+      const int grow = min(m0 + wid * 32 + rr, p.M - 1);
+      const char* src = reinterpret_cast<const char*>(p.X + (size_t)grow * K) + ((qs ^ (rr & 15)) << 4);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(stage + i * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* rowp = stage + l31 * (KH * 4);
+    static_for<NC / 4>([&](auto c4_) {
+      constexpr int c0 = 4 * decltype(c4_)::value;
+      f32x4 x0[4], x1[4], s0[4], s1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = 4 * (c0 + u) + 2 * lh;
+        x0[u] = *reinterpret_cast<const f32x4*>(rowp + ((q ^ (l31 & 15)) << 4));
+        x1[u] = *reinterpret_cast<const f32x4*>(rowp + (((q + 1) ^ (l31 & 15)) << 4));
+        if (uni) {
+          s0[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
+          s1[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
+        } else {
+          s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
+          s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<4>([&](auto u_) {
+        constexpr int u = decltype(u_)::value;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ssq = fmaf(x0[u][e], x0[u][e], fmaf(x1[u][e], x1[u][e], ssq));
+        u32x4 hi, lo;
+        split8(x0[u] * s0[u], x1[u] * s1[u], hi, lo);
+        if constexpr (AG) {
+          areg_write4<8 * (c0 + u)>(hi);
+          areg_write4<8 * (c0 + u) + 4>(lo);
+        } else {
+          asm volatile("" : "+v"(hi), "+v"(lo));
+          a_hi[c0 + u] = __builtin_bit_cast(bf16x8, hi);
+          a_lo[c0 + u] = __builtin_bit_cast(bf16x8, lo);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    ssq += __shfl_xor(ssq, 32, 64);
+    rs = rsqrtf(ssq / (float)K + p.eps);
+  }
+  static_for<NOB>([&](auto ob_) { areg_zero16<AO + 16 * decltype(ob_)::value>(); });
+  code_warm_end(warm);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  KD_BARRIER();                                        // every wave has taken its rows out of the slots it borrowed
+#pragma unroll
+  for (int s = 0; s < PDIST; ++s)
+#pragma unroll
+    for (int j = 0; j < PB; ++j) issue_rel(0, s, j);
+  if (probe) p.clk[4] = __builtin_amdgcn_s_memtime();
+
+  const int o0 = swz64(l31, lh), o1 = swz64(l31, 2 + lh);
+  const float rsh = 0.5f * rs;
+  f32x16 acc[4];
+  bf16x8 wh[2][4], wl[2][4];
+  auto read_frags = [&](int slot, int h, bf16x8 (&fh)[4], bf16x8 (&fl)[4]) {
+    const char* st = smem + slot * STG + (h ? o1 : o0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fh[j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 64);
+      fl[j] = *reinterpret_cast<const bf16x8*>(st + IMG + j * 32 * 64);
+    }
+  };
+  // stage s in (its slot's pieces landed for every wave) and stage s - 1's slot released: the wait + barrier in the MIDDLE of a stage
+  auto next_stage_in = [&]() {
+    wait_vm(PB * (PDIST - 2));                        // behind stage s + 1: the PDIST - 2 stages requested after it (no stores until the end)
+    KD_BARRIER();
+  };
+  wait_vm(PB * (PDIST - 1));
+  KD_BARRIER();
+  read_frags(0, 0, wh[0], wl[0]);
+
+  for (int t = 0; t < T; ++t) {
+    const int sbase = t * UNIT;
+    const int slot0 = sbase % NSTG;                   // ring slot of the tile's first stage (UNIT is not a multiple of NSTG at K = 128)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // v_mov -> SrcC of an asm MFMA: the compiler pads that hazard for its own MFMAs only (tile 0's first MFMA read two stale registers)
+    asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    // ================= up projection of tile t: value / gate accumulators of its 2 x 32 hidden features (K / 32 stages) =================
+    static_for<NKU>([&](auto ks_) {
+      constexpr int ks = decltype(ks_)::value;
+      const int slot = (slot0 + ks) % NSTG, nslot = (slot0 + ks + 1) % NSTG;
+      auto mm = [&](auto b_, int j, bool w_lo, auto a_lo_) {
+        constexpr int b = decltype(b_)::value, al = decltype(a_lo_)::value, c = 2 * ks + b;
+        const bf16x8& w = w_lo ? wl[b][j] : wh[b][j];
+        if constexpr (AG) mfma_ag<8 * c + 4 * al>(acc[j], w);
+        else mfma_vv(acc[j], w, al ? a_lo[c] : a_hi[c]);      // (asm: the accumulators must stay out of the AccVGPRs this kernel names)
+      };
+      constexpr std::integral_constant<int, 0> I0{};
+      constexpr std::integral_constant<int, 1> I1{};
+      mm(I0, 0, true, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(slot, 1, wh[1], wl[1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 1; j < 4; ++j) mm(I0, j, true, I0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mm(I0, j, false, I1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mm(I0, j, false, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      next_stage_in();
+      mm(I1, 0, true, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(nslot, 0, wh[0], wl[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I1, 1, true, I0);
+      mm(I1, 2, true, I0);
+      issue_rel(t, ks + PDIST, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I1, 3, true, I0);
+      mm(I1, 0, false, I1);
+      mm(I1, 1, false, I1);
+      issue_rel(t, ks + PDIST, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I1, 2, false, I1);
+      mm(I1, 3, false, I1);
+      mm(I1, 0, false, I0);
+      issue_rel(t, ks + PDIST, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I1, 1, false, I0);
+      mm(I1, 2, false, I0);
+      issue_rel(t, ks + PDIST, 3);
+      mm(I1, 3, false, I0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));      // asm MFMA results -> vector reads
+    if (probe && t == 0) p.clk[5] = __builtin_amdgcn_s_memtime();
+
+    // ================= GEGLU in the lane that owns the row -> hi / lo B-operand fragments of the 4 hidden 16-chunks ======================
+    // chunk c' = 2 jj + (g >> 1) of the tile; the lane's 8 values of it are accumulator registers 8 (c' & 1) .. + 7 of blocks (2 jj, 2 jj + 1),
+    // i.e. hidden features 16 c' + 8 (e >> 2) + 4 lh + (e & 3): pack layout 2 of the down projection's weight puts its k in that order
+    bf16x8 hf_hi[4], hf_lo[4];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int hc = 0; hc < 2; ++hc) {
+        f32x4 v0, v1;
+        const int r0 = 8 * hc;
+        {
+          const f32x2 a = geglu_pair(f32x2{acc[2 * jj][r0], acc[2 * jj][r0 + 1]} * rsh, f32x2{acc[2 * jj + 1][r0], acc[2 * jj + 1][r0 + 1]} * rs);
+          const f32x2 b = geglu_pair(f32x2{acc[2 * jj][r0 + 2], acc[2 * jj][r0 + 3]} * rsh, f32x2{acc[2 * jj + 1][r0 + 2], acc[2 * jj + 1][r0 + 3]} * rs);
+          v0 = f32x4{a.x, a.y, b.x, b.y};
+        }
+        {
+          const f32x2 a = geglu_pair(f32x2{acc[2 * jj][r0 + 4], acc[2 * jj][r0 + 5]} * rsh, f32x2{acc[2 * jj + 1][r0 + 4], acc[2 * jj + 1][r0 + 5]} * rs);
+          const f32x2 b = geglu_pair(f32x2{acc[2 * jj][r0 + 6], acc[2 * jj][r0 + 7]} * rsh, f32x2{acc[2 * jj + 1][r0 + 6], acc[2 * jj + 1][r0 + 7]} * rs);
+          v1 = f32x4{a.x, a.y, b.x, b.y};
+        }
+        u32x4 hi, lo;
+        split8(v0, v1, hi, lo);
+        hf_hi[2 * jj + hc] = __builtin_bit_cast(bf16x8, hi);
+        hf_lo[2 * jj + hc] = __builtin_bit_cast(bf16x8, lo);
+      }
+    // vector-written fragments -> operands of asm MFMAs: no hazard padding from the compiler.  The pad names every fragment as an operand:
+    // a bare `s_nop` is ordered against nothing, and the scheduler put the pack of chunk 0's first dword behind it (wrong hidden features
+    // 0, 1, 4, 5 of every tile's first chunk on the first try)
+    asm volatile("s_nop 7" : "+v"(hf_hi[0]), "+v"(hf_hi[1]), "+v"(hf_hi[2]), "+v"(hf_hi[3]), "+v"(hf_lo[0]), "+v"(hf_lo[1]), "+v"(hf_lo[2]), "+v"(hf_lo[3]));
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ================= down projection: k-steps 2 t, 2 t + 1 (64 hidden features) into the row's K output features ========================
+    // stage v = 2 nt + kk: output n-tile nt (4 blocks of 32), hidden chunks 2 kk, 2 kk + 1
+    static_for<NKD>([&](auto v_) {
+      constexpr int v = decltype(v_)::value, ntile = v >> 1, kk = v & 1;
+      const int slot = (slot0 + NKU + v) % NSTG, nslot = (slot0 + NKU + v + 1) % NSTG;
+      auto dd = [&](auto b_, auto j_, bool w_lo, bool h_lo) {
+        constexpr int b = decltype(b_)::value, j = decltype(j_)::value;
+        const bf16x8& w = w_lo ? wl[b][j] : wh[b][j];
+        const bf16x8& h = h_lo ? hf_lo[2 * kk + b] : hf_hi[2 * kk + b];
+        mfma_acc_ag<AO + 16 * (4 * ntile + j)>(w, h);
+      };
+      constexpr std::integral_constant<int, 0> I0{};
+      constexpr std::integral_constant<int, 1> I1{};
+      constexpr std::integral_constant<int, 2> I2{};
+      constexpr std::integral_constant<int, 3> I3{};
+      dd(I0, I0, true, false);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(slot, 1, wh[1], wl[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      dd(I0, I1, true, false); dd(I0, I2, true, false); dd(I0, I3, true, false);
+      dd(I0, I0, false, true); dd(I0, I1, false, true); dd(I0, I2, false, true); dd(I0, I3, false, true);
+      dd(I0, I0, false, false); dd(I0, I1, false, false); dd(I0, I2, false, false); dd(I0, I3, false, false);
+      __builtin_amdgcn_sched_barrier(0);
+      next_stage_in();
+      dd(I1, I0, true, false);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(nslot, 0, wh[0], wl[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      dd(I1, I1, true, false); dd(I1, I2, true, false);
+      issue_rel(t, NKU + v + PDIST, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      dd(I1, I3, true, false); dd(I1, I0, false, true); dd(I1, I1, false, true);
+      issue_rel(t, NKU + v + PDIST, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      dd(I1, I2, false, true); dd(I1, I3, false, true); dd(I1, I0, false, false);
+      issue_rel(t, NKU + v + PDIST, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      dd(I1, I1, false, false); dd(I1, I2, false, false);
+      issue_rel(t, NKU + v + PDIST, 3);
+      dd(I1, I3, false, false);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (probe && t == 0) p.clk[6] = __builtin_amdgcn_s_memtime();
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 3" ::: "memory");       // tail LDS-DMA drained; last MFMA results readable
+
+  // ---- + x, store: out accumulators from the AccVGPRs, the row's x read again (fp32), through the wave's store strip -------------------
+  char* strip = smem + NSTG * STG + 4 * SCL + wid * 2048;
+  float* st_row[2];
+  const float* sk_row[2];
+  bool st_ok[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int r = m0 + wid * 32 + 16 * it + (lane >> 2);
+    st_ok[it] = r < p.M;
+    st_row[it] = p.Y + (size_t)min(r, p.M - 1) * K + 4 * (lane & 3);
+    sk_row[it] = p.X + (size_t)min(r, p.M - 1) * K + 4 * (lane & 3);
+  }
+  static_for<NOB>([&](auto ob_) {
+    constexpr int ob = decltype(ob_)::value;
+    f32x4 blk[4];
+    static_for<4>([&](auto g_) { blk[decltype(g_)::value] = areg_read4<AO + 16 * ob + 4 * decltype(g_)::value>(); });
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      f32x4 skip[2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) skip[it] = *reinterpret_cast<const f32x4*>(sk_row[it] + 32 * ob + 16 * hb);
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg)
+        *reinterpret_cast<f32x4*>(strip + l31 * 64 + (((2 * gg + lh) ^ ((l31 >> 2) & 1)) << 4)) = blk[2 * hb + gg];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int r16 = 16 * it + (lane >> 2), c = lane & 3;
+        const f32x4 o = *reinterpret_cast<const f32x4*>(strip + r16 * 64 + ((c ^ ((r16 >> 2) & 1)) << 4));
+        if (st_ok[it]) *reinterpret_cast<f32x4*>(st_row[it] + 32 * ob + 16 * hb) = o + skip[it];
+      }
+    }
+  });
+  if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)total; }
+}
+
+extern unsigned long long* g_clk;      // gemm_x3.hip (kd_prof_clock_buffer)
+
+template <int NC>
+static int launch_ffn(const FArgs3& a, const char* nm, double flops, double bytes, hipStream_t s) {
+  auto kern = ffn_x3_kernel<NC>;
+  constexpr int K = NC * 16;
+  constexpr int LDS = 8 * STG + 4 * (K * 4 < 1024 ? 1024 : K * 4) + 4 * 2048;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  LaunchScope prof(nm, flops, bytes, s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + 127) / 128)), dim3(256), LDS, s, a);
+  return check_launch("kd_ffn_f32");
+}
+
+}  // namespace x3
+}  // namespace kd
+
+using namespace kd;
+
+extern "C" int kd_ffn_f32_supported(int M, int K, int d_ff) {
+  if (!option("ffn_x3", 1)) return 0;
+  return (K == 128 || K == 256) && d_ff > 0 && d_ff % 64 == 0 && M >= 2048;
+}
+
+extern "C" int kd_ffn_f32(const KdFfn* dp, void* stream) {
+  if (!dp) return fail(KD_EINVAL, "kd_ffn_f32: null descriptor");
+  const KdFfn& d = *dp;
+  if (!d.x || !d.out || !d.scale || !d.Wp_up || !d.Wp_down) return fail(KD_EINVAL, "kd_ffn_f32: null x / out / scale / Wp_up / Wp_down");
+  if ((d.K != 128 && d.K != 256) || d.d_ff <= 0 || (d.d_ff & 63) || d.M <= 0) return fail(KD_EINVAL, "kd_ffn_f32: K must be 128 or 256, d_ff a multiple of 64 (K=%d d_ff=%d)", d.K, d.d_ff);
+  if (d.rows_per_sample <= 0 || (d.scale_stride & 3)) return fail(KD_EINVAL, "kd_ffn_f32: rows_per_sample > 0, scale_stride %% 4 == 0");
+  x3::FArgs3 a{};
+  a.X = reinterpret_cast<const float*>(d.x); a.Y = reinterpret_cast<float*>(d.out);
+  a.Wu = reinterpret_cast<const char*>(d.Wp_up); a.Wd = reinterpret_cast<const char*>(d.Wp_down);
+  a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample; a.eps = d.eps;
+  a.M = d.M; a.d_ff = d.d_ff; a.n_tiles = d.d_ff / 64;
+  a.warm = option("code_warm", KD_CODE_WARM_DEFAULT);
+  a.clk = x3::g_clk;
+  const double flops = 2.0 * d.M * 3.0 * d.d_ff * d.K;
+  const double bytes = 4.0 * (2.0 * d.M * d.K + 3.0 * d.d_ff * d.K);
+  char nm[96] = "ffn_x3";
+  if (prof_on()) snprintf(nm, sizeof(nm), "ffn_x3 M=%d K=%d d_ff=%d", d.M, d.K, d.d_ff);
+  if (d.K == 128) return x3::launch_ffn<8>(a, nm, flops, bytes, (hipStream_t)stream);
+  return x3::launch_ffn<16>(a, nm, flops, bytes, (hipStream_t)stream);
+}
+
+KD_TEXT_PAD(ffn_x3)      // last function of this code object: kd_common.h, code warm-up

@@ -442,7 +442,19 @@ class _Plan:
                 else:
                     call(prefix + "attn_window", lib.kd_attn_window_f32, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.window_size, shift, *prep)
                 gemm(prefix + "out_proj", att, sa.out_proj.weight, x, T, d, d, epi=nat.EPI_RESIDUAL, R=x)
-            if bf and target is self.launches and lib.kd_ffn_bf16_supported(T, d, lv.d_ff):
+            if precision == nat.PREC_SPLIT3 and target is self.launches and lib.kd_ffn_f32_supported(T, d, lv.d_ff) \
+                    and os.environ.get("KDIFF_FFN_X3", "1") != "0":
+                # fp32-parity mode: the whole FeedForwardBlock in one kernel (csrc/ffn_x3.hip), hidden activation on the chip
+                fd = nat.KdFfn()
+                fd.x = fd.out = x.data_ptr()
+                fd.scale_stride, fd.rows_per_sample, fd.eps = total, rps, 1e-6
+                fd.Wp_up = m._packed_image(mod.ff.up_proj.weight, lv.d_ff, d, 1).data_ptr()
+                fd.Wp_down = m._packed_image(mod.ff.down_proj.weight, d, lv.d_ff, 2).data_ptr()
+                fd.M, fd.K, fd.d_ff = T, d, lv.d_ff
+                self.norm_descs.append((fd, scale_ptr(prefix + "ff.norm")[1]))
+                self.keep.append(fd)
+                target.append(_Launch(lib.kd_ffn_f32, (C.byref(fd),), prefix + "ff"))
+            elif bf and target is self.launches and lib.kd_ffn_bf16_supported(T, d, lv.d_ff):
                 # the whole FeedForwardBlock (:487-493) in one kernel: the d_ff-wide hidden activation stays on the chip
                 fd = nat.KdFfn()
                 fd.x = fd.out = x.data_ptr()

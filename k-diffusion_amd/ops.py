@@ -47,12 +47,9 @@ _packed = {}
 
 def pack_weight(W, N, K, geglu, cache=True, bf16=False):
     """Packed image of a weight (uint8 tensor): the split-bf16 image of KD_PREC_SPLIT3, or with ``bf16=True`` the plain bf16
-    image of KD_PREC_BF16.  ``geglu``: 0 / False plain, 1 / True GEGLU rows, 2 (bf16 only) the k order of the fused FF block's
-    down projection.  Weights are static while sampling, so the image is cached per tensor OBJECT (weak reference +
+    image of KD_PREC_BF16.  ``geglu``: 0 / False plain, 1 / True GEGLU rows, 2 the k order of the fused FF block's down projection.  Weights are static while sampling, so the image is cached per tensor OBJECT (weak reference +
     version counter: a new tensor that happens to reuse the address of a freed one never hits a stale image)."""
     geglu = int(geglu)
-    if geglu == 2 and not bf16:
-        raise ValueError("pack layout 2 exists for the bf16 image only")
     key = (id(W), bool(bf16), geglu)
     ent = _packed.get(key) if cache else None
     if ent is not None:
@@ -239,9 +236,11 @@ def patch_out(x, norm_scale, weight, patch, channels, x_in=None, sigma=None, sig
                 sigma_data=sigma_data, eps=eps, precision=_prec_of(x))
 
 
-def ffn_supported(M, K, d_ff):
-    """Does the fused feed-forward kernel take this shape (bf16 mode)?  Otherwise use the up / down pair of ``gemm`` calls."""
-    return bool(nat.lib().kd_ffn_bf16_supported(int(M), int(K), int(d_ff)))
+def ffn_supported(M, K, d_ff, bf16=True):
+    """Does the fused feed-forward kernel take this shape (bf16 mode, or with ``bf16=False`` the fp32-parity split3 mode)?
+    Otherwise use the up / down pair of ``gemm`` calls."""
+    fn = nat.lib().kd_ffn_bf16_supported if bf16 else nat.lib().kd_ffn_f32_supported
+    return bool(fn(int(M), int(K), int(d_ff)))
 
 
 def ffn(x, norm_scale, w_up, w_down, out=None, scale_stride=None, rows_per_sample=None, eps=1e-6):
@@ -251,18 +250,22 @@ def ffn(x, norm_scale, w_up, w_down, out=None, scale_stride=None, rows_per_sampl
     K = x.shape[-1]
     M = x.numel() // K
     d_ff = w_down.shape[1]
-    if x.dtype != torch.bfloat16:
-        raise TypeError("ffn: bf16 activations only (KDIFF_GEMM=bf16)")
+    if x.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("ffn: bf16 activations (KDIFF_GEMM=bf16) or fp32 activations (the fp32-parity split3 mode)")
+    bf = x.dtype == torch.bfloat16
     out = torch.empty_like(x) if out is None else out
     d = nat.KdFfn()
-    d.x, d.out, d.scale = _p(_chk(x, "x", torch.bfloat16)), _p(_chk(out, "out", torch.bfloat16)), _p(_chk(norm_scale, "norm_scale"))
+    d.x, d.out, d.scale = _p(_chk(x, "x", x.dtype)), _p(_chk(out, "out", x.dtype)), _p(_chk(norm_scale, "norm_scale"))
     d.scale_stride = norm_scale.shape[-1] if scale_stride is None else scale_stride
     d.rows_per_sample = (M // max(norm_scale.numel() // norm_scale.shape[-1], 1)) if rows_per_sample is None else rows_per_sample
     d.eps = eps
-    up_img, down_img = pack_weight(w_up, d_ff, K, 1, bf16=True), pack_weight(w_down, K, d_ff, 2, bf16=True)
+    up_img, down_img = pack_weight(w_up, d_ff, K, 1, bf16=bf), pack_weight(w_down, K, d_ff, 2, bf16=bf)
     d.Wp_up, d.Wp_down = _p(up_img), _p(down_img)
     d.M, d.K, d.d_ff = M, K, d_ff
-    nat.check(nat.lib().kd_ffn_bf16(C.byref(d), _stream()), "kd_ffn_bf16")
+    if bf:
+        nat.check(nat.lib().kd_ffn_bf16(C.byref(d), _stream()), "kd_ffn_bf16")
+    else:
+        nat.check(nat.lib().kd_ffn_f32(C.byref(d), _stream()), "kd_ffn_f32")
     return out
 
 

@@ -725,6 +725,29 @@ def test_split3_projections_round3(KD, ops, monkeypatch, H, W, nh, B, K):
     assert relerr(qkv, old) < 1e-4 and (B * T < 512 or K >= 512 or not torch.equal(qkv, old))      # (another kernel really ran)
 
 
+@pytest.mark.parametrize("H,W,B,K,dff", [(64, 64, 2, 128, 384), (32, 32, 4, 256, 768), (48, 40, 2, 128, 320), (30, 30, 3, 256, 448)])
+def test_fused_feed_forward_split3(KD, ops, monkeypatch, H, W, B, K, dff):
+    """kd_ffn_f32 (csrc/ffn_x3.hip): the whole FeedForwardBlock (image_transformer_v2.py:487-493) in fp32-parity arithmetic against the
+    oracle's separate steps, and against the two-GEMM form it replaces.  Full and ragged 128-row panels, rows of two samples in one wave
+    (30 x 30 tokens), d_ff that is not a multiple of 128."""
+    monkeypatch.setenv("KDIFF_GEMM", "split3")
+    T = H * W
+    x, scale = rn(B, T, K, seed=21), 1 + 0.2 * rn(B, K, seed=22)
+    wu, wd = rn(2 * dff, K, seed=23, scale=K ** -0.5), rn(K, dff, seed=24, scale=dff ** -0.5)
+    assert ops.ffn_supported(B * T, K, dff, bf16=False)
+    y = ops.ffn(g(x), g(scale), g(wu), g(wd), rows_per_sample=T)
+    ref = x + hdit.linear_geglu(hdit.rms_norm(x, scale[:, None, :]), wu) @ wd.T
+    assert relerr(y, ref) < 1e-4
+    hid = ops.norm_linear(g(x), g(scale), g(wu), rows_per_sample=T, epi=KD._native.EPI_GEGLU)
+    two = ops.linear(hid, g(wd), residual=g(x))
+    assert relerr(y, two) < 1e-4
+    xi = g(x).clone()                                   # in place, as the model runs it
+    ops.ffn(xi, g(scale), g(wu), g(wd), out=xi, rows_per_sample=T)
+    assert torch.equal(xi, y)
+    with pytest.raises(RuntimeError, match="kd_ffn_f32"):
+        ops.ffn(g(rn(4, 96, seed=1)), g(rn(1, 96, seed=2)), g(rn(2 * 64, 96, seed=3)), g(rn(96, 64, seed=4)), rows_per_sample=4)
+
+
 def test_bf16_attention_cores(ops, golden):
     """bf16 global / window / neighbourhood cores against the reference's op goldens (prepared q, k) and the oracle."""
     o = golden["ops"]
