@@ -101,7 +101,7 @@ def family_roofline(name, g, mode, total_ms):
     sec = g["ms"] * 1e-3
     gbs = g["bytes"] / sec / 1e9
     is_bf16 = "bf16" in name and "bf16x3" not in name
-    is_x3 = "bf16x3" in name or "_x3_" in name or name in ("gemm_astat", "attn_na2d") or (mode == "split3" and name.startswith("gemm_bf16x3"))
+    is_x3 = "bf16x3" in name or "_x3" in name or name in ("gemm_astat", "attn_na2d") or (mode == "split3" and name.startswith("gemm_bf16x3"))
     has_mfma = name.startswith("gemm") or name.startswith("attn")
     if is_bf16 or is_x3:
         mult, peak = (3.0 if is_x3 else 1.0), BF16_MFMA_PEAK_TFLOPS

@@ -13,7 +13,8 @@
 //   * the K-wide fp32 output accumulators of a row block live in named AccVGPRs for the whole kernel (64 at K = 128, 128 at K = 256):
 //     they are the C operand of asm MFMAs and never compete with the up projection's accumulators for ArchVGPRs;
 //   * epilogue: + x (re-read: 512 / 1024 bytes per row, the only second touch of x), fp32, through the wave's LDS strip.
-// One workgroup per CU (the register file is the wave's): the GEGLU phase of a tile (packed fp32 math, no MFMA in flight: v_pk_* beside
+// One workgroup per CU (the register file is the wave's; at K = 128 the wave would fit 256 registers with 64 AccVGPRs, but once a kernel
+// uses AccVGPRs hipcc splits a two-wave budget 128 + 128 whatever it is told, and spills): the GEGLU phase of a tile (packed fp32 math, no MFMA in flight: v_pk_* beside
 // an MFMA costs 20 cycles each, profiles/r03_issue_model.md) is the only part of a tile the matrix pipe sits out.
 #include "x3_common.h"
 
