@@ -35,6 +35,8 @@ const char* kd_last_error(void);
  * environment variables: the Python package maps its documented KDIFF_* variables onto these calls.  Thread-safe.
  *   fp32 kernels : "skinny" (1) "astat" (1) "ksplit" (1) "astat_max_k" (512) "astat_waves" (4) "astat_storewait" (0)
  *                  "gemm_debug" (0; profiling ablations of benchmarks/: 1 no C stores, 2 no MFMA, 8 GEGLU without erf)
+ *                  "x3" (1; 0 = the round-1 / round-2 kernels for KD_PREC_SPLIT3 projections) "x3_splits" (0 = cost model)
+ *                  "ffn_x3" (1; 0 = kd_ffn_f32_supported answers no) "ffn_x3_half" (1; 0 = one workgroup per CU at K = 128)
  *   bf16 kernels : "bf16_fast" (1; 0 = generic kernel only) "wstat" (1) "wstat_waves" (0 = per shape) "wstat_max_slices" (24)
  *                  "wstat_prefetch" (0; 1 next-chunk prefetch, 2 software-pipelined tiles) "astat_bf16" (1) "astat_splits" (0 = auto)
  *                  "tiled_bm" (0 = auto, 128, 256) "attn_global_qw" (8) "patch_fast" (1; 0 = patch-in / patch-out through the generic kernel)
@@ -146,7 +148,8 @@ int kd_ffn_bf16(const KdFfn* desc, void* stream);
 /* The same block in fp32-parity arithmetic (KD_PREC_SPLIT3: fp32 x / out, three split-bf16 MFMA terms per product, fp32 accumulate):
  * Wp_up = kd_pack_weight_bf16x3(up_proj.weight, N = d_ff, K, geglu = 1), Wp_down = kd_pack_weight_bf16x3(down_proj.weight [K, d_ff],
  * N = K, K = d_ff, geglu = 2).  K == 128 or 256, d_ff % 64 == 0; out may be x.  kd_ffn_f32_supported says where it is the faster form
- * (M >= 2048; option "ffn_x3" = 0 answers no). */
+ * (M >= 2048; option "ffn_x3" = 0 answers no).  At K == 128 the kernel runs two workgroups per CU over half tiles of 32 hidden features
+ * (option "ffn_x3_half" = 0: the one-workgroup form; same results). */
 int kd_ffn_f32_supported(int M, int K, int d_ff);
 int kd_ffn_f32(const KdFfn* desc, void* stream);
 
@@ -294,11 +297,12 @@ int kd_prof_enable(int on);
 int kd_prof_count(void);
 int kd_prof_get(int i, char* name, int name_cap, float* ms, double* flops, double* bytes);
 int kd_prof_reset(void);
-/* In-kernel time line probe (benchmarks/): while `dev_ptr` (8 x uint64 of device memory) is set, workgroup 0 of the bf16 GEMM kernels
+/* In-kernel time line probe (benchmarks/): while `dev_ptr` (16 x uint64 of device memory) is set, workgroup 0 of the bf16 GEMM kernels
  * (W-stationary, A-stationary, tiled) and of kd_ffn_bf16 writes s_memtime stamps: [0] entry, [2] exit, [1] / [3] s_memrealtime at
  * entry / exit (shader clock under load = ([2]-[0]) / ([3]-[1]) x 100 MHz), [4] end of the row prologue / first blocks in,
  * [5] end of the first tile's K loop (tiled, ffn: of the whole loop), [6] end of its epilogue, [7] number of ring blocks / tiles.
- * NULL switches it off.  Not for concurrent launches. */
+ * kd_ffn_f32 also stamps its third d_ff tile: [8] start, [9] up projection done, [10] GEGLU done, [11] down k-steps done, and [12]
+ * the end of the tile loop.  NULL switches it off.  Not for concurrent launches. */
 int kd_prof_clock_buffer(void* dev_ptr);
 
 #ifdef __cplusplus

@@ -58,6 +58,9 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
   constexpr int WAREA = (NSTG / 4) * STG;
   constexpr int KH = WAREA / 128 >= K ? K : WAREA / 128, NR = K / KH, CPR = KH / 4, PIECES = 32 * CPR / 64;
   constexpr int SCL = K * 4 < 1024 ? 1024 : K * 4;
+  // K = 128: a wave's rows take 16 KiB; they borrow ring slots 4 .. 7 and the first EARLY weight stages are requested into slots 0 .. 3 before
+  // the rows have even arrived (the first MFMA then waits for nothing).  K = 256: the rows need all 8 slots.
+  constexpr int EARLY = K == 128 ? 4 : 0;
   static_assert(NR == 1 && (K == 128 || K == 256), "widths 128 and 256");
   static_assert(UNIT <= 2 * NSTG, "slot arithmetic below assumes at most two trips round the ring per tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
   const auto warm = code_warm_begin<(NC <= 8 ? 16 : 28) * 1024>((int)blockIdx.x < p.warm && tid < 64);
   const int m0 = blockIdx.x * 128;
   const int T = p.n_tiles, total = T * UNIT;
-  const bool probe = p.clk && blockIdx.x == 0 && tid == 0;
+  const bool probe = p.clk && blockIdx.x == (gridDim.x * 5) / 8 && tid == 0;      // a workgroup of a later round: the chip under load
   if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
 
   // The weight stream: tile t contributes UNIT stages -- u < NKU: up block (t, u); else down block (n-tile (u - NKU) / 2, k-step
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
   bf16x8 a_hi[AG ? 1 : NC], a_lo[AG ? 1 : NC];
   float rs;
   {
-    char* stage = smem + wid * WAREA;
+    char* stage = smem + (EARLY ? EARLY * STG + wid * STG : wid * WAREA);
     char* scl = smem + NSTG * STG + wid * SCL;
     const int r_first = min(m0 + wid * 32, p.M - 1), r_last = min(m0 + wid * 32 + 31, p.M - 1);
     const bool uni = p.scale_stride == 0 || r_first / p.rows_per_sample == r_last / p.rows_per_sample;
@@ -112,7 +115,15 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(stage + i * 1024), 16, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (EARLY > 0) {                       // the first weight stages go to the slots no row borrows, behind the rows in the queue
+#pragma unroll
+      for (int s = 0; s < EARLY; ++s)
+#pragma unroll
+        for (int j = 0; j < PB; ++j) issue_rel(0, s, j);
+      wait_vm(PB * EARLY);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const char* rowp = stage + l31 * (KH * 4);
     static_for<NC / 4>([&](auto c4_) {
       constexpr int c0 = 4 * decltype(c4_)::value;
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   KD_BARRIER();                                        // every wave has taken its rows out of the slots it borrowed
 #pragma unroll
-  for (int s = 0; s < PDIST; ++s)
+  for (int s = EARLY; s < PDIST; ++s)
 #pragma unroll
     for (int j = 0; j < PB; ++j) issue_rel(0, s, j);
   if (probe) p.clk[4] = __builtin_amdgcn_s_memtime();
@@ -185,12 +196,9 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
   for (int t = 0; t < T; ++t) {
     const int sbase = t * UNIT;
     const int slot0 = sbase % NSTG;                   // ring slot of the tile's first stage (UNIT is not a multiple of NSTG at K = 128)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    // v_mov -> SrcC of an asm MFMA: the compiler pads that hazard for its own MFMAs only (tile 0's first MFMA read two stale registers)
-    asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    if (probe && t == 2) p.clk[8] = __builtin_amdgcn_s_memtime();
+    // (no zeroing of the accumulators: the first MFMA of each chain takes the constant 0 as its C operand -- 64 v_mov per tile less, and
+    // no v_mov -> SrcC hazard, which the compiler pads for its own MFMAs only)
     // ================= up projection of tile t: value / gate accumulators of its 2 x 32 hidden features (K / 32 stages) =================
     static_for<NKU>([&](auto ks_) {
       constexpr int ks = decltype(ks_)::value;
@@ -198,8 +206,14 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
       auto mm = [&](auto b_, int j, bool w_lo, auto a_lo_) {
         constexpr int b = decltype(b_)::value, al = decltype(a_lo_)::value, c = 2 * ks + b;
         const bf16x8& w = w_lo ? wl[b][j] : wh[b][j];
-        if constexpr (AG) mfma_ag<8 * c + 4 * al>(acc[j], w);
-        else mfma_vv(acc[j], w, al ? a_lo[c] : a_hi[c]);      // (asm: the accumulators must stay out of the AccVGPRs this kernel names)
+        constexpr bool first = ks == 0 && b == 0;             // the chain of block j starts with its w_lo x a_hi term of chunk 0
+        if constexpr (AG) {
+          if (first && w_lo) mfma_ag0<8 * c + 4 * al>(acc[j], w);
+          else mfma_ag<8 * c + 4 * al>(acc[j], w);
+        } else {                                              // (asm: the accumulators must stay out of the AccVGPRs this kernel names)
+          if (first && w_lo) mfma_vv0(acc[j], w, al ? a_lo[c] : a_hi[c]);
+          else mfma_vv(acc[j], w, al ? a_lo[c] : a_hi[c]);
+        }
       };
       constexpr std::integral_constant<int, 0> I0{};
       constexpr std::integral_constant<int, 1> I1{};
@@ -241,6 +255,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
     });
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));      // asm MFMA results -> vector reads
     if (probe && t == 0) p.clk[5] = __builtin_amdgcn_s_memtime();
+    if (probe && t == 2) p.clk[9] = __builtin_amdgcn_s_memtime();
 
     // ================= GEGLU in the lane that owns the row -> hi / lo B-operand fragments of the 4 hidden 16-chunks ======================
     // chunk c' = 2 jj + (g >> 1) of the tile; the lane's 8 values of it are accumulator registers 8 (c' & 1) .. + 7 of blocks (2 jj, 2 jj + 1),
@@ -272,6 +287,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
     // 0, 1, 4, 5 of every tile's first chunk on the first try)
     asm volatile("s_nop 7" : "+v"(hf_hi[0]), "+v"(hf_hi[1]), "+v"(hf_hi[2]), "+v"(hf_hi[3]), "+v"(hf_lo[0]), "+v"(hf_lo[1]), "+v"(hf_lo[2]), "+v"(hf_lo[3]));
     __builtin_amdgcn_sched_barrier(0);
+    if (probe && t == 2) p.clk[10] = __builtin_amdgcn_s_memtime();
 
     // ================= down projection: k-steps 2 t, 2 t + 1 (64 hidden features) into the row's K output features ========================
     // stage v = 2 nt + kk: output n-tile nt (4 blocks of 32), hidden chunks 2 kk, 2 kk + 1
@@ -316,9 +332,9 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
       __builtin_amdgcn_sched_barrier(0);
     });
     if (probe && t == 0) p.clk[6] = __builtin_amdgcn_s_memtime();
+    if (probe && t == 2) p.clk[11] = __builtin_amdgcn_s_memtime();
   }
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 3" ::: "memory");       // tail LDS-DMA drained; last MFMA results readable
-
+  if (probe) p.clk[12] = __builtin_amdgcn_s_memtime();
   // ---- + x, store: out accumulators from the AccVGPRs, the row's x read again (fp32), through the wave's store strip -------------------
   char* strip = smem + NSTG * STG + 4 * SCL + wid * 2048;
   float* st_row[2];
@@ -331,15 +347,23 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
     st_row[it] = p.Y + (size_t)min(r, p.M - 1) * K + 4 * (lane & 3);
     sk_row[it] = p.X + (size_t)min(r, p.M - 1) * K + 4 * (lane & 3);
   }
+  // every skip piece of the wave's rows requested up front (4 NOB loads in flight: one memory latency for the epilogue, not one per piece)
+  f32x4 skip_all[NOB][2][2];
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) skip_all[ob][hb][it] = *reinterpret_cast<const f32x4*>(sk_row[it] + 32 * ob + 16 * hb);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 3" ::: "memory");       // tail LDS-DMA drained; last MFMA results readable
   static_for<NOB>([&](auto ob_) {
     constexpr int ob = decltype(ob_)::value;
     f32x4 blk[4];
     static_for<4>([&](auto g_) { blk[decltype(g_)::value] = areg_read4<AO + 16 * ob + 4 * decltype(g_)::value>(); });
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
-      f32x4 skip[2];
-#pragma unroll
-      for (int it = 0; it < 2; ++it) skip[it] = *reinterpret_cast<const f32x4*>(sk_row[it] + 32 * ob + 16 * hb);
+      const f32x4 (&skip)[2] = skip_all[ob][hb];
 #pragma unroll
       for (int gg = 0; gg < 2; ++gg)
         *reinterpret_cast<f32x4*>(strip + l31 * 64 + (((2 * gg + lh) ^ ((l31 >> 2) & 1)) << 4)) = blk[2 * hb + gg];
@@ -354,7 +378,352 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
   if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)total; }
 }
 
+
+// ===========================================================================================================================================
+// Width 128, TWO workgroups per CU.  The kernel above leaves the matrix pipe idle for ~45 % of a workgroup's life at level 0 (row prologue
+// under load 12 k clocks, GEGLU 1.9 k per tile, epilogue 6.7 k, of 72 k: profiles/r03_ffn_x3_timeline.log) and nothing else is resident to
+// fill it.  Two independent workgroups per CU need <= 128 ArchVGPRs + 128 AccVGPRs per wave and <= 80 KiB of LDS each:
+//   * AccVGPRs a0..a63 = the row's activation fragments, a64..a127 = the 128 output accumulators (all of that half of the file);
+//   * the d_ff range is walked in HALF tiles of 32 hidden features (value block + gate block: 32 accumulator registers instead of 64,
+//     16 registers of hidden fragments instead of 32), straight out of the same packed images: a half tile's rows are one contiguous 4 KiB
+//     run inside each [128 rows][32 k] image of pack layout 1, its down k-step one whole 16 KiB block of pack layout 2;
+//   * ring of 4 stages of 16 KiB: per half tile 2 up stages (each two 32-k sub-stages [hi 4 KiB | lo 4 KiB] of the half tile's 64 rows)
+//     and 1 down stage; 24 MFMAs per stage as above, one mid-stage barrier per stage, requests for stage s + 3 between the MFMAs of stage s.
+// LDS 76 KiB per workgroup.  Measured (profiles/r03_ffn_x3_timeline.log): 157 -> 130 us per launch at level 0; inside the tile loop the two
+// waves of a SIMD keep the matrix pipe 94 % busy (4 900 clocks per half tile and wave against 2 x 2 304 of MFMA).  The GEGLU stays packed
+// fp32: beside ANOTHER wave's MFMAs v_pk_* costs nothing extra (a scalar build was level: 130.1 / 128.7 vs 130.2 / 131.0 us).
+#define KD_A10(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+#define KD_AGPR_LO128                                                                                                                     \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", KD_A10(1), KD_A10(2), KD_A10(3), KD_A10(4), KD_A10(5), KD_A10(6), KD_A10(7),   \
+      KD_A10(8), KD_A10(9), KD_A10(10), KD_A10(11), "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+template <int IDX>
+__device__ __forceinline__ void areg_write4_lo(const u32x4 v) {
+  asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
+               :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "i"(IDX), "i"(IDX + 1), "i"(IDX + 2), "i"(IDX + 3) : KD_AGPR_LO128);
+}
+template <int IDX>
+__device__ __forceinline__ void mfma_acc_ag_lo(const bf16x8 w, const bf16x8 h) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(w), "v"(h), "i"(IDX), "i"(IDX + 15) : KD_AGPR_LO128);
+}
+template <int IDX>
+__device__ __forceinline__ void areg_zero16_lo() {
+  static_for<16>([&](auto i_) { asm volatile("v_accvgpr_write_b32 a[%c0], 0" :: "i"(IDX + decltype(i_)::value) : KD_AGPR_LO128); });
+}
+
+__global__ __launch_bounds__(256, 2) void ffn_x3h_kernel(const FArgs3 p) {
+  constexpr int NC = 8, K = 128, NOB = 4;
+  constexpr int NSTG = 4, PDIST = NSTG - 1, PB = 4, UNIT = 3;   // stages per half tile: 2 up + 1 down
+  constexpr int AO = 64;
+  constexpr int CPR = K / 4, PIECES = 32 * CPR / 64, SCL = 1024, SUB = 8192, HALF = 4096;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const auto warm = code_warm_begin<16 * 1024>((int)blockIdx.x < p.warm && tid < 64);
+  const int m0 = blockIdx.x * 128;
+  const int T2 = 2 * p.n_tiles;                                 // half tiles
+  const bool probe = p.clk && blockIdx.x == (gridDim.x * 5) / 8 && tid == 0;
+  if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
+
+  // stage (th, u): u < 2: sub-stages 2 u, 2 u + 1 of half tile th's up rows (piece j: sub-stage j >> 1, hi / lo image j & 1: this wave's
+  // KiB of that 4 KiB run); u == 2: the down block of k-step th (this wave's 4 KiB of it).  Requests past the end repeat the last stage.
+  auto issue_rel = [&](int th, auto off_, int j) {
+    constexpr int off = decltype(off_)::value, u = off % UNIT;
+    const int tt = min(th + off / UNIT, T2 - 1);                 // (past the end: the same kind of stage of the last half tile, never read)
+    char* slot = smem + ((th * UNIT + off) % NSTG) * STG;
+    const char* src;
+    char* dst;
+    if constexpr (u < 2) {
+      src = p.Wu + ((size_t)(tt >> 1) * (NC / 2) + 2 * u + (j >> 1)) * STG + (j & 1) * IMG + (tt & 1) * HALF + wid * 1024 + lane * 16;
+      dst = slot + (j >> 1) * SUB + (j & 1) * HALF + wid * 1024;
+    } else {
+      src = p.Wd + (size_t)tt * STG + wid * (PB * 1024) + j * 1024 + lane * 16;
+      dst = slot + wid * (PB * 1024) + j * 1024;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+
+  // ---- this wave's 32 rows -> a0..a63 (hi / lo fragments of the normalised, scaled row) -------------------------------------------------
+  const int row = m0 + wid * 32 + l31;
+  const bool ok = row < p.M;
+  const int rowc = ok ? row : p.M - 1;
+  float rs;
+  {
+    char* stage = smem + wid * STG;
+    char* scl = smem + NSTG * STG + wid * SCL;
+    const int r_first = min(m0 + wid * 32, p.M - 1), r_last = min(m0 + wid * 32 + 31, p.M - 1);
+    const bool uni = p.scale_stride == 0 || r_first / p.rows_per_sample == r_last / p.rows_per_sample;
+    if (uni) {
+      const char* ssrc = reinterpret_cast<const char*>(p.scale + (size_t)(r_first / p.rows_per_sample) * p.scale_stride);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc + (lane * 16) % (K * 4)),
+                                       (__attribute__((address_space(3))) void*)scl, 16, 0, 0);
+    }
+    const float* sp = p.scale + (size_t)(rowc / p.rows_per_sample) * p.scale_stride + 8 * lh;
+    const float* spl = reinterpret_cast<const float*>(scl) + 8 * lh;
+    float ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int ci = i * 64 + lane, rr = ci / CPR, qs = ci % CPR;
+      const int grow = min(m0 + wid * 32 + rr, p.M - 1);
+      const char* src = reinterpret_cast<const char*>(p.X + (size_t)grow * K) + ((qs ^ (rr & 15)) << 4);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(stage + i * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* rowp = stage + l31 * (K * 4);
+    static_for<NC / 4>([&](auto c4_) {
+      constexpr int c0 = 4 * decltype(c4_)::value;
+      f32x4 x0[4], x1[4], s0[4], s1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = 4 * (c0 + u) + 2 * lh;
+        x0[u] = *reinterpret_cast<const f32x4*>(rowp + ((q ^ (l31 & 15)) << 4));
+        x1[u] = *reinterpret_cast<const f32x4*>(rowp + (((q + 1) ^ (l31 & 15)) << 4));
+        if (uni) {
+          s0[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
+          s1[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
+        } else {
+          s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
+          s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<4>([&](auto u_) {
+        constexpr int u = decltype(u_)::value;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ssq = fmaf(x0[u][e], x0[u][e], fmaf(x1[u][e], x1[u][e], ssq));
+        u32x4 hi, lo;
+        split8(x0[u] * s0[u], x1[u] * s1[u], hi, lo);
+        areg_write4_lo<8 * (c0 + u)>(hi);
+        areg_write4_lo<8 * (c0 + u) + 4>(lo);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    ssq += __shfl_xor(ssq, 32, 64);
+    rs = rsqrtf(ssq / (float)K + p.eps);
+  }
+  static_for<NOB>([&](auto ob_) { areg_zero16_lo<AO + 16 * decltype(ob_)::value>(); });
+  code_warm_end(warm);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  KD_BARRIER();                                        // every wave has taken its rows out of the slot it borrowed
+  static_for<PDIST>([&](auto s_) {
+#pragma unroll
+    for (int j = 0; j < PB; ++j) issue_rel(0, s_, j);
+  });
+  if (probe) p.clk[4] = __builtin_amdgcn_s_memtime();
+
+  const int o0 = swz64(l31, lh), o1 = swz64(l31, 2 + lh);
+  const float rsh = 0.5f * rs;
+  f32x16 acc[2];
+  bf16x8 uh[2][2], ul[2][2];                           // up: [chunk parity][value / gate block]
+  bf16x8 dh[2][4], dl[2][4];                           // down: [hidden chunk][output block]
+  // chunk cc (0..3) of an up stage: sub-stage cc >> 1, 16-k chunk cc & 1 of it; rows 32 j + l31 of the half tile's 64
+  auto read_up = [&](int slot, int cc, bf16x8 (&fh)[2], bf16x8 (&fl)[2]) {
+    const char* st = smem + slot * STG + (cc >> 1) * SUB + ((cc & 1) ? o1 : o0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      fh[j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 64);
+      fl[j] = *reinterpret_cast<const bf16x8*>(st + HALF + j * 32 * 64);
+    }
+  };
+  auto read_dn = [&](int slot, int h, bf16x8 (&fh)[4], bf16x8 (&fl)[4]) {
+    const char* st = smem + slot * STG + (h ? o1 : o0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fh[j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 64);
+      fl[j] = *reinterpret_cast<const bf16x8*>(st + IMG + j * 32 * 64);
+    }
+  };
+  auto next_stage_in = [&]() {
+    wait_vm(PB * (PDIST - 2));
+    KD_BARRIER();
+  };
+  wait_vm(PB * (PDIST - 1));
+  KD_BARRIER();
+  read_up(0, 0, uh[0], ul[0]);
+
+  constexpr std::integral_constant<int, 0> I0{};
+  constexpr std::integral_constant<int, 1> I1{};
+  constexpr std::integral_constant<int, 2> I2{};
+  constexpr std::integral_constant<int, 3> I3{};
+  for (int th = 0; th < T2; ++th) {
+    const int slot0 = (th * UNIT) % NSTG;
+    if (probe && th == 4) p.clk[8] = __builtin_amdgcn_s_memtime();
+    // ================= up projection of the half tile: value / gate accumulators of its 32 hidden features (2 stages of 4 chunks) ==========
+    static_for<2>([&](auto u_) {
+      constexpr int u = decltype(u_)::value;
+      const int slot = (slot0 + u) % NSTG, nslot = (slot0 + u + 1) % NSTG;
+      // the 6 MFMAs of chunk cc: (w_lo x a_hi), (w_hi x a_lo), (w_hi x a_hi) for the value block and the gate block in alternation
+      auto mm = [&](auto cc_, auto i_) {
+        constexpr int cc = decltype(cc_)::value, i = decltype(i_)::value, j = i & 1, term = i >> 1, c = 4 * u + cc;
+        const bf16x8& w = term == 0 ? ul[cc & 1][j] : uh[cc & 1][j];
+        constexpr int al = term == 1;
+        if constexpr (c == 0 && term == 0) mfma_ag0<8 * c + 4 * al>(acc[j], w);      // first MFMA of the chain: C = 0
+        else mfma_ag<8 * c + 4 * al>(acc[j], w);
+      };
+      constexpr std::integral_constant<int, 4> I4{};
+      constexpr std::integral_constant<int, 5> I5{};
+      // chunk 0
+      mm(I0, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_up(slot, 1, uh[1], ul[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I0, I1); mm(I0, I2); mm(I0, I3); mm(I0, I4); mm(I0, I5);
+      // chunk 1
+      mm(I1, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_up(slot, 2, uh[0], ul[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I1, I1); mm(I1, I2); mm(I1, I3); mm(I1, I4); mm(I1, I5);
+      __builtin_amdgcn_sched_barrier(0);
+      next_stage_in();
+      // chunk 2
+      mm(I2, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_up(slot, 3, uh[1], ul[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I2, I1); mm(I2, I2);
+      issue_rel(th, std::integral_constant<int, u + PDIST>{}, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I2, I3); mm(I2, I4); mm(I2, I5);
+      issue_rel(th, std::integral_constant<int, u + PDIST>{}, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      // chunk 3
+      mm(I3, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (u == 0) read_up(nslot, 0, uh[0], ul[0]);
+      else read_dn(nslot, 0, dh[0], dl[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I3, I1); mm(I3, I2);
+      issue_rel(th, std::integral_constant<int, u + PDIST>{}, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I3, I3); mm(I3, I4);
+      issue_rel(th, std::integral_constant<int, u + PDIST>{}, 3);
+      mm(I3, I5);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));      // asm MFMA results -> vector reads
+    if (probe && th == 4) p.clk[9] = __builtin_amdgcn_s_memtime();
+
+    // ================= GEGLU in the lane that owns the row -> hi / lo fragments of the half tile's 2 hidden 16-chunks =====================
+    bf16x8 hf_hi[2], hf_lo[2];
+#pragma unroll
+    for (int hc = 0; hc < 2; ++hc) {
+      f32x4 v0, v1;
+      const int r0 = 8 * hc;
+      {
+        const f32x2 a = geglu_pair(f32x2{acc[0][r0], acc[0][r0 + 1]} * rsh, f32x2{acc[1][r0], acc[1][r0 + 1]} * rs);
+        const f32x2 b = geglu_pair(f32x2{acc[0][r0 + 2], acc[0][r0 + 3]} * rsh, f32x2{acc[1][r0 + 2], acc[1][r0 + 3]} * rs);
+        v0 = f32x4{a.x, a.y, b.x, b.y};
+      }
+      {
+        const f32x2 a = geglu_pair(f32x2{acc[0][r0 + 4], acc[0][r0 + 5]} * rsh, f32x2{acc[1][r0 + 4], acc[1][r0 + 5]} * rs);
+        const f32x2 b = geglu_pair(f32x2{acc[0][r0 + 6], acc[0][r0 + 7]} * rsh, f32x2{acc[1][r0 + 6], acc[1][r0 + 7]} * rs);
+        v1 = f32x4{a.x, a.y, b.x, b.y};
+      }
+      u32x4 hi, lo;
+      split8(v0, v1, hi, lo);
+      hf_hi[hc] = __builtin_bit_cast(bf16x8, hi);
+      hf_lo[hc] = __builtin_bit_cast(bf16x8, lo);
+    }
+    asm volatile("s_nop 7" : "+v"(hf_hi[0]), "+v"(hf_hi[1]), "+v"(hf_lo[0]), "+v"(hf_lo[1]));   // vector-written fragments -> asm MFMA operands
+    __builtin_amdgcn_sched_barrier(0);
+    if (probe && th == 4) p.clk[10] = __builtin_amdgcn_s_memtime();
+
+    // ================= down projection: the half tile's 32 hidden features into the row's 128 output features (1 stage) ===================
+    {
+      const int slot = (slot0 + 2) % NSTG, nslot = (slot0 + 3) % NSTG;
+      auto dd = [&](auto b_, auto j_, bool w_lo, bool h_lo) {
+        constexpr int b = decltype(b_)::value, j = decltype(j_)::value;
+        const bf16x8& w = w_lo ? dl[b][j] : dh[b][j];
+        const bf16x8& h = h_lo ? hf_lo[b] : hf_hi[b];
+        mfma_acc_ag_lo<AO + 16 * j>(w, h);
+      };
+      dd(I0, I0, true, false);
+      __builtin_amdgcn_sched_barrier(0);
+      read_dn(slot, 1, dh[1], dl[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      dd(I0, I1, true, false); dd(I0, I2, true, false); dd(I0, I3, true, false);
+      dd(I0, I0, false, true); dd(I0, I1, false, true); dd(I0, I2, false, true); dd(I0, I3, false, true);
+      dd(I0, I0, false, false); dd(I0, I1, false, false); dd(I0, I2, false, false); dd(I0, I3, false, false);
+      __builtin_amdgcn_sched_barrier(0);
+      next_stage_in();
+      dd(I1, I0, true, false);
+      __builtin_amdgcn_sched_barrier(0);
+      read_up(nslot, 0, uh[0], ul[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      dd(I1, I1, true, false); dd(I1, I2, true, false);
+      issue_rel(th, std::integral_constant<int, 2 + PDIST>{}, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      dd(I1, I3, true, false); dd(I1, I0, false, true); dd(I1, I1, false, true);
+      issue_rel(th, std::integral_constant<int, 2 + PDIST>{}, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      dd(I1, I2, false, true); dd(I1, I3, false, true); dd(I1, I0, false, false);
+      issue_rel(th, std::integral_constant<int, 2 + PDIST>{}, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      dd(I1, I1, false, false); dd(I1, I2, false, false);
+      issue_rel(th, std::integral_constant<int, 2 + PDIST>{}, 3);
+      dd(I1, I3, false, false);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (probe && th == 4) p.clk[11] = __builtin_amdgcn_s_memtime();
+  }
+  if (probe) p.clk[12] = __builtin_amdgcn_s_memtime();
+
+  // ---- + x, store (as above) -------------------------------------------------------------------------------------------------------------
+  char* strip = smem + NSTG * STG + 4 * SCL + wid * 2048;
+  float* st_row[2];
+  const float* sk_row[2];
+  bool st_ok[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int r = m0 + wid * 32 + 16 * it + (lane >> 2);
+    st_ok[it] = r < p.M;
+    st_row[it] = p.Y + (size_t)min(r, p.M - 1) * K + 4 * (lane & 3);
+    sk_row[it] = p.X + (size_t)min(r, p.M - 1) * K + 4 * (lane & 3);
+  }
+  f32x4 skip_all[NOB][2][2];
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) skip_all[ob][hb][it] = *reinterpret_cast<const f32x4*>(sk_row[it] + 32 * ob + 16 * hb);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 3" ::: "memory");       // tail LDS-DMA drained; last MFMA results readable
+  static_for<NOB>([&](auto ob_) {
+    constexpr int ob = decltype(ob_)::value;
+    f32x4 blk[4];
+    static_for<4>([&](auto g_) { blk[decltype(g_)::value] = areg_read4<AO + 16 * ob + 4 * decltype(g_)::value>(); });
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const f32x4 (&skip)[2] = skip_all[ob][hb];
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg)
+        *reinterpret_cast<f32x4*>(strip + l31 * 64 + (((2 * gg + lh) ^ ((l31 >> 2) & 1)) << 4)) = blk[2 * hb + gg];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int r16 = 16 * it + (lane >> 2), c = lane & 3;
+        const f32x4 o = *reinterpret_cast<const f32x4*>(strip + r16 * 64 + ((c ^ ((r16 >> 2) & 1)) << 4));
+        if (st_ok[it]) *reinterpret_cast<f32x4*>(st_row[it] + 32 * ob + 16 * hb) = o + skip[it];
+      }
+    }
+  });
+  if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)(T2 * UNIT); }
+}
+
 extern unsigned long long* g_clk;      // gemm_x3.hip (kd_prof_clock_buffer)
+
+static int launch_ffn_half(const FArgs3& a, const char* nm, double flops, double bytes, hipStream_t s) {
+  constexpr int LDS = 4 * STG + 4 * 1024 + 4 * 2048;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_x3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  LaunchScope prof(nm, flops, bytes, s);
+  hipLaunchKernelGGL(ffn_x3h_kernel, dim3((unsigned)((a.M + 127) / 128)), dim3(256), LDS, s, a);
+  return check_launch("kd_ffn_f32");
+}
 
 template <int NC>
 static int launch_ffn(const FArgs3& a, const char* nm, double flops, double bytes, hipStream_t s) {
@@ -398,6 +767,7 @@ extern "C" int kd_ffn_f32(const KdFfn* dp, void* stream) {
   const double bytes = 4.0 * (2.0 * d.M * d.K + 3.0 * d.d_ff * d.K);
   char nm[96] = "ffn_x3";
   if (prof_on()) snprintf(nm, sizeof(nm), "ffn_x3 M=%d K=%d d_ff=%d", d.M, d.K, d.d_ff);
+  if (d.K == 128 && option("ffn_x3_half", 1)) return x3::launch_ffn_half(a, nm, flops, bytes, (hipStream_t)stream);
   if (d.K == 128) return x3::launch_ffn<8>(a, nm, flops, bytes, (hipStream_t)stream);
   return x3::launch_ffn<16>(a, nm, flops, bytes, (hipStream_t)stream);
 }

@@ -78,6 +78,14 @@ __device__ __forceinline__ void areg_write4(const u32x4 v) {
 __device__ __forceinline__ void mfma_vv(f32x16& acc, const bf16x8 w, const bf16x8 a) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
 }
+// first MFMA of an accumulate chain: C = 0 (inline constant), the accumulator is written only
+__device__ __forceinline__ void mfma_vv0(f32x16& acc, const bf16x8 w, const bf16x8 a) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(a));
+}
+template <int IDX>
+__device__ __forceinline__ void mfma_ag0(f32x16& acc, const bf16x8 w) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(acc) : "v"(w), "i"(IDX), "i"(IDX + 3));
+}
 template <int IDX>
 __device__ __forceinline__ void mfma_ag(f32x16& acc, const bf16x8 w) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(w), "i"(IDX), "i"(IDX + 3));
