@@ -110,6 +110,16 @@ for name, B, H, W, nh, Kd, dff in LEVELS:
             tl = timeline(fn)
             if tl:
                 print(tl.replace("tile0 K loop", "tile0 up").replace("tile0 epilogue", "tile0 GEGLU + down"))
+    # the residual projection behind the attention core (out = x + att W_o^T): round-3 A-stationary kernel vs the round-1 tile kernel
+    wo = (torch.randn(Kd, Kd, generator=g) * Kd ** -0.5).to(dev)
+    att = torch.randn(B, T, Kd, generator=g).to(dev)
+    line = f"{name} out-proj M={B * T:6d} N={Kd:3d} K={Kd:3d}"
+    for opt in (1, 0):
+        nat.set_option("x3_res", opt)
+        us = timed(lambda: ops.gemm(att, wo, yo, M=B * T, N=Kd, K=Kd, epi=nat.EPI_RESIDUAL, residual=res))
+        line += f" | x3_res={opt}: {us:7.1f} us {12.0 * B * T * Kd / us * 1e-3:5.0f} GB/s (x3 executed {6.0 * B * T * Kd * Kd / us * 1e-6 / 2500:.2f} of peak)"
+    nat.set_option("x3_res", 1)
+    print(line)
     for cname, fn in cases.items():
         nw = 3 * d if cname == "qkv" else 2 * dff
         flops = 2.0 * B * T * nw * Kd

@@ -142,6 +142,12 @@ typedef struct KdFfn {
   const void* Wp_up;
   const void* Wp_down;
   int M, K, d_ff;
+  /* kd_ffn_f32 only (round 3), both NULL or both set: the attention block's out projection fused in front of the block
+   * (image_transformer_v2.py:473-476 then :487-493):  x' = x + attn Wout^T;  out = x' + down(GEGLU(up(norm(x')))).
+   * attn = [M, K] fp32 (the attention core's output, heads merged), Wp_out = kd_pack_weight_bf16x3(out_proj.weight [K, K], N = K, K,
+   * geglu = 0), and Wp_up must then be packed with geglu = 3 (the k order in which an MFMA result holds a row).  K == 128. */
+  const void* attn;
+  const void* Wp_out;
 } KdFfn;
 int kd_ffn_bf16_supported(int M, int K, int d_ff);
 int kd_ffn_bf16(const KdFfn* desc, void* stream);

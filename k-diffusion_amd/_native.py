@@ -59,6 +59,7 @@ class KdFfn(C.Structure):
         ("scale_stride", C.c_int), ("rows_per_sample", C.c_int), ("eps", C.c_float),
         ("Wp_up", C.c_void_p), ("Wp_down", C.c_void_p),
         ("M", C.c_int), ("K", C.c_int), ("d_ff", C.c_int),
+        ("attn", C.c_void_p), ("Wp_out", C.c_void_p),
     ]
 
 

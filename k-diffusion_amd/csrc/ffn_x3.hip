@@ -28,6 +28,7 @@ struct FArgs3 {
   int M, d_ff, n_tiles;
   int warm;
   unsigned long long* clk;
+  const float* Att; const char* Wo;   // fused out projection in front of the block (round 3): X <- X + Att Wo^T first; NULL = none
 };
 
 // acc_o block ob (32 output features) of this lane's row: AccVGPRs AO + 16 ob .. + 15
@@ -405,11 +406,23 @@ template <int IDX>
 __device__ __forceinline__ void mfma_acc_ag_lo(const bf16x8 w, const bf16x8 h) {
   asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(w), "v"(h), "i"(IDX), "i"(IDX + 15) : KD_AGPR_LO128);
 }
+// output accumulators (named AccVGPRs) += W fragment x activation fragment held in AccVGPRs too
+template <int IDX, int BIDX>
+__device__ __forceinline__ void mfma_acc_aa_lo(const bf16x8 w) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, a[%c3:%c4], a[%c1:%c2]" :: "v"(w), "i"(IDX), "i"(IDX + 15), "i"(BIDX), "i"(BIDX + 3) : KD_AGPR_LO128);
+}
 template <int IDX>
 __device__ __forceinline__ void areg_zero16_lo() {
   static_for<16>([&](auto i_) { asm volatile("v_accvgpr_write_b32 a[%c0], 0" :: "i"(IDX + decltype(i_)::value) : KD_AGPR_LO128); });
 }
 
+// OUTP: the attention block's out projection runs first, in the same workgroup (x <- x + att Wo^T, image_transformer_v2.py:473-476 in front of
+// :487-493): the wave's 32 ATTENTION rows become the B fragments (a0..a63), the output accumulators start from x (read straight into the C
+// layout) and take 4 stages of Wo; what they then hold IS the new residual stream in the layout of an MFMA result -- which, with the up
+// projection's weight packed in that k order (pack layout 3), is also the up projection's B operand: norm statistics, scale and hi / lo
+// split happen in registers, the fragments replace the attention ones, and the block's own down projection keeps accumulating on top of
+// the new x, so that neither the out projection's result nor the skip operand ever crosses HBM (per level-0 layer: 402 -> 201 MB).
+template <bool OUTP>
 __global__ __launch_bounds__(256, 2) void ffn_x3h_kernel(const FArgs3 p) {
   constexpr int NC = 8, K = 128, NOB = 4;
   constexpr int NSTG = 4, PDIST = NSTG - 1, PB = 4, UNIT = 3;   // stages per half tile: 2 up + 1 down
@@ -442,11 +455,19 @@ __global__ __launch_bounds__(256, 2) void ffn_x3h_kernel(const FArgs3 p) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
 
-  // ---- this wave's 32 rows -> a0..a63 (hi / lo fragments of the normalised, scaled row) -------------------------------------------------
+  // ---- this wave's 32 rows -> a0..a63 (hi / lo fragments of the normalised, scaled row; OUTP: of the attention row as it is) --------------
   const int row = m0 + wid * 32 + l31;
   const bool ok = row < p.M;
   const int rowc = ok ? row : p.M - 1;
-  float rs;
+  float rs = 1.f;
+  f32x4 xres[OUTP ? NOB : 1][4];                       // OUTP: x of the lane's row in the C layout (features 32 ob + 8 g + 4 lh + 0..3)
+  if constexpr (OUTP) {
+    const float* xr = p.X + (size_t)rowc * K + 4 * lh;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xres[ob][g] = *reinterpret_cast<const f32x4*>(xr + 32 * ob + 8 * g);
+  }
   {
     char* stage = smem + wid * STG;
     char* scl = smem + NSTG * STG + wid * SCL;
@@ -464,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void ffn_x3h_kernel(const FArgs3 p) {
     for (int i = 0; i < PIECES; ++i) {
       const int ci = i * 64 + lane, rr = ci / CPR, qs = ci % CPR;
       const int grow = min(m0 + wid * 32 + rr, p.M - 1);
-      const char* src = reinterpret_cast<const char*>(p.X + (size_t)grow * K) + ((qs ^ (rr & 15)) << 4);
+      const char* src = reinterpret_cast<const char*>((OUTP ? p.Att : p.X) + (size_t)grow * K) + ((qs ^ (rr & 15)) << 4);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(stage + i * 1024), 16, 0, 0);
     }
@@ -478,41 +499,71 @@ __global__ __launch_bounds__(256, 2) void ffn_x3h_kernel(const FArgs3 p) {
         const int q = 4 * (c0 + u) + 2 * lh;
         x0[u] = *reinterpret_cast<const f32x4*>(rowp + ((q ^ (l31 & 15)) << 4));
         x1[u] = *reinterpret_cast<const f32x4*>(rowp + (((q + 1) ^ (l31 & 15)) << 4));
-        if (uni) {
-          s0[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
-          s1[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
-        } else {
-          s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
-          s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
+        if constexpr (!OUTP) {
+          if (uni) {
+            s0[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
+            s1[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
+          } else {
+            s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
+            s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
       static_for<4>([&](auto u_) {
         constexpr int u = decltype(u_)::value;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ssq = fmaf(x0[u][e], x0[u][e], fmaf(x1[u][e], x1[u][e], ssq));
         u32x4 hi, lo;
-        split8(x0[u] * s0[u], x1[u] * s1[u], hi, lo);
+        if constexpr (OUTP) {
+          split8(x0[u], x1[u], hi, lo);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ssq = fmaf(x0[u][e], x0[u][e], fmaf(x1[u][e], x1[u][e], ssq));
+          split8(x0[u] * s0[u], x1[u] * s1[u], hi, lo);
+        }
         areg_write4_lo<8 * (c0 + u)>(hi);
         areg_write4_lo<8 * (c0 + u) + 4>(lo);
       });
       __builtin_amdgcn_sched_barrier(0);
     });
-    ssq += __shfl_xor(ssq, 32, 64);
-    rs = rsqrtf(ssq / (float)K + p.eps);
+    if constexpr (!OUTP) {
+      ssq += __shfl_xor(ssq, 32, 64);
+      rs = rsqrtf(ssq / (float)K + p.eps);
+    }
   }
-  static_for<NOB>([&](auto ob_) { areg_zero16_lo<AO + 16 * decltype(ob_)::value>(); });
+  if constexpr (OUTP) {                                // the output accumulators start from x
+    static_for<NOB>([&](auto ob_) {
+      static_for<4>([&](auto g_) {
+        constexpr int ob = decltype(ob_)::value, gq = decltype(g_)::value;
+        areg_write4_lo<AO + 16 * ob + 4 * gq>(__builtin_bit_cast(u32x4, xres[ob][gq]));
+      });
+    });
+  } else {
+    static_for<NOB>([&](auto ob_) { areg_zero16_lo<AO + 16 * decltype(ob_)::value>(); });
+  }
   code_warm_end(warm);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   KD_BARRIER();                                        // every wave has taken its rows out of the slot it borrowed
-  static_for<PDIST>([&](auto s_) {
+  // OUTP: the stream starts with the 4 stages of Wo ([128 out rows][32 k] hi | lo, plain layout); the block's own stages follow in the same
+  // ring positions as without it (4 stages = once round the ring)
+  auto issue_wo = [&](int q, int j) {
+    const char* src = p.Wo + (size_t)q * STG + wid * (PB * 1024) + j * 1024 + lane * 16;
+    char* dst = smem + (q % NSTG) * STG + wid * (PB * 1024) + j * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  if constexpr (OUTP) {
 #pragma unroll
-    for (int j = 0; j < PB; ++j) issue_rel(0, s_, j);
-  });
+    for (int q = 0; q < PDIST; ++q)
+#pragma unroll
+      for (int j = 0; j < PB; ++j) issue_wo(q, j);
+  } else {
+    static_for<PDIST>([&](auto s_) {
+#pragma unroll
+      for (int j = 0; j < PB; ++j) issue_rel(0, s_, j);
+    });
+  }
   if (probe) p.clk[4] = __builtin_amdgcn_s_memtime();
 
   const int o0 = swz64(l31, lh), o1 = swz64(l31, 2 + lh);
-  const float rsh = 0.5f * rs;
   f32x16 acc[2];
   bf16x8 uh[2][2], ul[2][2];                           // up: [chunk parity][value / gate block]
   bf16x8 dh[2][4], dl[2][4];                           // down: [hidden chunk][output block]
@@ -537,14 +588,88 @@ __global__ __launch_bounds__(256, 2) void ffn_x3h_kernel(const FArgs3 p) {
     wait_vm(PB * (PDIST - 2));
     KD_BARRIER();
   };
-  wait_vm(PB * (PDIST - 1));
-  KD_BARRIER();
-  read_up(0, 0, uh[0], ul[0]);
-
   constexpr std::integral_constant<int, 0> I0{};
   constexpr std::integral_constant<int, 1> I1{};
   constexpr std::integral_constant<int, 2> I2{};
   constexpr std::integral_constant<int, 3> I3{};
+  wait_vm(PB * (PDIST - 1));
+  KD_BARRIER();
+  if constexpr (OUTP) {
+    // ================= out projection: x (in the output accumulators) += att Wo^T, 4 stages of 24 MFMAs ===================================
+    read_dn(0, 0, dh[0], dl[0]);
+    static_for<4>([&](auto q_) {
+      constexpr int q = decltype(q_)::value;
+      auto oo = [&](auto b_, auto j_, bool w_lo, auto al_) {
+        constexpr int b = decltype(b_)::value, j = decltype(j_)::value, al = decltype(al_)::value, c = 2 * q + b;
+        mfma_acc_aa_lo<AO + 16 * j, 8 * c + 4 * al>(w_lo ? dl[b][j] : dh[b][j]);
+      };
+      auto request = [&](int j) {                      // stage q + 3 of the stream: Wo's last stage, then the block's first three
+        if constexpr (q == 0) issue_wo(3, j);
+        else issue_rel(0, std::integral_constant<int, (q > 0 ? q - 1 : 0)>{}, j);
+      };
+      oo(I0, I0, true, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_dn(q % NSTG, 1, dh[1], dl[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      oo(I0, I1, true, I0); oo(I0, I2, true, I0); oo(I0, I3, true, I0);
+      oo(I0, I0, false, I1); oo(I0, I1, false, I1); oo(I0, I2, false, I1); oo(I0, I3, false, I1);
+      oo(I0, I0, false, I0); oo(I0, I1, false, I0); oo(I0, I2, false, I0); oo(I0, I3, false, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      next_stage_in();
+      oo(I1, I0, true, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (q < 3) read_dn((q + 1) % NSTG, 0, dh[0], dl[0]);
+      else read_up(0, 0, uh[0], ul[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      oo(I1, I1, true, I0); oo(I1, I2, true, I0);
+      request(0);
+      __builtin_amdgcn_sched_barrier(0);
+      oo(I1, I3, true, I0); oo(I1, I0, false, I1); oo(I1, I1, false, I1);
+      request(1);
+      __builtin_amdgcn_sched_barrier(0);
+      oo(I1, I2, false, I1); oo(I1, I3, false, I1); oo(I1, I0, false, I0);
+      request(2);
+      __builtin_amdgcn_sched_barrier(0);
+      oo(I1, I1, false, I0); oo(I1, I2, false, I0);
+      request(3);
+      oo(I1, I3, false, I0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // asm MFMA results -> v_accvgpr_read
+    // ---- new x (C layout, still in the accumulators) -> AdaRMSNorm statistics, scale, hi / lo fragments in the k order of pack layout 3:
+    // chunk 2 ob + hc of the row = registers 8 hc .. + 7 of output block ob -----------------------------------------------------------
+    {
+      const char* scl = smem + NSTG * STG + wid * SCL;
+      const int r_first = min(m0 + wid * 32, p.M - 1), r_last = min(m0 + wid * 32 + 31, p.M - 1);
+      const bool uni = p.scale_stride == 0 || r_first / p.rows_per_sample == r_last / p.rows_per_sample;
+      const float* sg = uni ? nullptr : p.scale + (size_t)(rowc / p.rows_per_sample) * p.scale_stride + 4 * lh;
+      const float* sl = reinterpret_cast<const float*>(scl) + 4 * lh;
+      float ssq = 0.f;
+      static_for<NOB>([&](auto ob_) {
+        constexpr int ob = decltype(ob_)::value;
+        f32x4 v[4], sc[4];
+        static_for<4>([&](auto g_) { v[decltype(g_)::value] = areg_read4<AO + 16 * ob + 4 * decltype(g_)::value>(); });
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sc[g] = uni ? *reinterpret_cast<const f32x4*>(sl + 32 * ob + 8 * g) : *reinterpret_cast<const f32x4*>(sg + 32 * ob + 8 * g);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ssq = fmaf(v[g][e], v[g][e], ssq);
+        static_for<2>([&](auto hc_) {
+          constexpr int hc = decltype(hc_)::value;
+          u32x4 hi, lo;
+          split8(v[2 * hc] * sc[2 * hc], v[2 * hc + 1] * sc[2 * hc + 1], hi, lo);
+          areg_write4_lo<8 * (2 * ob + hc)>(hi);
+          areg_write4_lo<8 * (2 * ob + hc) + 4>(lo);
+        });
+      });
+      ssq += __shfl_xor(ssq, 32, 64);
+      rs = rsqrtf(ssq / (float)K + p.eps);
+    }
+  } else {
+    read_up(0, 0, uh[0], ul[0]);
+  }
+  const float rsh = 0.5f * rs;
   for (int th = 0; th < T2; ++th) {
     const int slot0 = (th * UNIT) % NSTG;
     if (probe && th == 4) p.clk[8] = __builtin_amdgcn_s_memtime();
@@ -681,13 +806,14 @@ __global__ __launch_bounds__(256, 2) void ffn_x3h_kernel(const FArgs3 p) {
     st_row[it] = p.Y + (size_t)min(r, p.M - 1) * K + 4 * (lane & 3);
     sk_row[it] = p.X + (size_t)min(r, p.M - 1) * K + 4 * (lane & 3);
   }
-  f32x4 skip_all[NOB][2][2];
+  f32x4 skip_all[NOB][2][2];                           // (OUTP: the accumulators started from x: nothing to add)
 #pragma unroll
   for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-      for (int it = 0; it < 2; ++it) skip_all[ob][hb][it] = *reinterpret_cast<const f32x4*>(sk_row[it] + 32 * ob + 16 * hb);
+      for (int it = 0; it < 2; ++it)
+        skip_all[ob][hb][it] = OUTP ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(sk_row[it] + 32 * ob + 16 * hb);
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 3" ::: "memory");       // tail LDS-DMA drained; last MFMA results readable
   static_for<NOB>([&](auto ob_) {
@@ -713,15 +839,17 @@ __global__ __launch_bounds__(256, 2) void ffn_x3h_kernel(const FArgs3 p) {
 
 extern unsigned long long* g_clk;      // gemm_x3.hip (kd_prof_clock_buffer)
 
+template <bool OUTP>
 static int launch_ffn_half(const FArgs3& a, const char* nm, double flops, double bytes, hipStream_t s) {
   constexpr int LDS = 4 * STG + 4 * 1024 + 4 * 2048;
+  auto kern = ffn_x3h_kernel<OUTP>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_x3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   LaunchScope prof(nm, flops, bytes, s);
-  hipLaunchKernelGGL(ffn_x3h_kernel, dim3((unsigned)((a.M + 127) / 128)), dim3(256), LDS, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + 127) / 128)), dim3(256), LDS, s, a);
   return check_launch("kd_ffn_f32");
 }
 
@@ -767,7 +895,15 @@ extern "C" int kd_ffn_f32(const KdFfn* dp, void* stream) {
   const double bytes = 4.0 * (2.0 * d.M * d.K + 3.0 * d.d_ff * d.K);
   char nm[96] = "ffn_x3";
   if (prof_on()) snprintf(nm, sizeof(nm), "ffn_x3 M=%d K=%d d_ff=%d", d.M, d.K, d.d_ff);
-  if (d.K == 128 && option("ffn_x3_half", 1)) return x3::launch_ffn_half(a, nm, flops, bytes, (hipStream_t)stream);
+  if (d.attn) {
+    if (!d.Wp_out) return fail(KD_EINVAL, "kd_ffn_f32: attn without Wp_out");
+    if (d.K != 128) return fail(KD_EINVAL, "kd_ffn_f32: the fused out projection needs K == 128 (K=%d)", d.K);
+    a.Att = reinterpret_cast<const float*>(d.attn); a.Wo = reinterpret_cast<const char*>(d.Wp_out);
+    const double fl2 = flops + 2.0 * d.M * d.K * d.K, by2 = 4.0 * (3.0 * d.M * d.K + 3.0 * d.d_ff * d.K + (double)d.K * d.K);
+    if (prof_on()) snprintf(nm, sizeof(nm), "ffn_x3+out M=%d K=%d d_ff=%d", d.M, d.K, d.d_ff);
+    return x3::launch_ffn_half<true>(a, nm, fl2, by2, (hipStream_t)stream);
+  }
+  if (d.K == 128 && option("ffn_x3_half", 1)) return x3::launch_ffn_half<false>(a, nm, flops, bytes, (hipStream_t)stream);
   if (d.K == 128) return x3::launch_ffn<8>(a, nm, flops, bytes, (hipStream_t)stream);
   return x3::launch_ffn<16>(a, nm, flops, bytes, (hipStream_t)stream);
 }

@@ -552,13 +552,14 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   const int c = idx & 3, r = (idx >> 2) & (BN - 1);
   const long blk = idx >> 9;
   const int ks = blk % nk, nt = blk / nk;
-  const int wrow = w_row_of(nt, r, N, geglu == 1);
+  const int wrow = w_row_of(nt, r, N, (geglu & 1) != 0);
   float v[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    // layout 2 (down projection of the fused FF block, ffn_x3.hip): inside every group of 16 k the order in which the GEGLU epilogue's
-    // accumulator registers hold the hidden features: 0-3, 8-11, 4-7, 12-15 (chunk c = 2 g + h of the stage: k 16 g + 4 h + {0..3, 8..11})
-    const int k = ks * BK + (geglu == 2 ? 16 * (c >> 1) + 4 * (c & 1) + (u & 3) + 8 * (u >> 2) : c * 8 + u);
+    // layout bit 2 (down projection of the fused FF block, ffn_x3.hip; with bit 1 -- layout 3 -- its up projection behind a fused out
+    // projection): inside every group of 16 k the order in which an MFMA's accumulator registers hold a row's features: 0-3, 8-11, 4-7,
+    // 12-15 (chunk c = 2 g + h of the stage: k 16 g + 4 h + {0..3, 8..11}), so that a C-layout result IS the next product's B operand
+    const int k = ks * BK + ((geglu & 2) ? 16 * (c >> 1) + 4 * (c & 1) + (u & 3) + 8 * (u >> 2) : c * 8 + u);
     v[u] = (wrow >= 0 && k < K) ? W[(long)wrow * K + k] : 0.f;
   }
   u32x2 h0, l0, h1, l1;
@@ -682,13 +683,13 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
 
 extern "C" long long kd_packed_weight_bytes(int N, int K, int geglu) {
   if (N <= 0 || K <= 0) return 0;
-  const long n_tiles = (N + (geglu == 1 ? 64 : BN) - 1) / (geglu == 1 ? 64 : BN), nk = (K + BK - 1) / BK;
+  const long n_tiles = (N + ((geglu & 1) ? 64 : BN) - 1) / ((geglu & 1) ? 64 : BN), nk = (K + BK - 1) / BK;
   return n_tiles * nk * (long long)WP_BLOCK;
 }
 
 extern "C" int kd_pack_weight_bf16x3(const float* W, void* out, int N, int K, int geglu, void* stream) {
-  if (!W || !out || N <= 0 || K <= 0 || geglu < 0 || geglu > 2) return fail(KD_EINVAL, "kd_pack_weight_bf16x3: bad arguments");
-  const int n_tiles = (N + (geglu == 1 ? 64 : BN) - 1) / (geglu == 1 ? 64 : BN), nk = (K + BK - 1) / BK;
+  if (!W || !out || N <= 0 || K <= 0 || geglu < 0 || geglu > 3) return fail(KD_EINVAL, "kd_pack_weight_bf16x3: bad arguments");
+  const int n_tiles = (N + ((geglu & 1) ? 64 : BN) - 1) / ((geglu & 1) ? 64 : BN), nk = (K + BK - 1) / BK;
   const long total = (long)n_tiles * nk * BN * 4;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
                      reinterpret_cast<char*>(out), N, K, geglu, n_tiles, nk);

@@ -27,6 +27,7 @@ struct XArgs {
   int M, N, n_tiles, n_splits;
   int n_heads; const float* qk_scale; const float* pos; const float* freq; int qkv_packed;
   float out_add;
+  const float* R;                   // KD_EPI_RESIDUAL: [M, N] added to the product (the accumulators start from it); one n-tile per workgroup
   int warm;
   unsigned long long* clk;
 };
@@ -75,6 +76,24 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
   const bool probe = p.clk && blockIdx.x == 0 && tid == 0;
   if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
 
+  // KD_EPI_RESIDUAL (out projection: no norm, + x): the accumulators START from the residual, read straight into the C layout (lane
+  // (l31, lh), block j, register 4 g + e <-> row l31, feature 32 j + 8 g + 4 lh + e: 16 bytes per load, 32 contiguous bytes per row and
+  // instruction) at kernel entry, in flight behind the row staging.  One n-tile per workgroup (the host forces n_splits = n_tiles): a
+  // vector load between two tiles would make hipcc drain the weight ring (vmcnt(0)).
+  f32x16 acc[4];
+  if constexpr (EPI == KD_EPI_RESIDUAL) {
+    const int rrow = min(m0 + wid * 32 + l31, p.M - 1);
+    const float* rp = p.R + (size_t)rrow * p.N + nt_begin * NCOL + 4 * lh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rp + 32 * j + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = v[e];
+      }
+  }
+
   const char* wp = p.Wp + (size_t)nt_begin * NK * STG + wid * (PB * 1024) + lane * 16;
   // stage s of this workgroup's W stream -> ring slot s % NSTG.  Stages past the end re-request the last one (into a slot nobody reads
   // any more): every wave then issues exactly PB pieces per stage, which keeps the vmcnt arithmetic uniform and lets the requests sit
@@ -101,7 +120,8 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
     char* stage = smem + wid * WAREA;
     char* scl = smem + NSTG * STG + wid * SCL;
     const int r_first = min(m0 + wid * 32, p.M - 1), r_last = min(m0 + wid * 32 + 31, p.M - 1);
-    const bool uni = p.scale_stride == 0 || r_first / p.rows_per_sample == r_last / p.rows_per_sample;
+    constexpr bool nrm = EPI != KD_EPI_RESIDUAL;         // (the residual projection has no norm in front: the row is split as it is)
+    const bool uni = nrm && (p.scale_stride == 0 || r_first / p.rows_per_sample == r_last / p.rows_per_sample);
     if (uni) {     // the sample's scale vector -> LDS (K * 4 bytes; lanes past the vector re-read its start: a whole 1 KiB piece lands)
       const char* ssrc = reinterpret_cast<const char*>(p.scale + (size_t)(r_first / p.rows_per_sample) * p.scale_stride);
 #pragma unroll
@@ -132,12 +152,14 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
           const int q = 4 * (c0 - r * (NC / NR) + u) + 2 * lh;             // 16-byte chunk inside this round's part of the row
           x0[u] = *reinterpret_cast<const f32x4*>(rowp + ((q ^ (l31 & 15)) << 4));
           x1[u] = *reinterpret_cast<const f32x4*>(rowp + (((q + 1) ^ (l31 & 15)) << 4));
-          if (uni) {
-            s0[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
-            s1[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
-          } else {
-            s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
-            s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
+          if constexpr (nrm) {
+            if (uni) {
+              s0[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
+              s1[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
+            } else {
+              s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
+              s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -146,7 +168,8 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
 #pragma unroll
           for (int e = 0; e < 4; ++e) ssq = fmaf(x0[u][e], x0[u][e], fmaf(x1[u][e], x1[u][e], ssq));
           u32x4 hi, lo;
-          split8(x0[u] * s0[u], x1[u] * s1[u], hi, lo);
+          if constexpr (nrm) split8(x0[u] * s0[u], x1[u] * s1[u], hi, lo);
+          else split8(x0[u], x1[u], hi, lo);
           if constexpr (AG) {
             areg_write4<8 * (c0 + u)>(hi);
             areg_write4<8 * (c0 + u) + 4>(lo);
@@ -161,7 +184,7 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
       if constexpr (NR > 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the area is overwritten by the next round
     });
     ssq += __shfl_xor(ssq, 32, 64);
-    rs = rsqrtf(ssq / (float)K + p.eps);
+    rs = nrm ? rsqrtf(ssq / (float)K + p.eps) : 1.f;
   }
   float py = 0.f, px = 0.f;
   if (EPI == KD_EPI_QKV) {
@@ -192,11 +215,12 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
     st_ok[it] = r < p.M;
     st_row[it] = p.C + (size_t)min(r, p.M - 1) * p.N + 4 * (lane & 3);
   }
-  f32x16 acc[4];
+  if constexpr (EPI != KD_EPI_RESIDUAL) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  }
   if constexpr (AG) asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 
   bf16x8 wh[2][4], wl[2][4];
@@ -414,7 +438,7 @@ static int cu_count() {
 }
 
 template <int NC, int EPI>
-static int launch(const XArgs& a0, const char* nm, double flops, double bytes, hipStream_t s) {
+static int launch(const XArgs& a0, const char* nm, double flops, double bytes, hipStream_t s, int force_splits = 0) {
   auto kern = gemm_x3_astat_kernel<NC, EPI>;
   constexpr int K = NC * 16, NSTG = NC <= 8 ? 4 : 8;
   constexpr int LDS = NSTG * STG + 4 * (K * 4 < 1024 ? 1024 : K * 4) + 4 * 2048 + 1024;     // ring + scale vectors + store strips + per-head constants
@@ -435,7 +459,7 @@ static int launch(const XArgs& a0, const char* nm, double flops, double bytes, h
     const long cost = rounds * (1 + a0.n_tiles / sp);
     if (best_cost < 0 || cost < best_cost) { best = sp; best_cost = cost; }
   }
-  const int forced = option("x3_splits", 0);
+  const int forced = force_splits ? force_splits : option("x3_splits", 0);
   XArgs a = a0;
   a.n_splits = forced > 0 && forced <= a0.n_tiles ? forced : best;
   LaunchScope prof(nm, flops, bytes, s);
@@ -449,16 +473,20 @@ static int launch(const XArgs& a0, const char* nm, double flops, double bytes, h
 int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc) {
   using namespace x3;
   if (!option("x3", 1)) return 1;
-  if (d.precision != KD_PREC_SPLIT3 || d.a_mode != KD_A_PLAIN || !d.norm || !d.Wp || d.debug) return 1;
-  if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_QKV && d.epi != KD_EPI_GEGLU) return 1;
+  if (d.precision != KD_PREC_SPLIT3 || d.a_mode != KD_A_PLAIN || !d.Wp || d.debug) return 1;
+  if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_QKV && d.epi != KD_EPI_GEGLU && d.epi != KD_EPI_RESIDUAL) return 1;
+  // norm -> wide projection, or (round 3) the plain residual projection behind the attention core: C = R + A W^T
+  // (K = 512 only: 25.3 vs 27.1 us at the headline shape; at K = 128 it is level with the round-1 tile kernel (both at the memory roof) and
+  // at K = 256 slower, 32.0 vs 26.4 us -- a workgroup there pays a whole row prologue for one or two n-tiles: benchmarks/x3_bench.py)
+  if (d.epi == KD_EPI_RESIDUAL ? (d.norm || !d.R || d.K != 512 || !option("x3_res", 1)) : !d.norm) return 1;
   if (d.K != 128 && d.K != 256 && d.K != 512) return 1;
   const int ncol = d.epi == KD_EPI_GEGLU ? 64 : 128;
-  if (d.N % ncol || d.M < 512 || d.rows_per_sample <= 0) return 1;
+  if (d.N % ncol || d.M < 512 || (d.norm && d.rows_per_sample <= 0)) return 1;
   if (d.epi == KD_EPI_QKV && (!d.rope_pos || !d.rope_freq || d.n_heads > 16)) return 1;   // tables only / many heads: round-1 kernel
   if (d.c_split && (d.epi != KD_EPI_GEGLU || !d.C_lo || (d.N & 31))) return 1;
   XArgs a{};
   a.A = d.A; a.Wp = reinterpret_cast<const char*>(d.Wp); a.C = d.C;
-  a.scale = d.scale; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample; a.eps = d.eps;
+  a.scale = d.norm ? d.scale : nullptr; a.R = d.R; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample > 0 ? d.rows_per_sample : d.M; a.eps = d.eps;
   a.M = d.M; a.N = d.N; a.n_tiles = d.N / ncol; a.n_splits = 1;
   a.n_heads = d.n_heads; a.qk_scale = d.qk_scale; a.pos = d.rope_pos; a.freq = d.rope_freq; a.qkv_packed = d.qkv_packed;
   a.out_add = d.out_add;
@@ -467,13 +495,14 @@ int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc) {
   a.clk = g_clk;
   const double n_eff = d.epi == KD_EPI_GEGLU ? 2.0 * d.N : (double)d.N;
   const double flops = 2.0 * d.M * n_eff * d.K;
-  const double bytes = 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N);
+  const double bytes = 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N * (d.epi == KD_EPI_RESIDUAL ? 2 : 1));
   char nm[96] = "gemm_x3_astat";
   if (prof_on()) snprintf(nm, sizeof(nm), "gemm_x3_astat<e%d> M=%d N=%d K=%d", d.epi, d.M, d.N, d.K);
-#define KD_X3(NCV, EP) if (d.K == NCV * 16 && d.epi == EP) { *rc = launch<NCV, EP>(a, nm, flops, bytes, s); return 0; }
+#define KD_X3(NCV, EP) if (d.K == NCV * 16 && d.epi == EP) { *rc = launch<NCV, EP>(a, nm, flops, bytes, s, EP == KD_EPI_RESIDUAL ? a.n_tiles : 0); return 0; }
   KD_X3(8, KD_EPI_STORE) KD_X3(8, KD_EPI_QKV) KD_X3(8, KD_EPI_GEGLU)
   KD_X3(16, KD_EPI_STORE) KD_X3(16, KD_EPI_QKV) KD_X3(16, KD_EPI_GEGLU)
   KD_X3(32, KD_EPI_STORE) KD_X3(32, KD_EPI_QKV) KD_X3(32, KD_EPI_GEGLU)
+  KD_X3(32, KD_EPI_RESIDUAL)
 #undef KD_X3
   return 1;
 }

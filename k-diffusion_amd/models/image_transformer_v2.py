@@ -395,6 +395,9 @@ class _Plan:
             lv, (gh, gw), T = levels[li], grids[li], toks[li]
             d, x = lv.width, xs[li]
             rps = gh * gw
+            ffn_x3 = precision == nat.PREC_SPLIT3 and target is self.launches and lib.kd_ffn_f32_supported(T, d, lv.d_ff) \
+                and os.environ.get("KDIFF_FFN_X3", "1") != "0"
+            fuse_out = ffn_x3 and hasattr(mod, "self_attn") and d == 128 and os.environ.get("KDIFF_FFN_OUT", "1") != "0"
             if hasattr(mod, "self_attn"):
                 sa, spec = mod.self_attn, lv.self_attn
                 nh = d // spec.d_head
@@ -441,15 +444,19 @@ class _Plan:
                     call(prefix + "attn_na2d", lib.kd_attn_na2d_f32, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.kernel_size, *prep)
                 else:
                     call(prefix + "attn_window", lib.kd_attn_window_f32, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.window_size, shift, *prep)
-                gemm(prefix + "out_proj", att, sa.out_proj.weight, x, T, d, d, epi=nat.EPI_RESIDUAL, R=x)
-            if precision == nat.PREC_SPLIT3 and target is self.launches and lib.kd_ffn_f32_supported(T, d, lv.d_ff) \
-                    and os.environ.get("KDIFF_FFN_X3", "1") != "0":
-                # fp32-parity mode: the whole FeedForwardBlock in one kernel (csrc/ffn_x3.hip), hidden activation on the chip
+                if not fuse_out:
+                    gemm(prefix + "out_proj", att, sa.out_proj.weight, x, T, d, d, epi=nat.EPI_RESIDUAL, R=x)
+            if ffn_x3:
+                # fp32-parity mode: the whole FeedForwardBlock in one kernel (csrc/ffn_x3.hip), hidden activation on the chip; at width 128
+                # the attention block's out projection runs in front of it in the same kernel (x + att W_out^T never crosses HBM)
                 fd = nat.KdFfn()
                 fd.x = fd.out = x.data_ptr()
                 fd.scale_stride, fd.rows_per_sample, fd.eps = total, rps, 1e-6
-                fd.Wp_up = m._packed_image(mod.ff.up_proj.weight, lv.d_ff, d, 1).data_ptr()
+                fd.Wp_up = m._packed_image(mod.ff.up_proj.weight, lv.d_ff, d, 3 if fuse_out else 1).data_ptr()
                 fd.Wp_down = m._packed_image(mod.ff.down_proj.weight, d, lv.d_ff, 2).data_ptr()
+                if fuse_out:
+                    fd.attn = att.data_ptr()
+                    fd.Wp_out = m._packed_image(mod.self_attn.out_proj.weight, d, d, 0).data_ptr()
                 fd.M, fd.K, fd.d_ff = T, d, lv.d_ff
                 self.norm_descs.append((fd, scale_ptr(prefix + "ff.norm")[1]))
                 self.keep.append(fd)

@@ -725,6 +725,31 @@ def test_split3_projections_round3(KD, ops, monkeypatch, H, W, nh, B, K):
     assert relerr(qkv, old) < 1e-4 and (B * T < 512 or K >= 512 or not torch.equal(qkv, old))      # (another kernel really ran)
 
 
+@pytest.mark.parametrize("M,K,N", [(1024, 512, 512), (1000, 512, 512), (8192, 512, 512), (2048, 256, 256), (640, 512, 256)])
+def test_split3_residual_projection_round3(KD, ops, monkeypatch, M, K, N):
+    """out = residual + A W^T (the projection behind the attention core) on the round-3 A-stationary kernel (taken at K = 512: the
+    accumulators start from the residual, one n-tile per workgroup); full and ragged row panels, in place (out is the residual) and
+    not, and against the round-1 kernel (option x3_res = 0; K = 256 goes there anyway)."""
+    from k_diffusion_amd import _native as nat
+    monkeypatch.setenv("KDIFF_GEMM", "split3")
+    a, res = rn(M, K, seed=21), rn(M, N, seed=22)
+    w = rn(N, K, seed=23, scale=K ** -0.5)
+    ref = res + a @ w.T
+    out = torch.empty(M, N, device="cuda")
+    ops.gemm(g(a), g(w), out, M=M, N=N, K=K, epi=nat.EPI_RESIDUAL, residual=g(res))
+    assert relerr(out, ref) < 1e-4
+    inplace = g(res).clone()
+    ops.gemm(g(a), g(w), inplace, M=M, N=N, K=K, epi=nat.EPI_RESIDUAL, residual=inplace)
+    assert torch.equal(inplace, out)
+    nat.set_option("x3_res", 0)
+    try:
+        old = torch.empty_like(out)
+        ops.gemm(g(a), g(w), old, M=M, N=N, K=K, epi=nat.EPI_RESIDUAL, residual=g(res))
+    finally:
+        nat.set_option("x3_res", 1)
+    assert relerr(old, ref) < 1e-4 and relerr(out, old) < 1e-4
+
+
 @pytest.mark.parametrize("H,W,B,K,dff", [(64, 64, 2, 128, 384), (32, 32, 4, 256, 768), (48, 40, 2, 128, 320), (30, 30, 3, 256, 448)])
 def test_fused_feed_forward_split3(KD, ops, monkeypatch, H, W, B, K, dff):
     """kd_ffn_f32 (csrc/ffn_x3.hip): the whole FeedForwardBlock (image_transformer_v2.py:487-493) in fp32-parity arithmetic against the
@@ -746,6 +771,27 @@ def test_fused_feed_forward_split3(KD, ops, monkeypatch, H, W, B, K, dff):
     assert torch.equal(xi, y)
     with pytest.raises(RuntimeError, match="kd_ffn_f32"):
         ops.ffn(g(rn(4, 96, seed=1)), g(rn(1, 96, seed=2)), g(rn(2 * 64, 96, seed=3)), g(rn(96, 64, seed=4)), rows_per_sample=4)
+
+
+@pytest.mark.parametrize("H,W,B,K,dff", [(64, 64, 2, 128, 384), (48, 40, 2, 128, 320), (30, 30, 3, 128, 192)])
+def test_fused_out_projection_and_feed_forward_split3(KD, ops, monkeypatch, H, W, B, K, dff):
+    """kd_ffn_f32 with the attention block's out projection fused in front (KdFfn.attn / Wp_out): x' = x + attn W_out^T (:473-476), then
+    x' + ff(x') (:487-493), against the oracle's separate steps and against out projection + fused block as two calls."""
+    monkeypatch.setenv("KDIFF_GEMM", "split3")
+    T = H * W
+    x, att, scale = rn(B, T, K, seed=31), rn(B, T, K, seed=32), 1 + 0.2 * rn(B, K, seed=33)
+    wo = rn(K, K, seed=34, scale=K ** -0.5)
+    wu, wd = rn(2 * dff, K, seed=35, scale=K ** -0.5), rn(K, dff, seed=36, scale=dff ** -0.5)
+    y = ops.ffn(g(x), g(scale), g(wu), g(wd), rows_per_sample=T, attn=g(att), w_out=g(wo))
+    x1 = x + att @ wo.T
+    ref = x1 + hdit.linear_geglu(hdit.rms_norm(x1, scale[:, None, :]), wu) @ wd.T
+    assert relerr(y, ref) < 1e-4
+    x1g = ops.linear(g(att), g(wo), residual=g(x))
+    two = ops.ffn(x1g, g(scale), g(wu), g(wd), rows_per_sample=T)
+    assert relerr(y, two) < 1e-4
+    xi = g(x).clone()                                   # in place, as the model runs it
+    ops.ffn(xi, g(scale), g(wu), g(wd), out=xi, rows_per_sample=T, attn=g(att), w_out=g(wo))
+    assert torch.equal(xi, y)
 
 
 def test_bf16_attention_cores(ops, golden):
