@@ -145,7 +145,7 @@ typedef struct KdFfn {
   /* kd_ffn_f32 only (round 3), both NULL or both set: the attention block's out projection fused in front of the block
    * (image_transformer_v2.py:473-476 then :487-493):  x' = x + attn Wout^T;  out = x' + down(GEGLU(up(norm(x')))).
    * attn = [M, K] fp32 (the attention core's output, heads merged), Wp_out = kd_pack_weight_bf16x3(out_proj.weight [K, K], N = K, K,
-   * geglu = 0), and Wp_up must then be packed with geglu = 3 (the k order in which an MFMA result holds a row).  K == 128. */
+   * geglu = 0), and Wp_up must then be packed with geglu = 3 (the k order in which an MFMA result holds a row). */
   const void* attn;
   const void* Wp_out;
 } KdFfn;

@@ -48,8 +48,15 @@ __device__ __forceinline__ f32x4 areg_read4() {
   return v;
 }
 
-template <int NC /* K / 16: 8 or 16 */>
+// output accumulators (named AccVGPRs) += W fragment x activation fragment held in AccVGPRs too (fused out projection, see ffn_x3h_kernel)
+template <int IDX, int BIDX>
+__device__ __forceinline__ void mfma_acc_aa(const bf16x8 w) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, a[%c3:%c4], a[%c1:%c2]" :: "v"(w), "i"(IDX), "i"(IDX + 15), "i"(BIDX), "i"(BIDX + 3) : KD_AGPR_ALL);
+}
+
+template <int NC /* K / 16: 8 or 16 */, bool OUTP = false /* K = 256: the attention block's out projection first (FArgs3.Att / Wo) */>
 __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
+  static_assert(!OUTP || NC == 16, "fused out projection: width 256 here, width 128 in ffn_x3h_kernel");
   constexpr int K = NC * 16, NKU = NC / 2;                      // ring stages of a tile's up projection
   constexpr int NOB = K / 32, NKD = 2 * (K / 128);              // output blocks of a row; ring stages of a tile's down-projection k-steps
   constexpr int UNIT = NKU + NKD;                               // stages per d_ff tile
@@ -92,7 +99,15 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
   const bool ok = row < p.M;
   const int rowc = ok ? row : p.M - 1;
   bf16x8 a_hi[AG ? 1 : NC], a_lo[AG ? 1 : NC];
-  float rs;
+  float rs = 1.f;
+  f32x4 xres[OUTP ? NOB : 1][4];                       // OUTP: x of the lane's row in the C layout (features 32 ob + 8 g + 4 lh + 0..3)
+  if constexpr (OUTP) {
+    const float* xr = p.X + (size_t)rowc * K + 4 * lh;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xres[ob][g] = *reinterpret_cast<const f32x4*>(xr + 32 * ob + 8 * g);
+  }
   {
     char* stage = smem + (EARLY ? EARLY * STG + wid * STG : wid * WAREA);
     char* scl = smem + NSTG * STG + wid * SCL;
@@ -112,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
     for (int i = 0; i < PIECES; ++i) {
       const int ci = i * 64 + lane, rr = ci / CPR, qs = ci % CPR;
       const int grow = min(m0 + wid * 32 + rr, p.M - 1);
-      const char* src = reinterpret_cast<const char*>(p.X + (size_t)grow * K) + ((qs ^ (rr & 15)) << 4);
+      const char* src = reinterpret_cast<const char*>((OUTP ? p.Att : p.X) + (size_t)grow * K) + ((qs ^ (rr & 15)) << 4);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(stage + i * 1024), 16, 0, 0);
     }
@@ -134,21 +149,27 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
         const int q = 4 * (c0 + u) + 2 * lh;
         x0[u] = *reinterpret_cast<const f32x4*>(rowp + ((q ^ (l31 & 15)) << 4));
         x1[u] = *reinterpret_cast<const f32x4*>(rowp + (((q + 1) ^ (l31 & 15)) << 4));
-        if (uni) {
-          s0[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
-          s1[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
-        } else {
-          s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
-          s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
+        if constexpr (!OUTP) {
+          if (uni) {
+            s0[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
+            s1[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
+          } else {
+            s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
+            s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
       static_for<4>([&](auto u_) {
         constexpr int u = decltype(u_)::value;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ssq = fmaf(x0[u][e], x0[u][e], fmaf(x1[u][e], x1[u][e], ssq));
         u32x4 hi, lo;
-        split8(x0[u] * s0[u], x1[u] * s1[u], hi, lo);
+        if constexpr (OUTP) {
+          split8(x0[u], x1[u], hi, lo);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ssq = fmaf(x0[u][e], x0[u][e], fmaf(x1[u][e], x1[u][e], ssq));
+          split8(x0[u] * s0[u], x1[u] * s1[u], hi, lo);
+        }
         if constexpr (AG) {
           areg_write4<8 * (c0 + u)>(hi);
           areg_write4<8 * (c0 + u) + 4>(lo);
@@ -160,21 +181,46 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
       });
       __builtin_amdgcn_sched_barrier(0);
     });
-    ssq += __shfl_xor(ssq, 32, 64);
-    rs = rsqrtf(ssq / (float)K + p.eps);
+    if constexpr (!OUTP) {
+      ssq += __shfl_xor(ssq, 32, 64);
+      rs = rsqrtf(ssq / (float)K + p.eps);
+    }
   }
-  static_for<NOB>([&](auto ob_) { areg_zero16<AO + 16 * decltype(ob_)::value>(); });
+  if constexpr (OUTP) {                                // the output accumulators start from x
+    static_for<NOB>([&](auto ob_) {
+      static_for<4>([&](auto g_) {
+        constexpr int ob = decltype(ob_)::value, gq = decltype(g_)::value;
+        areg_write4<AO + 16 * ob + 4 * gq>(__builtin_bit_cast(u32x4, xres[ob][gq]));
+      });
+    });
+  } else {
+    static_for<NOB>([&](auto ob_) { areg_zero16<AO + 16 * decltype(ob_)::value>(); });
+  }
   code_warm_end(warm);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   KD_BARRIER();                                        // every wave has taken its rows out of the slots it borrowed
+  // OUTP: the stream starts with Wo's 2 NKU stages ([n-tile of 128 out rows][32-k stage], plain layout): twice round the ring, so the
+  // block's own stages keep their ring positions
+  constexpr int NWO = OUTP ? 2 * NKU : 0;
+  auto issue_wo = [&](int q, int j) {
+    const char* src = p.Wo + (size_t)q * STG + wid * (PB * 1024) + j * 1024 + lane * 16;
+    char* dst = smem + (q % NSTG) * STG + wid * (PB * 1024) + j * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  if constexpr (OUTP) {
 #pragma unroll
-  for (int s = EARLY; s < PDIST; ++s)
+    for (int q = 0; q < PDIST; ++q)
 #pragma unroll
-    for (int j = 0; j < PB; ++j) issue_rel(0, s, j);
+      for (int j = 0; j < PB; ++j) issue_wo(q, j);
+  } else {
+#pragma unroll
+    for (int s = EARLY; s < PDIST; ++s)
+#pragma unroll
+      for (int j = 0; j < PB; ++j) issue_rel(0, s, j);
+  }
   if (probe) p.clk[4] = __builtin_amdgcn_s_memtime();
 
   const int o0 = swz64(l31, lh), o1 = swz64(l31, 2 + lh);
-  const float rsh = 0.5f * rs;
   f32x16 acc[4];
   bf16x8 wh[2][4], wl[2][4];
   auto read_frags = [&](int slot, int h, bf16x8 (&fh)[4], bf16x8 (&fl)[4]) {
@@ -193,6 +239,81 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
   wait_vm(PB * (PDIST - 1));
   KD_BARRIER();
   read_frags(0, 0, wh[0], wl[0]);
+  if constexpr (OUTP) {
+    // ================= out projection: x (in the output accumulators) += att Wo^T, 2 n-tiles x NKU stages of 24 MFMAs ======================
+    constexpr std::integral_constant<int, 0> I0{};
+    constexpr std::integral_constant<int, 1> I1{};
+    constexpr std::integral_constant<int, 2> I2{};
+    constexpr std::integral_constant<int, 3> I3{};
+    static_for<NWO>([&](auto q_) {
+      constexpr int q = decltype(q_)::value, ntile = q / NKU, ks = q % NKU;
+      auto oo = [&](auto b_, auto j_, bool w_lo, auto al_) {
+        constexpr int b = decltype(b_)::value, j = decltype(j_)::value, al = decltype(al_)::value, c = 2 * ks + b;
+        mfma_acc_aa<AO + 16 * (4 * ntile + j), 8 * c + 4 * al>(w_lo ? wl[b][j] : wh[b][j]);
+      };
+      auto request = [&](int j) {                      // stream position q + PDIST: Wo's later stages, then the block's first ones
+        if constexpr (q + PDIST < NWO) issue_wo(q + PDIST, j);
+        else issue_rel(0, q + PDIST - NWO, j);
+      };
+      oo(I0, I0, true, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(q % NSTG, 1, wh[1], wl[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      oo(I0, I1, true, I0); oo(I0, I2, true, I0); oo(I0, I3, true, I0);
+      oo(I0, I0, false, I1); oo(I0, I1, false, I1); oo(I0, I2, false, I1); oo(I0, I3, false, I1);
+      oo(I0, I0, false, I0); oo(I0, I1, false, I0); oo(I0, I2, false, I0); oo(I0, I3, false, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      next_stage_in();
+      oo(I1, I0, true, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags((q + 1) % NSTG, 0, wh[0], wl[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      oo(I1, I1, true, I0); oo(I1, I2, true, I0);
+      request(0);
+      __builtin_amdgcn_sched_barrier(0);
+      oo(I1, I3, true, I0); oo(I1, I0, false, I1); oo(I1, I1, false, I1);
+      request(1);
+      __builtin_amdgcn_sched_barrier(0);
+      oo(I1, I2, false, I1); oo(I1, I3, false, I1); oo(I1, I0, false, I0);
+      request(2);
+      __builtin_amdgcn_sched_barrier(0);
+      oo(I1, I1, false, I0); oo(I1, I2, false, I0);
+      request(3);
+      oo(I1, I3, false, I0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // asm MFMA results -> v_accvgpr_read
+    // ---- new x (C layout, in the accumulators) -> norm statistics, scale, hi / lo fragments in the k order of pack layout 3 -----------
+    {
+      const char* scl = smem + NSTG * STG + wid * SCL;
+      const int r_first = min(m0 + wid * 32, p.M - 1), r_last = min(m0 + wid * 32 + 31, p.M - 1);
+      const bool uni = p.scale_stride == 0 || r_first / p.rows_per_sample == r_last / p.rows_per_sample;
+      const float* sg = uni ? nullptr : p.scale + (size_t)(rowc / p.rows_per_sample) * p.scale_stride + 4 * lh;
+      const float* sl = reinterpret_cast<const float*>(scl) + 4 * lh;
+      float ssq = 0.f;
+      static_for<NOB>([&](auto ob_) {
+        constexpr int ob = decltype(ob_)::value;
+        f32x4 v[4], sc[4];
+        static_for<4>([&](auto g_) { v[decltype(g_)::value] = areg_read4<AO + 16 * ob + 4 * decltype(g_)::value>(); });
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sc[g] = uni ? *reinterpret_cast<const f32x4*>(sl + 32 * ob + 8 * g) : *reinterpret_cast<const f32x4*>(sg + 32 * ob + 8 * g);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ssq = fmaf(v[g][e], v[g][e], ssq);
+        static_for<2>([&](auto hc_) {
+          constexpr int hc = decltype(hc_)::value;
+          u32x4 hi, lo;
+          split8(v[2 * hc] * sc[2 * hc], v[2 * hc + 1] * sc[2 * hc + 1], hi, lo);
+          areg_write4<8 * (2 * ob + hc)>(hi);
+          areg_write4<8 * (2 * ob + hc) + 4>(lo);
+        });
+      });
+      ssq += __shfl_xor(ssq, 32, 64);
+      rs = rsqrtf(ssq / (float)K + p.eps);
+    }
+  }
+  const float rsh = 0.5f * rs;
 
   for (int t = 0; t < T; ++t) {
     const int sbase = t * UNIT;
@@ -355,7 +476,8 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-      for (int it = 0; it < 2; ++it) skip_all[ob][hb][it] = *reinterpret_cast<const f32x4*>(sk_row[it] + 32 * ob + 16 * hb);
+      for (int it = 0; it < 2; ++it)
+        skip_all[ob][hb][it] = OUTP ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(sk_row[it] + 32 * ob + 16 * hb);
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 3" ::: "memory");       // tail LDS-DMA drained; last MFMA results readable
   static_for<NOB>([&](auto ob_) {
@@ -853,9 +975,9 @@ static int launch_ffn_half(const FArgs3& a, const char* nm, double flops, double
   return check_launch("kd_ffn_f32");
 }
 
-template <int NC>
+template <int NC, bool OUTP = false>
 static int launch_ffn(const FArgs3& a, const char* nm, double flops, double bytes, hipStream_t s) {
-  auto kern = ffn_x3_kernel<NC>;
+  auto kern = ffn_x3_kernel<NC, OUTP>;
   constexpr int K = NC * 16;
   constexpr int LDS = 8 * STG + 4 * (K * 4 < 1024 ? 1024 : K * 4) + 4 * 2048;
   static bool attr_set = false;
@@ -897,11 +1019,11 @@ extern "C" int kd_ffn_f32(const KdFfn* dp, void* stream) {
   if (prof_on()) snprintf(nm, sizeof(nm), "ffn_x3 M=%d K=%d d_ff=%d", d.M, d.K, d.d_ff);
   if (d.attn) {
     if (!d.Wp_out) return fail(KD_EINVAL, "kd_ffn_f32: attn without Wp_out");
-    if (d.K != 128) return fail(KD_EINVAL, "kd_ffn_f32: the fused out projection needs K == 128 (K=%d)", d.K);
     a.Att = reinterpret_cast<const float*>(d.attn); a.Wo = reinterpret_cast<const char*>(d.Wp_out);
     const double fl2 = flops + 2.0 * d.M * d.K * d.K, by2 = 4.0 * (3.0 * d.M * d.K + 3.0 * d.d_ff * d.K + (double)d.K * d.K);
     if (prof_on()) snprintf(nm, sizeof(nm), "ffn_x3+out M=%d K=%d d_ff=%d", d.M, d.K, d.d_ff);
-    return x3::launch_ffn_half<true>(a, nm, fl2, by2, (hipStream_t)stream);
+    if (d.K == 128) return x3::launch_ffn_half<true>(a, nm, fl2, by2, (hipStream_t)stream);
+    return x3::launch_ffn<16, true>(a, nm, fl2, by2, (hipStream_t)stream);
   }
   if (d.K == 128 && option("ffn_x3_half", 1)) return x3::launch_ffn_half<false>(a, nm, flops, bytes, (hipStream_t)stream);
   if (d.K == 128) return x3::launch_ffn<8>(a, nm, flops, bytes, (hipStream_t)stream);

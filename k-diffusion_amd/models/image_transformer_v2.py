@@ -397,7 +397,10 @@ class _Plan:
             rps = gh * gw
             ffn_x3 = precision == nat.PREC_SPLIT3 and target is self.launches and lib.kd_ffn_f32_supported(T, d, lv.d_ff) \
                 and os.environ.get("KDIFF_FFN_X3", "1") != "0"
-            fuse_out = ffn_x3 and hasattr(mod, "self_attn") and d == 128 and os.environ.get("KDIFF_FFN_OUT", "1") != "0"
+            # out projection fused into the FF kernel: width 128 (+3.5 % images/s; at width 256, one wave per SIMD, it measured level:
+            # 176.1 vs 176.0).  KDIFF_FFN_OUT: 0 never, 1 default, all = every width the kernel takes, or ONE width
+            fo = os.environ.get("KDIFF_FFN_OUT", "1")
+            fuse_out = ffn_x3 and hasattr(mod, "self_attn") and d in (128, 256) and (d == 128 if fo == "1" else fo in ("all", str(d)))
             if hasattr(mod, "self_attn"):
                 sa, spec = mod.self_attn, lv.self_attn
                 nh = d // spec.d_head
@@ -447,7 +450,7 @@ class _Plan:
                 if not fuse_out:
                     gemm(prefix + "out_proj", att, sa.out_proj.weight, x, T, d, d, epi=nat.EPI_RESIDUAL, R=x)
             if ffn_x3:
-                # fp32-parity mode: the whole FeedForwardBlock in one kernel (csrc/ffn_x3.hip), hidden activation on the chip; at width 128
+                # fp32-parity mode: the whole FeedForwardBlock in one kernel (csrc/ffn_x3.hip), hidden activation on the chip; at widths 128 / 256
                 # the attention block's out projection runs in front of it in the same kernel (x + att W_out^T never crosses HBM)
                 fd = nat.KdFfn()
                 fd.x = fd.out = x.data_ptr()

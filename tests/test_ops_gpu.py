@@ -773,7 +773,7 @@ def test_fused_feed_forward_split3(KD, ops, monkeypatch, H, W, B, K, dff):
         ops.ffn(g(rn(4, 96, seed=1)), g(rn(1, 96, seed=2)), g(rn(2 * 64, 96, seed=3)), g(rn(96, 64, seed=4)), rows_per_sample=4)
 
 
-@pytest.mark.parametrize("H,W,B,K,dff", [(64, 64, 2, 128, 384), (48, 40, 2, 128, 320), (30, 30, 3, 128, 192)])
+@pytest.mark.parametrize("H,W,B,K,dff", [(64, 64, 2, 128, 384), (48, 40, 2, 128, 320), (30, 30, 3, 128, 192), (32, 32, 4, 256, 768), (30, 30, 3, 256, 448)])
 def test_fused_out_projection_and_feed_forward_split3(KD, ops, monkeypatch, H, W, B, K, dff):
     """kd_ffn_f32 with the attention block's out projection fused in front (KdFfn.attn / Wp_out): x' = x + attn W_out^T (:473-476), then
     x' + ff(x') (:487-493), against the oracle's separate steps and against out projection + fused block as two calls."""
