@@ -1236,6 +1236,8 @@ extern "C" int kd_qk_prep_f32(float* qkv, const float* scale_h, const float* cos
   return check_launch("kd_qk_prep_f32");
 }
 
+namespace kd { int attn_global_x3_try(const float* qkv, float* out, int batch, int T, int nh, hipStream_t s, int* rc); }   // attn_x3.hip
+
 extern "C" int kd_attn_global_f32(const float* qkv, float* out, int batch, int T, int nh, int prep, const float* scale_h,
                                   const float* cos_t, const float* sin_t, float eps, int precision, void* stream) {
   if (!qkv || !out || batch <= 0 || nh <= 0 || T <= 0) return fail(KD_EINVAL, "kd_attn_global_f32: bad arguments");
@@ -1251,6 +1253,10 @@ extern "C" int kd_attn_global_f32(const float* qkv, float* out, int batch, int T
     return launch_global_long(a, prep, s);
   }
   if (!exact) {
+    if (prep == 2) {      // operands stored split by the qkv projection: the round-3 core (two workgroups per CU, LDS-DMA, transposing V reads)
+      int rc = 0;
+      if (!attn_global_x3_try(qkv, out, batch, T, nh, s, &rc)) return rc;
+    }
     if (T <= 64) return launch_global_split<MODE_GLOBAL, 2>(a, prep, nb, s);
     if (T <= 128) return launch_global_split<MODE_GLOBAL, 4>(a, prep, nb, s);
     return launch_global_split<MODE_GLOBAL, 8>(a, prep, nb, s);
@@ -1282,6 +1288,8 @@ extern "C" int kd_attn_window_f32(const float* qkv, float* out, int batch, int H
   return launch_dense<MODE_WINDOW16, 8>(a, prep, nb, "attn_window_f32", s);
 }
 
+namespace kd { int attn_na2d_x3_try(const float* qkv, float* out, int batch, int H, int W, int nh, hipStream_t s, int* rc); }   // attn_x3.hip
+
 extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, int W, int nh, int ks, int prep,
                                 const float* scale_h, const float* cos_t, const float* sin_t, float eps, int precision, void* stream) {
   (void)precision;
@@ -1289,9 +1297,13 @@ extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, 
   if (ks != NA_K) return fail(KD_EINVAL, "kd_attn_na2d_f32: kernel_size %d unsupported (only 7)", ks);
   if (H < ks || W < ks) return fail(KD_EINVAL, "kd_attn_na2d_f32: grid %dx%d smaller than the %dx%d neighbourhood", H, W, ks, ks);
   if (int e = check_prep(prep, scale_h, cos_t, sin_t, "kd_attn_na2d_f32")) return e;
+  hipStream_t s = (hipStream_t)stream;
+  if (prep == 2) {        // operands stored split by the qkv projection: the round-3 core (LDS-DMA halo, transposing V reads)
+    int rc = 0;
+    if (!attn_na2d_x3_try(qkv, out, batch, H, W, nh, s, &rc)) return rc;
+  }
   NaArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H, W, nh, eps, option("code_warm", KD_CODE_WARM_DEFAULT)};
   const long nb = (long)batch * nh * ((H + NA_TH - 1) / NA_TH) * ((W + NA_TW - 1) / NA_TW);
-  hipStream_t s = (hipStream_t)stream;
   char nm[64] = "attn_na2d";
   if (prof_on()) snprintf(nm, sizeof(nm), "attn_na2d %dx%d nh=%d", H, W, nh);
   LaunchScope prof(nm, 4.0 * batch * (double)H * W * nh * DH * ks * ks, 16.0 * batch * (double)H * W * nh * DH, s);

@@ -211,6 +211,7 @@ def test_bf16_fused_ffn_width_256(ops, B, T, d_ff):
 def test_split_stored_qkv_feeds_the_attention_cores(ops, monkeypatch, H, W, nh, B, K):
     """qkv_packed: the qkv GEMM stores q, k, v as split-bf16 chunks and the split cores (prep='packed') take them as stored.
     Same split of the same values, so every core must return BIT-identical results to the fp32-qkv path."""
+    from k_diffusion_amd import _native as nat
     monkeypatch.setenv("KDIFF_GEMM", "split3")
     T, N = H * W, 3 * nh * 64
     x, w = rn(B * T, K, seed=1), rn(N, K, seed=3) / K ** 0.5
@@ -228,8 +229,20 @@ def test_split_stored_qkv_feeds_the_attention_cores(ops, monkeypatch, H, W, nh, 
     assert relerr((hi + lo).view_as(plain), plain) < 2.0 ** -15
     assert torch.equal(hi.view_as(plain), plain.to(torch.bfloat16).to(torch.float32))
     if H >= 7 and W >= 7:
-        assert torch.equal(ops.attn_na2d(packed, nh, 7, prep="packed"), ops.attn_na2d(plain, nh, 7))
-    assert torch.equal(ops.attn_global(packed.view(B, T, N), nh, prep="packed"), ops.attn_global(plain.view(B, T, N), nh))   # T <= 256 and streaming
+        # (the split-stored operands go to the round-3 core, attn_x3.hip: same products, another summation order and exp2 softmax)
+        assert relerr(ops.attn_na2d(packed, nh, 7, prep="packed"), ops.attn_na2d(plain, nh, 7)) < 2e-5
+        nat.set_option("attn_x3", 0)
+        try:
+            assert torch.equal(ops.attn_na2d(packed, nh, 7, prep="packed"), ops.attn_na2d(plain, nh, 7))
+        finally:
+            nat.set_option("attn_x3", 1)
+    # T <= 256 and streaming (T = 64 / 128 / 256 split-stored: the round-3 core, other summation order; the round-1 core is bit-identical)
+    assert relerr(ops.attn_global(packed.view(B, T, N), nh, prep="packed"), ops.attn_global(plain.view(B, T, N), nh)) < 2e-5
+    nat.set_option("attn_x3", 0)
+    try:
+        assert torch.equal(ops.attn_global(packed.view(B, T, N), nh, prep="packed"), ops.attn_global(plain.view(B, T, N), nh))
+    finally:
+        nat.set_option("attn_x3", 1)
     if H % 8 == 0 and W % 8 == 0:
         for shift in (0, 4):
             assert torch.equal(ops.attn_window(packed, nh, 8, shift, prep="packed"), ops.attn_window(plain, nh, 8, shift))
@@ -426,6 +439,52 @@ def test_attn_global_long_sequences(ops, monkeypatch, H, W, nh, B):
     monkeypatch.setenv("KDIFF_GEMM", "exact")
     with pytest.raises(RuntimeError, match="streaming"):
         ops.attn_global(g(_pack(q, k, v)).view(B, T, -1), nh)
+
+
+def _split_stored(x):
+    """fp32 [..., 64] -> the qkv_packed storage: every 4 dims as 16 bytes [hi: 4 x bf16][lo: 4 x bf16], viewed as fp32 [..., 64]."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    sh = x.shape[:-1]
+    return torch.cat([hi.view(*sh, 16, 4), lo.view(*sh, 16, 4)], dim=-1).contiguous().view(torch.float32).view(*sh, 64)
+
+
+@pytest.mark.parametrize("H,W,nh,B", [(7, 7, 1, 2), (8, 8, 2, 1), (9, 12, 1, 2), (16, 16, 2, 2), (20, 13, 1, 1), (32, 32, 4, 1), (64, 64, 2, 1), (14, 22, 1, 1), (15, 40, 2, 1)])
+def test_attn_na2d_split_stored_round3(ops, monkeypatch, H, W, nh, B):
+    """The round-3 neighbourhood core (csrc/attn_x3.hip: halo rows by LDS-DMA, transposing V reads, K and V through one image) on operands
+    stored split, against the restated na2d and against the round-1 core on the same operands; images smaller than the 14 x 22 halo,
+    ragged tiles, border clamping."""
+    from k_diffusion_amd import _native as nat
+    monkeypatch.setenv("KDIFF_GEMM", "split3")
+    q, k, v = (rn(B, H, W, nh, 64, seed=s, scale=sc) for s, sc in ((1, 0.5), (2, 0.5), (3, 1.0)))
+    ref = hdit.na2d(q, k, v, 7, 1.0)
+    packed = g(_pack(_split_stored(q), _split_stored(k), _split_stored(v)))
+    y = ops.attn_na2d(packed, nh, 7, prep="packed").view(B, H, W, nh, 64)
+    assert relerr(y, ref) < 1e-4
+    nat.set_option("attn_x3", 0)
+    try:
+        old = ops.attn_na2d(packed, nh, 7, prep="packed").view(B, H, W, nh, 64)
+    finally:
+        nat.set_option("attn_x3", 1)
+    assert relerr(y, old) < 2e-5
+
+
+@pytest.mark.parametrize("T,nh,B", [(256, 8, 3), (128, 2, 2), (64, 1, 5), (256, 1, 1)])
+def test_attn_global_split_stored_round3(ops, monkeypatch, T, nh, B):
+    """The round-3 global core (csrc/attn_x3.hip) on operands stored split, T = 64 / 128 / 256, against the oracle and the round-1 core."""
+    from k_diffusion_amd import _native as nat
+    monkeypatch.setenv("KDIFF_GEMM", "split3")
+    q, k, v = (rn(B, 1, T, nh, 64, seed=s, scale=sc) for s, sc in ((4, 0.5), (5, 0.5), (6, 1.0)))
+    ref = hdit.attn_global(q, k, v, 1.0).view(B, T, nh, 64)
+    packed = g(_pack(_split_stored(q), _split_stored(k), _split_stored(v))).view(B, T, -1)
+    y = ops.attn_global(packed, nh, prep="packed").view(B, T, nh, 64)
+    assert relerr(y, ref) < 1e-4
+    nat.set_option("attn_x3", 0)
+    try:
+        old = ops.attn_global(packed, nh, prep="packed").view(B, T, nh, 64)
+    finally:
+        nat.set_option("attn_x3", 1)
+    assert relerr(y, old) < 2e-5
 
 
 @pytest.mark.parametrize("H,W,nh,B", [(7, 7, 1, 2), (8, 8, 2, 1), (9, 12, 1, 2), (16, 16, 2, 2), (20, 13, 1, 1), (32, 32, 4, 1)])
