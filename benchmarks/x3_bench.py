@@ -36,7 +36,7 @@ def timed(fn):
 
 
 def timeline(fn):
-    clk = torch.zeros(8, dtype=torch.int64, device=dev)
+    clk = torch.zeros(16, dtype=torch.int64, device=dev)
     nat.lib().kd_prof_clock_buffer(C.c_void_p(clk.data_ptr()))
     fn()
     torch.cuda.synchronize()
@@ -45,6 +45,9 @@ def timeline(fn):
     if c[3] <= c[1] or not c[4]:
         return ""
     ghz = (c[2] - c[0]) / (c[3] - c[1]) * 0.1
+    if c[8] and c[10]:       # half-tile kernels (two workgroups per CU): a workgroup of a later round, its second half tile
+        return (f"  wg 5/8 {c[2] - c[0]} clk @ {ghz:.2f} GHz: prologue {c[4] - c[0]}, half tile 1: K loop {c[9] - c[8]} (96 MFMAs: floor 3072), "
+                f"epilogue {c[10] - c[9]}, stages {c[7]}")
     return (f"  wg0 {c[2] - c[0]} clk @ {ghz:.2f} GHz: prologue {c[4] - c[0]}, tile0 K loop {c[5] - c[4]}, tile0 epilogue {c[6] - c[5]}, stages {c[7]}")
 
 
@@ -132,6 +135,10 @@ for name, B, H, W, nh, Kd, dff in LEVELS:
             if opt == 1:
                 tl = timeline(fn)
         nat.set_option("x3", 1)
+        if Kd == 256:                # two workgroups per CU over half tiles (default) vs one workgroup per CU
+            nat.set_option("x3_half", 0)
+            line += f" | x3_half=0: {timed(fn):7.1f} us"
+            nat.set_option("x3_half", 1)
         print(line)
         if tl:
             print(tl)

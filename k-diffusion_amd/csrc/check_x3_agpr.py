@@ -26,7 +26,7 @@ def main(src):
     pos = [(m.start(), m.group(1)) for m in re.finditer(r"\n(_ZN2kd2x3[A-Za-z0-9_]+):", txt)]
     checked = 0
     for (st, name), (en, _) in zip(pos, pos[1:] + [(len(txt), "")]):
-        if "gemm_x3_astat_kernelILi32E" not in name and "ffn_x3" not in name:
+        if "gemm_x3_astat_kernelILi32E" not in name and "ffn_x3" not in name and "gemm_x3h_kernel" not in name:
             continue
         body = txt[st:en].split(".end_amdhsa_kernel")[0]
         if not re.search(r"\.vgpr_spill_count:\s*0", txt[st:]) and "vgpr_spill_count" in txt[st:en]:

@@ -425,6 +425,294 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
   if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)total; }
 }
 
+// ===========================================================================================================================================
+// K = 256, TWO workgroups per CU.  At one workgroup per CU (NC = 16 above: 128 + 64 + 64 registers of fragments and accumulators per wave)
+// nothing runs while a wave is in its row prologue or in an epilogue: the level-1 qkv projection spends 5.4 k of every 14 k clocks per
+// n-tile in the cosine-sim / RoPE / store epilogue with the matrix pipe idle (benchmarks/x3_bench.py time line).  Same cure as ffn_x3.hip's
+// width-128 kernel: the row fragments go to the named AccVGPRs a0..a127 (all of that half of a two-wave budget), the n range is walked in
+// HALF tiles of 64 W rows (one head vector, or 32 GEGLU outputs: 32 accumulator registers), whose rows are one contiguous 4 KiB run of each
+// [128 rows][32 k] image of the packed weight, through a 4-stage ring (a stage = two 32-k sub-stages [hi 4 KiB | lo 4 KiB], 24 MFMAs).
+// <= 128 ArchVGPRs, 77 KiB of LDS: two independent workgroups per CU fill each other's prologues and epilogues.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(const XArgs p) {
+  constexpr int NC = 16, K = 256, NK = 8;                       // 32-k sub-stages of an n-tile in the packed image
+  constexpr int NSTG = 4, PDIST = NSTG - 1, PB = 4, UNIT = 4;   // ring stages per half tile
+  constexpr bool GEGLU = EPI == KD_EPI_GEGLU;
+  constexpr int HCOL = GEGLU ? 32 : 64;                         // output columns of a half tile
+  constexpr int NST = GEGLU ? 4 : 8;                            // 16-byte stores per lane per half tile
+  constexpr int KH = 128, NR = K / KH, CPR = KH / 4, PIECES = 32 * CPR / 64, SCL = 1024, SUB = 8192, HALF = 4096, CB = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const auto warm = code_warm_begin<20 * 1024>((int)blockIdx.x < p.warm && tid < 64);
+  int panel, split;
+  const int n_splits = p.n_splits, n_panels = gridDim.x / n_splits;
+  if ((n_panels & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    panel = (j / n_splits) * 8 + xcd;
+    split = j % n_splits;
+  } else {
+    panel = blockIdx.x % n_panels;
+    split = blockIdx.x / n_panels;
+  }
+  panel = __builtin_amdgcn_readfirstlane(panel);
+  split = __builtin_amdgcn_readfirstlane(split);
+  const int ht_begin = __builtin_amdgcn_readfirstlane((int)((long)p.n_tiles * split / n_splits));      // (n_tiles counts HALF tiles here)
+  const int ht_end = __builtin_amdgcn_readfirstlane((int)((long)p.n_tiles * (split + 1) / n_splits));
+  const int n_ht = ht_end - ht_begin, total = n_ht * UNIT;
+  const int m0 = panel * 128;
+  const bool probe = p.clk && blockIdx.x == (gridDim.x * 5) / 8 && tid == 0;
+  if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
+
+  // stage q of this workgroup's stream: half tile ht_begin + q / 4, sub-stages 2 (q % 4), + 1 of its n-tile; piece j: sub-stage j >> 1, hi / lo
+  // image j & 1 -- this wave's KiB of the half tile's 4 KiB run.  Past the end: the last stage again (never read).
+  const char* wp = p.Wp + wid * 1024 + lane * 16;
+  auto issue_piece = [&](int q_, int j) {
+    const int q = min(q_, total - 1), ht = ht_begin + (q >> 2), u = q & 3;
+    const char* src = wp + ((size_t)(ht >> 1) * NK + 2 * u + (j >> 1)) * STG + (j & 1) * IMG + (ht & 1) * HALF;
+    char* dst = smem + (q_ % NSTG) * STG + (j >> 1) * SUB + (j & 1) * HALF + wid * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+
+  // ---- this wave's 32 rows -> a0..a127 (two staging rounds of 128 floats per row) ------------------------------------------------------
+  const int row = m0 + wid * 32 + l31;
+  const bool ok = row < p.M;
+  const int rowc = ok ? row : p.M - 1;
+  float rs;
+  {
+    char* stage = smem + wid * STG;
+    char* scl = smem + NSTG * STG + wid * SCL;
+    const int r_first = min(m0 + wid * 32, p.M - 1), r_last = min(m0 + wid * 32 + 31, p.M - 1);
+    const bool uni = p.scale_stride == 0 || r_first / p.rows_per_sample == r_last / p.rows_per_sample;
+    if (uni) {
+      const char* ssrc = reinterpret_cast<const char*>(p.scale + (size_t)(r_first / p.rows_per_sample) * p.scale_stride);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc + lane * 16),
+                                       (__attribute__((address_space(3))) void*)scl, 16, 0, 0);
+    }
+    const float* sp = p.scale + (size_t)(rowc / p.rows_per_sample) * p.scale_stride + 8 * lh;
+    const float* spl = reinterpret_cast<const float*>(scl) + 8 * lh;
+    float ssq = 0.f;
+    static_for<NR>([&](auto r_) {
+      constexpr int r = decltype(r_)::value;
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) {
+        const int ci = i * 64 + lane, rr = ci / CPR, qs = ci % CPR;
+        const int grow = min(m0 + wid * 32 + rr, p.M - 1);
+        const char* src = reinterpret_cast<const char*>(p.A + (size_t)grow * K + r * KH) + ((qs ^ (rr & 15)) << 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + i * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const char* rowp = stage + l31 * (KH * 4);
+      static_for<NC / NR / CB>([&](auto c4_) {           // CB chunks at a time (registers: 128 ArchVGPRs for everything)
+        constexpr int c0 = r * (NC / NR) + CB * decltype(c4_)::value;
+        f32x4 x0[CB], x1[CB], s0[CB], s1[CB];
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+          const int q = 4 * (c0 - r * (NC / NR) + u) + 2 * lh;
+          x0[u] = *reinterpret_cast<const f32x4*>(rowp + ((q ^ (l31 & 15)) << 4));
+          x1[u] = *reinterpret_cast<const f32x4*>(rowp + (((q + 1) ^ (l31 & 15)) << 4));
+          if (uni) {
+            s0[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
+            s1[u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
+          } else {
+            s0[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u));
+            s1[u] = *reinterpret_cast<const f32x4*>(sp + 16 * (c0 + u) + 4);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<CB>([&](auto u_) {
+          constexpr int u = decltype(u_)::value;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ssq = fmaf(x0[u][e], x0[u][e], fmaf(x1[u][e], x1[u][e], ssq));
+          u32x4 hi, lo;
+          split8(x0[u] * s0[u], x1[u] * s1[u], hi, lo);
+          areg_write4_lo<8 * (c0 + u)>(hi);
+          areg_write4_lo<8 * (c0 + u) + 4>(lo);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (r + 1 < NR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the area is overwritten by the next round
+    });
+    ssq += __shfl_xor(ssq, 32, 64);
+    rs = rsqrtf(ssq / (float)K + p.eps);
+  }
+  float py = 0.f, px = 0.f;
+  if (EPI == KD_EPI_QKV) {
+    float* qk_tab = reinterpret_cast<float*>(smem + NSTG * STG + 4 * SCL + 4 * 2048);
+    if (tid < p.n_heads * 8) qk_tab[tid] = p.freq[tid];
+    if (tid < p.n_heads) qk_tab[128 + tid] = sqrtf(p.qk_scale[tid]);
+    const int tok = rowc % p.rows_per_sample;
+    py = p.pos[2 * tok];
+    px = p.pos[2 * tok + 1];
+    asm volatile("" : "+v"(py), "+v"(px));
+  }
+  code_warm_end(warm);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  KD_BARRIER();                                        // every wave has taken its rows out of the slot it borrowed
+  const bool full_panel = m0 + 128 <= p.M;
+#pragma unroll
+  for (int s = 0; s < PDIST; ++s)
+#pragma unroll
+    for (int j = 0; j < PB; ++j) issue_piece(s, j);
+  if (probe) p.clk[4] = __builtin_amdgcn_s_memtime();
+
+  const int o0 = swz64(l31, lh), o1 = swz64(l31, 2 + lh);
+  char* strip = smem + NSTG * STG + 4 * SCL + wid * 2048;
+  const char* qkc = smem + NSTG * STG + 4 * SCL + 4 * 2048;
+  float* st_row[2];
+  bool st_ok[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int r = m0 + wid * 32 + 16 * it + (lane >> 2);
+    st_ok[it] = r < p.M;
+    st_row[it] = p.C + (size_t)min(r, p.M - 1) * p.N + 4 * (lane & 3);
+  }
+  f32x16 acc[2];
+  bf16x8 uh[2][2], ul[2][2];                           // [chunk parity][W block of the half tile]
+  auto read_up = [&](int slot, int cc, bf16x8 (&fh)[2], bf16x8 (&fl)[2]) {
+    const char* st = smem + slot * STG + (cc >> 1) * SUB + ((cc & 1) ? o1 : o0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      fh[j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 64);
+      fl[j] = *reinterpret_cast<const bf16x8*>(st + HALF + j * 32 * 64);
+    }
+  };
+  auto store_block = [&](const f32x4 (&v)[4], int col) {
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg)
+        *reinterpret_cast<f32x4*>(strip + l31 * 64 + (((2 * gg + lh) ^ ((l31 >> 2) & 1)) << 4)) = v[2 * hb + gg];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int r16 = 16 * it + (lane >> 2), c = lane & 3;
+        const f32x4 o = *reinterpret_cast<const f32x4*>(strip + r16 * 64 + ((c ^ ((r16 >> 2) & 1)) << 4));
+        if (st_ok[it]) *reinterpret_cast<f32x4*>(st_row[it] + col + 16 * hb) = o;
+      }
+    }
+  };
+  wait_vm(PB * (PDIST - 1));
+  // (Starting one of a CU's two workgroups half a period late -- by wave-slot parity or by split parity, s_sleep -- so that their K loops
+  // and epilogues interleave was measured slower: 52.3 / 53.8 vs 49.0 us.  The tile phase is close to what the stores allow: 100 MB in
+  // ~30 us at level 1.)
+  KD_BARRIER();
+  read_up(0, 0, uh[0], ul[0]);
+
+  constexpr std::integral_constant<int, 0> I0{};
+  constexpr std::integral_constant<int, 1> I1{};
+  constexpr std::integral_constant<int, 2> I2{};
+  constexpr std::integral_constant<int, 3> I3{};
+  constexpr std::integral_constant<int, 4> I4{};
+  constexpr std::integral_constant<int, 5> I5{};
+  for (int h = 0; h < n_ht; ++h) {
+    if (probe && h == 1) p.clk[8] = __builtin_amdgcn_s_memtime();
+    static_for<UNIT>([&](auto u_) {
+      constexpr int u = decltype(u_)::value;
+      const int s = h * UNIT + u;
+      // the 6 MFMAs of chunk cc: (w_lo x a_hi), (w_hi x a_lo), (w_hi x a_hi) for the two W blocks in alternation
+      auto mm = [&](auto cc_, auto i_) {
+        constexpr int cc = decltype(cc_)::value, i = decltype(i_)::value, j = i & 1, term = i >> 1, c = 4 * u + cc;
+        const bf16x8& w = term == 0 ? ul[cc & 1][j] : uh[cc & 1][j];
+        constexpr int al = term == 1;
+        if constexpr (c == 0 && term == 0) mfma_ag0<8 * c + 4 * al>(acc[j], w);      // first MFMA of the chain: C = 0
+        else mfma_ag<8 * c + 4 * al>(acc[j], w);
+      };
+      mm(I0, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_up(u, 1, uh[1], ul[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I0, I1); mm(I0, I2); mm(I0, I3); mm(I0, I4); mm(I0, I5);
+      mm(I1, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_up(u, 2, uh[0], ul[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I1, I1); mm(I1, I2); mm(I1, I3); mm(I1, I4); mm(I1, I5);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        // behind stage s + 1 in this wave's queue: the stage requested after it and the stores of an epilogue that ran since its request
+        int allow = PB * (PDIST - 2);
+        if (full_panel && h > 0 && u + 2 <= PDIST) allow += NST;
+        wait_vm(allow);
+        KD_BARRIER();
+      }
+      mm(I2, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_up(u, 3, uh[1], ul[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I2, I1); mm(I2, I2);
+      issue_piece(s + PDIST, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I2, I3); mm(I2, I4); mm(I2, I5);
+      issue_piece(s + PDIST, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I3, I0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_up((u + 1) % NSTG, 0, uh[0], ul[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I3, I1); mm(I3, I2);
+      issue_piece(s + PDIST, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(I3, I3); mm(I3, I4);
+      issue_piece(s + PDIST, 3);
+      mm(I3, I5);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));      // asm MFMA results -> vector reads
+    if (probe && h == 1) p.clk[9] = __builtin_amdgcn_s_memtime();
+
+    // ---- epilogue of the half tile, in the lane that owns the row -----------------------------------------------------------------------
+    const int n0 = (ht_begin + h) * HCOL;
+    if (GEGLU) {
+      const float rsh = 0.5f * rs;
+      f32x4 blk[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x2 a = geglu_pair(f32x2{acc[0][4 * g], acc[0][4 * g + 1]} * rsh, f32x2{acc[1][4 * g], acc[1][4 * g + 1]} * rs);
+        const f32x2 b = geglu_pair(f32x2{acc[0][4 * g + 2], acc[0][4 * g + 3]} * rsh, f32x2{acc[1][4 * g + 2], acc[1][4 * g + 3]} * rs);
+        blk[g] = f32x4{a.x, a.y, b.x, b.y};
+      }
+      store_block(blk, n0);
+    } else if (EPI == KD_EPI_QKV) {
+      const int vec = n0 >> 6;                              // (q | k | v, head) vector index of these 64 columns
+      const int which = vec >= 2 * p.n_heads ? 2 : (vec >= p.n_heads ? 1 : 0), head = vec - which * p.n_heads;
+      if (which < 2) {
+        const f32x4 fv = *reinterpret_cast<const f32x4*>(qkc + (head * 8 + 4 * lh) * 4);
+        const float qsc = *reinterpret_cast<const float*>(qkc + 512 + head * 4);
+        const float fr[4] = {fv[0], fv[1], fv[2], fv[3]};
+        b16::qk_prep_blocks(acc[0], acc[1], rs, qsc, p.eps, py, px, fr);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] *= rs; acc[1][r] *= rs; }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        f32x4 blk[4];
+        const f32x16& a = acc[jj];
+        if (p.qkv_packed) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) blk[g] = pack_split4(f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]});
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) blk[g] = f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+        }
+        store_block(blk, n0 + 32 * jj);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4 blk[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) blk[g] = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]} * rs + p.out_add;
+        store_block(blk, n0 + 32 * j);
+      }
+    }
+    if (probe && h == 1) p.clk[10] = __builtin_amdgcn_s_memtime();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail requests still target this workgroup's LDS
+  if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)total; }
+}
+
 unsigned long long* g_clk = nullptr;
 
 static int cu_count() {
@@ -467,6 +755,33 @@ static int launch(const XArgs& a0, const char* nm, double flops, double bytes, h
   return check_launch("kd_gemm_f32(x3 astat)");
 }
 
+template <int EPI>
+static int launch_half(const XArgs& a0, const char* nm, double flops, double bytes, hipStream_t s) {
+  auto kern = gemm_x3h_kernel<EPI>;
+  constexpr int LDS = 4 * STG + 4 * 1024 + 4 * 2048 + 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  // the same cost model as launch() with two resident workgroups per CU; a prologue costs about two half tiles
+  const int panels = (a0.M + 127) / 128, slots = 2 * cu_count();
+  int best = 1;
+  long best_cost = -1;
+  for (int sp = 1; sp <= a0.n_tiles; ++sp) {
+    if (a0.n_tiles % sp) continue;
+    const long rounds = ((long)panels * sp + slots - 1) / slots;
+    const long cost = rounds * (2 + a0.n_tiles / sp);
+    if (best_cost < 0 || cost < best_cost) { best = sp; best_cost = cost; }
+  }
+  const int forced = option("x3_splits", 0);
+  XArgs a = a0;
+  a.n_splits = forced > 0 && forced <= a0.n_tiles && a0.n_tiles % forced == 0 ? forced : best;
+  LaunchScope prof(nm, flops, bytes, s);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(panels * a.n_splits)), dim3(256), LDS, s, a);
+  return check_launch("kd_gemm_f32(x3 half tiles)");
+}
+
 }  // namespace x3
 
 // Eligibility + dispatch (called by kd_gemm_f32 ahead of the round-1 A-stationary kernel).  Returns 1 if the descriptor was not taken.
@@ -498,6 +813,14 @@ int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc) {
   const double bytes = 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N * (d.epi == KD_EPI_RESIDUAL ? 2 : 1));
   char nm[96] = "gemm_x3_astat";
   if (prof_on()) snprintf(nm, sizeof(nm), "gemm_x3_astat<e%d> M=%d N=%d K=%d", d.epi, d.M, d.N, d.K);
+  if (d.K == 256 && d.epi != KD_EPI_RESIDUAL && !d.c_split && option("x3_half", 1)) {      // two workgroups per CU, half tiles
+    a.n_tiles = d.N / (d.epi == KD_EPI_GEGLU ? 32 : 64);
+    if (prof_on()) snprintf(nm, sizeof(nm), "gemm_x3_astat<e%d,h> M=%d N=%d K=%d", d.epi, d.M, d.N, d.K);
+    if (d.epi == KD_EPI_QKV) *rc = launch_half<KD_EPI_QKV>(a, nm, flops, bytes, s);
+    else if (d.epi == KD_EPI_GEGLU) *rc = launch_half<KD_EPI_GEGLU>(a, nm, flops, bytes, s);
+    else *rc = launch_half<KD_EPI_STORE>(a, nm, flops, bytes, s);
+    return 0;
+  }
 #define KD_X3(NCV, EP) if (d.K == NCV * 16 && d.epi == EP) { *rc = launch<NCV, EP>(a, nm, flops, bytes, s, EP == KD_EPI_RESIDUAL ? a.n_tiles : 0); return 0; }
   KD_X3(8, KD_EPI_STORE) KD_X3(8, KD_EPI_QKV) KD_X3(8, KD_EPI_GEGLU)
   KD_X3(16, KD_EPI_STORE) KD_X3(16, KD_EPI_QKV) KD_X3(16, KD_EPI_GEGLU)

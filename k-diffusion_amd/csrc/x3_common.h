@@ -74,6 +74,16 @@ __device__ __forceinline__ void areg_write4(const u32x4 v) {
   asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
                :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "i"(IDX), "i"(IDX + 1), "i"(IDX + 2), "i"(IDX + 3) : KD_AGPR_ALL);
 }
+// kernels that run TWO waves per SIMD have the low 128 AccVGPRs (hipcc splits a 256-register budget 128 + 128 once AccVGPRs are used)
+#define KD_A10(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+#define KD_AGPR_LO128                                                                                                                     \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", KD_A10(1), KD_A10(2), KD_A10(3), KD_A10(4), KD_A10(5), KD_A10(6), KD_A10(7),   \
+      KD_A10(8), KD_A10(9), KD_A10(10), KD_A10(11), "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+template <int IDX>
+__device__ __forceinline__ void areg_write4_lo(const u32x4 v) {
+  asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
+               :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "i"(IDX), "i"(IDX + 1), "i"(IDX + 2), "i"(IDX + 3) : KD_AGPR_LO128);
+}
 // all operands in ArchVGPRs, as asm: for kernels that name AccVGPRs themselves and cannot let the compiler choose the accumulator's file
 __device__ __forceinline__ void mfma_vv(f32x16& acc, const bf16x8 w, const bf16x8 a) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
