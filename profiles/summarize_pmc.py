@@ -30,7 +30,12 @@ def load(path, counter):
 
 def family_of(symbol):
     """rocprof kernel symbol -> the family name bench.py reports (LaunchScope names in csrc/)."""
-    for needle, name in (("x3::gemm_x3_astat_kernel", "gemm_x3_astat"), ("x3t::gemm_x3_tiled_kernel", "gemm_x3_tiled"), ("norm_split_kernel", "norm_split_f32"),
+    if "x3::ffn_x3" in symbol:          # ffn_x3_kernel<NC, OUTP> / ffn_x3h_kernel<OUTP>: with the out projection fused in front or not
+        outp = ("ffn_x3h_kernel<true" in symbol or "ffn_x3h_kernel<1" in symbol or ", true>" in symbol or ", 1>" in symbol
+                or "(bool)1" in symbol)
+        return "ffn_x3+out" if outp else "ffn_x3"
+    for needle, name in (("x3::gemm_x3_astat_kernel", "gemm_x3_astat"), ("x3::gemm_x3h_kernel", "gemm_x3_astat"),
+                         ("x3a::attn_na2d_x3_kernel", "attn_na2d_x3"), ("x3a::attn_global_x3_kernel", "attn_global_x3"), ("x3t::gemm_x3_tiled_kernel", "gemm_x3_tiled"), ("norm_split_kernel", "norm_split_f32"),
                          ("b16::ffn_kernel", "ffn_bf16"), ("b16::unpatch4_kernel", "gemm_bf16_unpatch4"), ("b16::patchin4_kernel", "gemm_bf16_patchin4"),
                          ("b16::gemm_wstat_kernel", "gemm_bf16_wstat"), ("b16::gemm_astat_kernel", "gemm_bf16_astat"), ("b16::gemm_tiled_kernel", "gemm_bf16_tiled"),
                          ("b16::gemm_generic_bf16_kernel", "gemm_bf16_generic"), ("b16::attn_na2d_bf16_kernel", "attn_na2d_bf16"),

@@ -37,7 +37,7 @@ def load(path):
 
 
 def short(name):
-    name = name.replace("void ", "").replace("kd::", "").replace("b16::", "").replace("x3t::", "").replace("x3::", "")
+    name = name.replace("void ", "").replace("kd::", "").replace("b16::", "").replace("x3t::", "").replace("x3a::", "").replace("x3::", "")
     return name.split("(")[0][:44]
 
 
