@@ -33,6 +33,30 @@ def test_library_exports_every_declared_symbol(KD):
     assert lib.kd_version() >= 100
 
 
+def test_ctypes_structs_mirror_the_header(KD):
+    """The descriptor structs of the C ABI are declared twice (include/kdiff_hip.h, k-diffusion_amd/_native.py): same field names in the
+    same order with the same kind (pointer / int / float), or every call through them reads garbage."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "kdiff_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    for name in ("KdGemm", "KdFfn"):
+        end = re.search(r"\}\s*" + name + r"\s*;", text).start()
+        body = text[text.rindex("typedef struct", 0, end):end].split("{", 1)[1]
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            kind = "p" if "*" in decl else ("f" if decl.startswith("float") else "i")
+            names = decl.replace("*", " ").split(None, 2 if decl.startswith("const") else 1)[-1]
+            fields += [(n.strip(), kind) for n in names.split(",")]
+        mirror = []
+        for fname, ftype in getattr(KD._native, name)._fields_:
+            mirror.append((fname, "p" if ftype is ctypes.c_void_p else ("f" if ftype is ctypes.c_float else "i")))
+        assert fields == mirror, (name, [a for a, b in zip(fields, mirror) if a != b][:3], len(fields), len(mirror))
+
+
 def test_schedule_rows_are_recognised_by_storage_and_version(KD):
     """prefetch_schedule bookkeeping (host logic, no GPU): a model call is served from a schedule's scale table only when its sigma
     argument IS a row of the hinted table -- same storage, same version counter, whole contiguous fp32 row."""
