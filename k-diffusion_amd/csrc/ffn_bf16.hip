@@ -27,6 +27,7 @@ struct FArgs {
   int M, n_tiles;            // n_tiles = d_ff / 64
   unsigned long long* clk;   // kd_prof_clock_buffer: time line of workgroup 0
   int warm;                  // code warm-up workgroups (kd_common.h)
+  const u16* Att; const char* Wo;   // fused out projection in front of the block (round 3, width 128): X <- X + Att Wo^T first; NULL = none
 };
 
 #define KD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -45,8 +46,15 @@ constexpr int FF_NW = 8;
 // barrier per tile otherwise keeps both waves of a SIMD in the SAME phase (both want the matrix pipe, then both want the VALU,
 // and the per-tile costs add up); skewed, one wave's MFMAs run beside the other's GEGLU.  The down-projection k-step of tile t - 1
 // has to stay one interval longer: its ring gets a fourth slot (3 x 32 KiB + 4 x 16 KiB = all 160 KiB of LDS).
-template <int NC /* K / 16 */, bool SKEW>
+// OUTP (round 3, as in ffn_x3.hip): the attention block's out projection runs first in the same workgroup (x <- x + att Wo^T,
+// image_transformer_v2.py:473-476).  The lane's ATTENTION row is the B operand as it is stored (bf16), the fp32 output accumulators start
+// from x (read into the C layout) and take the 32 MFMAs of Wo (32 KiB, parked in the ring slot the third weight unit will use); what they
+// then hold is the new residual stream in the layout of an MFMA result, which under pack layout 3 of the up projection's weight IS its B
+// operand: norm statistics, scale and rounding in registers, and the down projection keeps accumulating on top of the new x -- the out
+// projection's result and the skip operand never cross HBM (and the new x reaches the norm in fp32, not rounded to bf16).
+template <int NC /* K / 16 */, bool SKEW, bool OUTP = false>
 __global__ __launch_bounds__(FF_NW * 64) void ffn_kernel(const FArgs p) {
+  static_assert(!OUTP || (NC == 8 && !SKEW), "fused out projection: width 128, plain variant");
   constexpr int K = NC * 16, NKU = NC / 4, KB = K / 32, NTD = K / 128;
   constexpr int UP_BYTES = NKU * WBLK, DN_BYTES = NTD * WBLK, UNIT = UP_BYTES + DN_BYTES;
   constexpr int NDS = SKEW ? 4 : 3;                   // slots of the down-projection ring
@@ -87,22 +95,73 @@ __global__ __launch_bounds__(FF_NW * 64) void ffn_kernel(const FArgs p) {
 
   // ---- this lane's row: raw bf16 + the sample's scale vector requested first, then the first two weight units ----------------
   u32x4 raw[NC];
-  f32x4 s0[NC], s1[NC];
+  f32x4 s0[NC], s1[NC];                               // OUTP: the scale in the C layout (features 32 ob + 8 g + 4 lh .. + 3: s0 / s1[2 ob + (g >> 1)], g & 1)
   {
-    const u32x4* ap = reinterpret_cast<const u32x4*>(p.X + (size_t)rowc * K + 8 * lh);
-    const float* sp = p.scale + (size_t)(rowc / p.rows_per_sample) * p.scale_stride + 8 * lh;
+    const u32x4* ap = reinterpret_cast<const u32x4*>((OUTP ? p.Att : p.X) + (size_t)rowc * K + 8 * lh);
+    const float* sp = p.scale + (size_t)(rowc / p.rows_per_sample) * p.scale_stride + (OUTP ? 4 : 8) * lh;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       raw[c] = ap[2 * c];
       s0[c] = *reinterpret_cast<const f32x4*>(sp + 16 * c);
-      s1[c] = *reinterpret_cast<const f32x4*>(sp + 16 * c + 4);
+      s1[c] = *reinterpret_cast<const f32x4*>(sp + 16 * c + (OUTP ? 8 : 4));
     }
+  }
+  f32x16 acc_o[K / 32];
+  if constexpr (OUTP) {
+    // x of the lane's row -> the output accumulators (C layout); requested BEFORE the weight copies so that the counted wait below covers it
+    const u16* xrow = p.X + (size_t)rowc * K;
+#pragma unroll
+    for (int ob = 0; ob < K / 32; ++ob) {
+      float sk[16];
+      load_block_bf16(xrow + 32 * ob, sk, lh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_o[ob][r] = sk[r];
+    }
+    // Wo: two [128 rows][64 k] blocks -> the third up slot (free until unit 2 is requested)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.Wo + (wid + FF_NW * i) * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(up_slot(2) + (wid + FF_NW * i) * 1024), 16, 0, 0);
   }
   issue(0);
   if (T > 1) issue(1);
   bf16x8 a[NC];
   float rs;
-  {
+  if constexpr (OUTP) {
+    if (T > 1) { KD_WAIT_VM(12); } else { KD_WAIT_VM(6); }      // rows, x and Wo are in (the two weight units may still be in flight)
+    KD_BARRIER();
+    int offo[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) offo[cc] = swz128(l31, 2 * cc + lh);
+    const char* wo = up_slot(2);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const bf16x8 af = __builtin_bit_cast(bf16x8, raw[c]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wo + (c >> 2) * WBLK + offo[c & 3] + j * 32 * 128);
+        acc_o[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc_o[j], 0, 0, 0);
+      }
+    }
+    // new x (fp32, C layout) -> norm statistics, scale, bf16 fragments in the k order of pack layout 3: chunk 2 ob + hc = registers 8 hc .. + 7
+    float ssq = 0.f;
+#pragma unroll
+    for (int ob = 0; ob < K / 32; ++ob) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ssq = fmaf(acc_o[ob][r], acc_o[ob][r], ssq);
+#pragma unroll
+      for (int hc = 0; hc < 2; ++hc) {
+        const f32x4 sa = s0[2 * ob + hc], sb = s1[2 * ob + hc];      // features 32 ob + 16 hc + 4 lh + 0..3, and + 8
+        const f32x16& v = acc_o[ob];
+        u32x4 o = {pack_bf16(v[8 * hc] * sa[0], v[8 * hc + 1] * sa[1]), pack_bf16(v[8 * hc + 2] * sa[2], v[8 * hc + 3] * sa[3]),
+                   pack_bf16(v[8 * hc + 4] * sb[0], v[8 * hc + 5] * sb[1]), pack_bf16(v[8 * hc + 6] * sb[2], v[8 * hc + 7] * sb[3])};
+        asm volatile("" : "+v"(o));
+        a[2 * ob + hc] = __builtin_bit_cast(bf16x8, o);
+      }
+    }
+    ssq += __shfl_xor(ssq, 32, 64);
+    rs = rsqrtf(ssq / (float)K + p.eps);
+  } else {
     float ssq = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -126,11 +185,12 @@ __global__ __launch_bounds__(FF_NW * 64) void ffn_kernel(const FArgs p) {
   int off4[4];
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) off4[cc] = swz128(l31, 2 * cc + lh);
-  f32x16 acc_o[KB];
+  if constexpr (!OUTP) {
 #pragma unroll
-  for (int ob = 0; ob < KB; ++ob)
+    for (int ob = 0; ob < KB; ++ob)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc_o[ob][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc_o[ob][r] = 0.f;
+  }
 
   f32x16 acc[4];
   bf16x8 hf[4];
@@ -194,7 +254,15 @@ __global__ __launch_bounds__(FF_NW * 64) void ffn_kernel(const FArgs p) {
   // lanes 32-63 get the partner's last 4 and keep their own -- instead of reading the row a second time (round 2 did: 94.8 MB per
   // launch for 67 MB of algorithmic traffic, half of the re-reads missed L2).
   u16* yrow = p.Y + (size_t)rowc * K;
-  if (SKEW) {        // the skewed variant (on request only) has no registers to spare for the raw row: it reads it again
+  if constexpr (OUTP) {       // the accumulators started from the new x: nothing to add
+#pragma unroll
+    for (int ob = 0; ob < KB; ++ob) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc_o[ob][r];
+      store_block_bf16(yrow + 32 * ob, v, lh, ok);
+    }
+  } else if (SKEW) {        // the skewed variant (on request only) has no registers to spare for the raw row: it reads it again
     const u16* xrow = p.X + (size_t)rowc * K;
 #pragma unroll
     for (int ob = 0; ob < KB; ++ob) {
@@ -418,6 +486,7 @@ extern "C" int kd_ffn_bf16(const KdFfn* dp, void* stream) {
   a.M = d.M; a.n_tiles = d.d_ff / 64;
   a.clk = g_clk;
   a.warm = option("code_warm", KD_CODE_WARM_DEFAULT);
+  if (d.attn && d.K != 128) return fail(KD_EINVAL, "kd_ffn_bf16: the fused out projection needs K == 128 (K=%d)", d.K);
   if (d.K == 256) {
     constexpr int LDS256 = 9 * WBLK;
     static bool attr256 = false;
@@ -435,19 +504,25 @@ extern "C" int kd_ffn_bf16(const KdFfn* dp, void* stream) {
   // one wave per SIMD and the two row blocks' MFMA / GEGLU streams interleaved instruction by instruction took 71 us):
   // profiles/r02_ffn_fused.md -- under this kernel the chip runs against its power limit and re-arranging the same work buys nothing.
   const int variant = option("ffn_variant", 1);
-  auto kern = variant == 3 ? ffn_kernel<8, true> : ffn_kernel<8, false>;
+  const bool outp = d.attn != nullptr;
+  if (outp) {
+    if (!d.Wp_out) return fail(KD_EINVAL, "kd_ffn_bf16: attn without Wp_out");
+    a.Att = reinterpret_cast<const u16*>(d.attn); a.Wo = reinterpret_cast<const char*>(d.Wp_out);
+  }
+  auto kern = outp ? ffn_kernel<8, false, true> : (variant == 3 ? ffn_kernel<8, true> : ffn_kernel<8, false>);
   const int panel = FF_NW * 32, threads = FF_NW * 64;
-  const int LDS = (variant == 3 ? 10 : 9) * WBLK;
+  const int LDS = (variant == 3 && !outp ? 10 : 9) * WBLK;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * WBLK);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 10 * WBLK);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * WBLK);
     attr_set = true;
   }
   char nm[96] = "ffn_bf16";
-  if (prof_on()) snprintf(nm, sizeof(nm), "ffn_bf16 M=%d K=%d dff=%d", d.M, d.K, d.d_ff);
-  const double flops = 2.0 * d.M * (double)d.K * (3.0 * d.d_ff);
-  const double bytes = 4.0 * d.M * (double)d.K + 6.0 * d.d_ff * (double)d.K;
+  if (prof_on()) snprintf(nm, sizeof(nm), "%s M=%d K=%d dff=%d", outp ? "ffn_bf16+out" : "ffn_bf16", d.M, d.K, d.d_ff);
+  const double flops = 2.0 * d.M * (double)d.K * (3.0 * d.d_ff + (outp ? d.K : 0));
+  const double bytes = (outp ? 6.0 : 4.0) * d.M * (double)d.K + 6.0 * d.d_ff * (double)d.K + (outp ? 2.0 * d.K * d.K : 0.0);
   LaunchScope prof(nm, flops, bytes, s);
   hipLaunchKernelGGL(kern, dim3((unsigned)((d.M + panel - 1) / panel)), dim3(threads), LDS, s, a);
   return check_launch("kd_ffn_bf16");

@@ -1268,12 +1268,12 @@ __global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* __re
   const int q = idx & 7, r = (idx >> 3) & (WROWS - 1);
   const long blk = idx >> 10;
   const int ks = blk % nk, nt = blk / nk;
-  const int wrow = w_row_of_tile(nt, r, N, geglu == 1);
+  const int wrow = w_row_of_tile(nt, r, N, (geglu & 1) != 0);
   float v[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     // layout 2 (down projection of the fused FF block): chunk q = 2 g + h of a k-step holds k 16 g + {4h .. 4h+3, 8 + 4h .. 8 + 4h+3}
-    const int k = ks * WKS + (geglu == 2 ? 16 * (q >> 1) + 4 * (q & 1) + (u & 3) + 8 * (u >> 2) : q * 8 + u);
+    const int k = ks * WKS + ((geglu & 2) ? 16 * (q >> 1) + 4 * (q & 1) + (u & 3) + 8 * (u >> 2) : q * 8 + u);
     v[u] = (wrow >= 0 && k < K) ? W[(long)wrow * K + k] : 0.f;
   }
   *reinterpret_cast<u32x4*>(out + blk * WBLK + swz128(r, q)) =
@@ -1297,13 +1297,13 @@ extern "C" int kd_prof_clock_buffer(void* dev_ptr) {
 
 extern "C" long long kd_packed_weight_bytes_bf16(int N, int K, int geglu) {
   if (N <= 0 || K <= 0) return 0;
-  const long n_tiles = (N + (geglu == 1 ? 64 : 128) - 1) / (geglu == 1 ? 64 : 128), nk = (K + b16::WKS - 1) / b16::WKS;
+  const long n_tiles = (N + ((geglu & 1) ? 64 : 128) - 1) / ((geglu & 1) ? 64 : 128), nk = (K + b16::WKS - 1) / b16::WKS;
   return n_tiles * nk * (long long)b16::WBLK;
 }
 
 extern "C" int kd_pack_weight_bf16(const float* W, void* out, int N, int K, int geglu, void* stream) {
-  if (!W || !out || N <= 0 || K <= 0 || geglu < 0 || geglu > 2) return fail(KD_EINVAL, "kd_pack_weight_bf16: bad arguments");
-  const int n_tiles = (N + (geglu == 1 ? 64 : 128) - 1) / (geglu == 1 ? 64 : 128), nk = (K + b16::WKS - 1) / b16::WKS;
+  if (!W || !out || N <= 0 || K <= 0 || geglu < 0 || geglu > 3) return fail(KD_EINVAL, "kd_pack_weight_bf16: bad arguments");
+  const int n_tiles = (N + ((geglu & 1) ? 64 : 128) - 1) / ((geglu & 1) ? 64 : 128), nk = (K + b16::WKS - 1) / b16::WKS;
   const long total = (long)n_tiles * nk * b16::WROWS * 8;
   hipLaunchKernelGGL(b16::pack_weight_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
                      reinterpret_cast<char*>(out), N, K, geglu, n_tiles, nk);

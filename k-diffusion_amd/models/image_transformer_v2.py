@@ -400,7 +400,9 @@ class _Plan:
             # out projection fused into the FF kernel: width 128 (+3.5 % images/s; at width 256, one wave per SIMD, it measured level:
             # 176.1 vs 176.0).  KDIFF_FFN_OUT: 0 never, 1 default, all = every width the kernel takes, or ONE width
             fo = os.environ.get("KDIFF_FFN_OUT", "1")
-            fuse_out = ffn_x3 and hasattr(mod, "self_attn") and d in (128, 256) and (d == 128 if fo == "1" else fo in ("all", str(d)))
+            ffn_bf = bf and target is self.launches and bool(lib.kd_ffn_bf16_supported(T, d, lv.d_ff))
+            fuse_out = hasattr(mod, "self_attn") and ((ffn_x3 and d in (128, 256)) or (ffn_bf and d == 128)) \
+                and (d == 128 if fo == "1" else fo in ("all", str(d)))
             if hasattr(mod, "self_attn"):
                 sa, spec = mod.self_attn, lv.self_attn
                 nh = d // spec.d_head
@@ -464,13 +466,17 @@ class _Plan:
                 self.norm_descs.append((fd, scale_ptr(prefix + "ff.norm")[1]))
                 self.keep.append(fd)
                 target.append(_Launch(lib.kd_ffn_f32, (C.byref(fd),), prefix + "ff"))
-            elif bf and target is self.launches and lib.kd_ffn_bf16_supported(T, d, lv.d_ff):
-                # the whole FeedForwardBlock (:487-493) in one kernel: the d_ff-wide hidden activation stays on the chip
+            elif ffn_bf:
+                # the whole FeedForwardBlock (:487-493) in one kernel: the d_ff-wide hidden activation stays on the chip (width 128: with
+                # the attention block's out projection in front of it)
                 fd = nat.KdFfn()
                 fd.x = fd.out = x.data_ptr()
                 fd.scale_stride, fd.rows_per_sample, fd.eps = total, rps, 1e-6
-                fd.Wp_up = m._packed_image(mod.ff.up_proj.weight, lv.d_ff, d, 1, bf16=True).data_ptr()
+                fd.Wp_up = m._packed_image(mod.ff.up_proj.weight, lv.d_ff, d, 3 if fuse_out else 1, bf16=True).data_ptr()
                 fd.Wp_down = m._packed_image(mod.ff.down_proj.weight, d, lv.d_ff, 2, bf16=True).data_ptr()
+                if fuse_out:
+                    fd.attn = att.data_ptr()
+                    fd.Wp_out = m._packed_image(mod.self_attn.out_proj.weight, d, d, 0, bf16=True).data_ptr()
                 fd.M, fd.K, fd.d_ff = T, d, lv.d_ff
                 self.norm_descs.append((fd, scale_ptr(prefix + "ff.norm")[1]))
                 self.keep.append(fd)

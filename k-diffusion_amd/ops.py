@@ -247,8 +247,9 @@ def ffn(x, norm_scale, w_up, w_down, out=None, scale_stride=None, rows_per_sampl
     """FeedForwardBlock.forward (image_transformer_v2.py:487-493) in one kernel:
     out = x + down_proj(GEGLU(up_proj(rms_norm(x) * norm_scale))).  x: bf16 or fp32 [..., K]; norm_scale: fp32 [B, K] (one row per
     sample; ``rows_per_sample`` tokens each) ; w_up: fp32 [2 d_ff, K]; w_down: fp32 [K, d_ff].  ``out`` may be x.
-    fp32 (split3) only: with ``attn`` ([..., K], the attention core's output) and ``w_out`` ([K, K]) the attention block's out projection
-    runs in front of the block in the same kernel: x' = x + attn @ w_out.T, out = x' + ff(x') (:473-476, :487-493)."""
+    With ``attn`` ([..., K], the attention core's output, same dtype as x) and ``w_out`` ([K, K]) the attention block's out projection
+    runs in front of the block in the same kernel: x' = x + attn @ w_out.T, out = x' + ff(x') (:473-476, :487-493); widths 128 (bf16,
+    fp32) and 256 (fp32)."""
     K = x.shape[-1]
     M = x.numel() // K
     d_ff = w_down.shape[1]
@@ -262,14 +263,14 @@ def ffn(x, norm_scale, w_up, w_down, out=None, scale_stride=None, rows_per_sampl
     d.rows_per_sample = (M // max(norm_scale.numel() // norm_scale.shape[-1], 1)) if rows_per_sample is None else rows_per_sample
     d.eps = eps
     fused_out = attn is not None
-    if fused_out and (bf or w_out is None):
-        raise ValueError("ffn: attn / w_out go together and need fp32 activations (split3 mode)")
+    if fused_out and w_out is None:
+        raise ValueError("ffn: attn and w_out go together")
     up_img, down_img = pack_weight(w_up, d_ff, K, 3 if fused_out else 1, bf16=bf), pack_weight(w_down, K, d_ff, 2, bf16=bf)
     d.Wp_up, d.Wp_down = _p(up_img), _p(down_img)
     d.M, d.K, d.d_ff = M, K, d_ff
     if fused_out:
-        out_img = pack_weight(w_out, K, K, 0)
-        d.attn, d.Wp_out = _p(_chk(attn, "attn")), _p(out_img)
+        out_img = pack_weight(w_out, K, K, 0, bf16=bf)
+        d.attn, d.Wp_out = _p(_chk(attn, "attn", x.dtype)), _p(out_img)
     if bf:
         nat.check(nat.lib().kd_ffn_bf16(C.byref(d), _stream()), "kd_ffn_bf16")
     else:

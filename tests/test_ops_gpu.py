@@ -853,6 +853,28 @@ def test_fused_out_projection_and_feed_forward_split3(KD, ops, monkeypatch, H, W
     assert torch.equal(xi, y)
 
 
+@pytest.mark.parametrize("H,W,B,dff", [(64, 64, 4, 384), (48, 40, 9, 320), (30, 30, 19, 192)])
+def test_fused_out_projection_and_feed_forward_bf16(KD, ops, monkeypatch, H, W, B, dff):
+    """kd_ffn_bf16 with the attention block's out projection fused in front (KdFfn.attn / Wp_out, width 128) against the oracle's
+    separate steps on the bf16-rounded operands and against out projection + fused block as two calls."""
+    monkeypatch.setenv("KDIFF_GEMM", "bf16")
+    K, T = 128, H * W
+    x, att, scale = rn(B, T, K, seed=41), rn(B, T, K, seed=42), 1 + 0.2 * rn(B, K, seed=43)
+    wo = rn(K, K, seed=44, scale=K ** -0.5)
+    wu, wd = rn(2 * dff, K, seed=45, scale=K ** -0.5), rn(K, dff, seed=46, scale=dff ** -0.5)
+    assert ops.ffn_supported(B * T, K, dff)
+    y = ops.ffn(_bf(x), g(scale), g(wu), g(wd), rows_per_sample=T, attn=_bf(att), w_out=g(wo)).float().cpu()
+    x1 = _rt(x) + _rt(att) @ _rt(wo).T
+    ref = x1 + hdit.linear_geglu(hdit.rms_norm(x1, scale[:, None, :]), _rt(wu)) @ _rt(wd).T
+    assert relerr(y, ref) < 1.2e-2
+    x1g = ops.linear(_bf(att), g(wo), residual=_bf(x))
+    two = ops.ffn(x1g, g(scale), g(wu), g(wd), rows_per_sample=T).float().cpu()
+    assert relerr(y, two) < 1.2e-2
+    xi = _bf(x).clone()                                 # in place, as the model runs it
+    ops.ffn(xi, g(scale), g(wu), g(wd), out=xi, rows_per_sample=T, attn=_bf(att), w_out=g(wo))
+    assert torch.equal(xi.float().cpu(), y)
+
+
 def test_bf16_attention_cores(ops, golden):
     """bf16 global / window / neighbourhood cores against the reference's op goldens (prepared q, k) and the oracle."""
     o = golden["ops"]
