@@ -45,6 +45,16 @@ for name, B, T, Kd, dff in [("L0", 32, 4096, 128, 384), ("L1", 32, 1024, 256, 76
     us = timed(fn)
     flops = 2.0 * B * T * 3 * dff * Kd
     print(f"{name} ffn_x3 M={B * T} K={Kd} d_ff={dff}: {us:7.1f} us, {3 * flops / us * 1e-6:6.0f} TF/s executed ({3 * flops / us * 1e-6 / 2500:.2f} of the bf16 MFMA peak)")
+    # with the attention block's out projection fused in front, against the out projection as its own launch + the block
+    att = torch.randn(B, T, Kd, generator=g).to(dev)
+    wo = (torch.randn(Kd, Kd, generator=g) * Kd ** -0.5).to(dev)
+    x1 = torch.empty_like(x)
+    fused = timed(lambda: ops.ffn(x, scale, wu, wd, out=y, rows_per_sample=T, attn=att, w_out=wo))
+
+    def pair():
+        ops.gemm(att, wo, x1, M=B * T, N=Kd, K=Kd, epi=nat.EPI_RESIDUAL, residual=x)
+        ops.ffn(x1, scale, wu, wd, out=y, rows_per_sample=T)
+    print(f"  + out projection: fused {fused:7.1f} us, as two launches {timed(pair):7.1f} us")
     clk = torch.zeros(16, dtype=torch.int64, device=dev)
     nat.lib().kd_prof_clock_buffer(C.c_void_p(clk.data_ptr()))
     fn()
@@ -56,4 +66,12 @@ for name, B, T, Kd, dff in [("L0", 32, 4096, 128, 384), ("L1", 32, 1024, 256, 76
     nt = dff // (32 if half else 64)
     mf_up, mf_dn = 3 * (2 if half else 4) * (Kd // 16), 3 * (Kd // 32) * (2 if half else 4)
     print(f"  wg 5/8 {c[2] - c[0]} clk @ {ghz:.2f} GHz: prologue {c[4] - c[0]}, tiles {c[12] - c[4]} ({nt} x {(c[12] - c[4]) // nt}), epilogue {c[2] - c[12]}")
+    for label, f2 in (("fused out projection", lambda: ops.ffn(x, scale, wu, wd, out=y, rows_per_sample=T, attn=att, w_out=wo)),):
+        clk2 = torch.zeros(16, dtype=torch.int64, device=dev)
+        nat.lib().kd_prof_clock_buffer(C.c_void_p(clk2.data_ptr()))
+        f2()
+        torch.cuda.synchronize()
+        nat.lib().kd_prof_clock_buffer(None)
+        c2 = clk2.cpu().tolist()
+        print(f"  {label}: wg 5/8 {c2[2] - c2[0]} clk: prologue + out projection + norm {c2[4] - c2[0]} (to the first weight request) ..., tiles {c2[12] - c2[4]}, epilogue {c2[2] - c2[12]}")
     print(f"  {'half tile 4' if half else 'tile 2'}: up {c[9] - c[8]} ({mf_up} MFMAs: floor {32 * mf_up}), GEGLU {c[10] - c[9]}, down {c[11] - c[10]} ({mf_dn} MFMAs: floor {32 * mf_dn})")

@@ -123,6 +123,34 @@ for name, B, H, W, nh, Kd, dff in LEVELS:
         line += f" | x3_res={opt}: {us:7.1f} us {12.0 * B * T * Kd / us * 1e-3:5.0f} GB/s (x3 executed {6.0 * B * T * Kd * Kd / us * 1e-6 / 2500:.2f} of peak)"
     nat.set_option("x3_res", 1)
     print(line)
+    # projections without a norm in front (gemm_x3r.hip) against the round-1 tile kernel: out projection, down projection, token merge
+    nat.set_option("x3_res", 0)
+    shapes = [("out-proj", B * T, Kd, Kd, att, wo, res, False), ("down", B * T, Kd, dff, hid32, wd, res, False)]
+    if name != "L2":
+        wm = (torch.randn(2 * Kd, 4 * Kd, generator=g) * (4 * Kd) ** -0.5).to(dev)
+        shapes.append(("merge", B * T // 4, 2 * Kd, 4 * Kd, x, wm, None, True))
+    for what, M_, N_, K_, a_, w_, r_, mg in shapes:
+        line = f"{name} {what:8s} M={M_:6d} N={N_:4d} K={K_:4d}"
+        outb = torch.empty(M_, N_, device=dev)
+        for opt in (2, 0):
+            nat.set_option("x3r", opt)
+            if mg:
+                f = lambda: ops.gemm(a_, w_, outb, M=M_, N=N_, K=K_, a_mode=nat.A_MERGE2x2, grid=(H // 2, W // 2))  # noqa: E731
+            else:
+                f = lambda: ops.gemm(a_, w_, outb, M=M_, N=N_, K=K_, epi=nat.EPI_RESIDUAL, residual=r_)  # noqa: E731
+            us = timed(f)
+            line += f" | x3r={opt}: {us:7.1f} us (x3 executed {6.0 * M_ * N_ * K_ / us * 1e-6 / 2500:.2f} of peak, {4.0 * (M_ * K_ + (2 if r_ is not None else 1) * M_ * N_) / us * 1e-3:5.0f} GB/s)"
+        nat.set_option("x3r", 1)
+        print(line)
+        clk = torch.zeros(16, dtype=torch.int64, device=dev)
+        nat.lib().kd_prof_clock_buffer(C.c_void_p(clk.data_ptr()))
+        f()
+        torch.cuda.synchronize()
+        nat.lib().kd_prof_clock_buffer(None)
+        c = clk.cpu().tolist()
+        if c[12]:
+            print(f"  wg 5/8: K loop {c[2] - c[0]} clk for {c[7]} stages; stage 8: chunk 0 {c[9] - c[8]}, wait {c[10] - c[9]}, barrier {c[11] - c[10]}, chunk 1 {c[12] - c[11]}")
+    nat.set_option("x3_res", 1)
     for cname, fn in cases.items():
         nw = 3 * d if cname == "qkv" else 2 * dff
         flops = 2.0 * B * T * nw * Kd

@@ -598,6 +598,7 @@ namespace kd { int gemm_astat_try(const GemmP& d, hipStream_t s, int* rc); }    
 namespace kd { int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc); }       // gemm_x3.hip
 namespace kd { int gemm_x3t_try(const GemmP& d, hipStream_t s, int* rc); }      // gemm_x3t.hip
 namespace kd { int gemm_skinny_try(const GemmP& d, hipStream_t s, int* rc); }   // gemm_skinny.hip
+namespace kd { int gemm_x3r_try(const GemmP& d, hipStream_t s, int* rc); }      // gemm_x3r.hip
 
 using namespace kd;
 
@@ -648,6 +649,7 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
     if (astat_on && !gemm_x3_try(e, s, &rc)) return rc;        // norm -> wide projection, split3: round-3 A-stationary kernel (gemm_x3.hip)
     if (e.c_split) return fail(KD_EINVAL, "kd_gemm_f32: c_split is produced by the GEGLU projections of gemm_x3.hip (K = 128 / 256, norm) and gemm_x3t.hip (a_split) only");
     if (astat_on && !gemm_astat_try(e, s, &rc)) return rc;     // ... and its round-1 predecessor (RoPE tables instead of positions; A/B runs)
+    if (!gemm_x3r_try(e, s, &rc)) return rc;                   // no norm in front (residual projections, merges), split3: gemm_x3r.hip
   }
   if (e.precision != KD_PREC_EXACT && e.precision != KD_PREC_SPLIT3) return fail(KD_EINVAL, "kd_gemm_f32: unknown precision %d", e.precision);
   if (e.precision == KD_PREC_SPLIT3 && !e.Wp) return fail(KD_EINVAL, "kd_gemm_f32: split3 needs the packed weight image Wp (kd_pack_weight_bf16x3)");

@@ -791,9 +791,9 @@ int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc) {
   if (d.precision != KD_PREC_SPLIT3 || d.a_mode != KD_A_PLAIN || !d.Wp || d.debug) return 1;
   if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_QKV && d.epi != KD_EPI_GEGLU && d.epi != KD_EPI_RESIDUAL) return 1;
   // norm -> wide projection, or (round 3) the plain residual projection behind the attention core: C = R + A W^T
-  // (K = 512 only: 25.3 vs 27.1 us at the headline shape; at K = 128 it is level with the round-1 tile kernel (both at the memory roof) and
+  // (on request, option "x3_res": gemm_x3r.hip takes that shape by default, 24.2 us.  K = 512 only: 25.3 vs 27.1 us at the headline shape; at K = 128 it is level with the round-1 tile kernel (both at the memory roof) and
   // at K = 256 slower, 32.0 vs 26.4 us -- a workgroup there pays a whole row prologue for one or two n-tiles: benchmarks/x3_bench.py)
-  if (d.epi == KD_EPI_RESIDUAL ? (d.norm || !d.R || d.K != 512 || !option("x3_res", 1)) : !d.norm) return 1;
+  if (d.epi == KD_EPI_RESIDUAL ? (d.norm || !d.R || d.K != 512 || !option("x3_res", 0)) : !d.norm) return 1;
   if (d.K != 128 && d.K != 256 && d.K != 512) return 1;
   const int ncol = d.epi == KD_EPI_GEGLU ? 64 : 128;
   if (d.N % ncol || d.M < 512 || (d.norm && d.rows_per_sample <= 0)) return 1;

@@ -784,11 +784,33 @@ def test_split3_projections_round3(KD, ops, monkeypatch, H, W, nh, B, K):
     assert relerr(qkv, old) < 1e-4 and (B * T < 512 or K >= 512 or not torch.equal(qkv, old))      # (another kernel really ran)
 
 
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 32, 32, 128, 256), (3, 16, 24, 256, 512), (1, 48, 40, 64, 128)])
+def test_split3_token_merge_round3(KD, ops, monkeypatch, B, H, W, C, N):
+    """TokenMerge (image_transformer_v2.py:586-595) on gemm_x3r.hip (the 2 x 2 gather as address arithmetic of its staging requests)
+    against the oracle and the round-1 kernel; a ragged last row panel (1 x 24 x 20 coarse tokens)."""
+    from k_diffusion_amd import _native as nat
+    monkeypatch.setenv("KDIFF_GEMM", "split3")
+    x, w = rn(B, H, W, C, seed=51), rn(N, 4 * C, seed=52, scale=(4 * C) ** -0.5)
+    ref = hdit.token_merge(x, w, 2, 2)
+    nat.set_option("x3r", 2)
+    try:
+        y = ops.token_merge(g(x), g(w))
+    finally:
+        nat.set_option("x3r", 1)
+    assert relerr(y, ref) < 1e-4
+    nat.set_option("x3r", 0)
+    try:
+        old = ops.token_merge(g(x), g(w))
+    finally:
+        nat.set_option("x3r", 1)
+    assert relerr(y, old) < 1e-4
+
+
 @pytest.mark.parametrize("M,K,N", [(1024, 512, 512), (1000, 512, 512), (8192, 512, 512), (2048, 256, 256), (640, 512, 256)])
 def test_split3_residual_projection_round3(KD, ops, monkeypatch, M, K, N):
-    """out = residual + A W^T (the projection behind the attention core) on the round-3 A-stationary kernel (taken at K = 512: the
-    accumulators start from the residual, one n-tile per workgroup); full and ragged row panels, in place (out is the residual) and
-    not, and against the round-1 kernel (option x3_res = 0; K = 256 goes there anyway)."""
+    """out = residual + A W^T (the projection behind the attention core) on the round-3 kernels (gemm_x3r.hip where the tiles fit one
+    round of the chip; the accumulators start from the residual); full and ragged row panels, in place (out is the residual) and not,
+    and against the A-stationary form (x3_res), the round-1 kernel (x3r = 0) and gemm_x3r forced (x3r = 2)."""
     from k_diffusion_amd import _native as nat
     monkeypatch.setenv("KDIFF_GEMM", "split3")
     a, res = rn(M, K, seed=21), rn(M, N, seed=22)
@@ -800,13 +822,15 @@ def test_split3_residual_projection_round3(KD, ops, monkeypatch, M, K, N):
     inplace = g(res).clone()
     ops.gemm(g(a), g(w), inplace, M=M, N=N, K=K, epi=nat.EPI_RESIDUAL, residual=inplace)
     assert torch.equal(inplace, out)
-    nat.set_option("x3_res", 0)
-    try:
-        old = torch.empty_like(out)
-        ops.gemm(g(a), g(w), old, M=M, N=N, K=K, epi=nat.EPI_RESIDUAL, residual=g(res))
-    finally:
-        nat.set_option("x3_res", 1)
-    assert relerr(old, ref) < 1e-4 and relerr(out, old) < 1e-4
+    # the same projection on the A-stationary kernel (option x3_res, K = 512) and on the round-1 tile kernel (x3r = 0)
+    for name, val, back in (("x3_res", 1, 0), ("x3r", 0, 1), ("x3r", 2, 1)):
+        nat.set_option(name, val)
+        try:
+            old = torch.empty_like(out)
+            ops.gemm(g(a), g(w), old, M=M, N=N, K=K, epi=nat.EPI_RESIDUAL, residual=g(res))
+        finally:
+            nat.set_option(name, back)
+        assert relerr(old, ref) < 1e-4 and relerr(out, old) < 1e-4, (name, val)
 
 
 @pytest.mark.parametrize("H,W,B,K,dff", [(64, 64, 2, 128, 384), (32, 32, 4, 256, 768), (48, 40, 2, 128, 320), (30, 30, 3, 256, 448)])
