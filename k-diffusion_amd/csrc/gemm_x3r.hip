@@ -285,7 +285,9 @@ int gemm_x3r_try(const GemmP& d, hipStream_t s, int* rc) {
   // One workgroup per CU (136 KiB of LDS): taken where the tiles fit ONE round of the chip -- the level-2 projections and the merge
   // into level 2 (M = 8192 at batch 32: 47-52 vs 59-62 us, 22-24 vs 28, 33-37 vs 50-52 us).  With more tiles than CUs the round-1 kernel's
   // two resident workgroups per CU win (level-1 out projection 31 vs 27 us, level-0 merge 45 vs 38 us: benchmarks/x3_bench.py).
-  // Option "x3r" = 2 takes every eligible shape (A/B runs).
+  // Option "x3r" = 2 takes every eligible shape (A/B runs).  (A TokenSplit + lerp epilogue on this kernel -- scatter as row bases of the
+  // store runs, skip requested ahead of the K loop -- was measured slower than the round-1 kernel's, 57.9 vs 53.8 and 44.6 vs 41.4 us, and
+  // was not kept.)
   {
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
