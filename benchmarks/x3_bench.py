@@ -51,6 +51,24 @@ def timeline(fn):
     return (f"  wg0 {c[2] - c[0]} clk @ {ghz:.2f} GHz: prologue {c[4] - c[0]}, tile0 K loop {c[5] - c[4]}, tile0 epilogue {c[6] - c[5]}, stages {c[7]}")
 
 
+# out patch projection of the headline config (out_norm -> 128 -> 48, unpatch, c_out / c_skip)
+if True:
+    B, Hh, Ww, Kd = 32, 64, 64, 128
+    g = torch.Generator().manual_seed(2)
+    tok = torch.randn(B, Hh, Ww, Kd, generator=g).to(dev)
+    gain = (1 + 0.1 * torch.randn(Kd, generator=g)).to(dev)
+    wpo = (torch.randn(48, Kd, generator=g) * Kd ** -0.5).to(dev)
+    img = torch.randn(B, 3, 4 * Hh, 4 * Ww, generator=g).to(dev)
+    sig = torch.rand(B, generator=g).to(dev) + 0.1
+    outi = torch.empty_like(img)
+    line = "patch-out M=131072 N=48 K=128"
+    for opt in (1, 0):
+        nat.set_option("x3_unpatch", opt)
+        us = timed(lambda: ops.patch_out(tok, gain, wpo, (4, 4), 3, x_in=img, sigma=sig, sigma_data=0.5, out=outi))
+        line += f" | x3_unpatch={opt}: {us:7.1f} us ({(tok.numel() + 2 * img.numel()) * 4 / us * 1e-3:5.0f} GB/s)"
+    nat.set_option("x3_unpatch", 1)
+    print(line)
+
 for name, B, H, W, nh, Kd, dff in LEVELS:
     T, d = H * W, nh * 64
     g = torch.Generator().manual_seed(1)

@@ -27,6 +27,7 @@ struct XArgs {
   int M, N, n_tiles, n_splits;
   int n_heads; const float* qk_scale; const float* pos; const float* freq; int qkv_packed;
   float out_add;
+  const float* sigma; float sigma_data; int gh, gw, chan;    // KD_EPI_UNPATCH_NCHW: Karras c_out / c_skip per sample, patch grid, image channels (4 x 4 patches)
   const float* R;                   // KD_EPI_RESIDUAL: [M, N] added to the product (the accumulators start from it); one n-tile per workgroup
   int warm;
   unsigned long long* clk;
@@ -224,12 +225,35 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
   if constexpr (AG) asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 
   bf16x8 wh[2][4], wl[2][4];
-  auto read_frags = [&](int slot, int h, bf16x8 (&fh)[4], bf16x8 (&fl)[4]) {
-    const char* st = smem + slot * STG + (h ? o1 : o0);
+  // KD_EPI_UNPATCH_NCHW (the out patch projection, N = 16 chan <= 64 outputs in ONE n-tile): the lane's W rows are read in the order
+  // n' = (py chan + c) 4 + px instead of the reference's n = (py 4 + px) chan + c, so that an accumulator group of 4 registers is the 4
+  // horizontally adjacent pixels of one image row and channel: 16-byte image accesses, 512 contiguous bytes per half-wave (the same
+  // re-ordering the bf16 patch kernels do at pack time: here it is only a permuted row index of the fragment reads).  Blocks 2, 3 are empty.
+  int ou0[2] = {0, 0}, ou1[2] = {0, 0};
+  if constexpr (EPI == KD_EPI_UNPATCH_NCHW) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      fh[j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 64);
-      fl[j] = *reinterpret_cast<const bf16x8*>(st + IMG + j * 32 * 64);
+    for (int j = 0; j < 2; ++j) {
+      const int np = 32 * j + l31, q = np >> 2, py = q / p.chan, cch = q - py * p.chan;
+      const int n = np < 16 * p.chan ? (py * 4 + (np & 3)) * p.chan + cch : np;        // rows past N are zero in the packed tile
+      ou0[j] = swz64(n, lh);
+      ou1[j] = swz64(n, 2 + lh);
+    }
+  }
+  auto read_frags = [&](int slot, int h, bf16x8 (&fh)[4], bf16x8 (&fl)[4]) {
+    if constexpr (EPI == KD_EPI_UNPATCH_NCHW) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* st = smem + slot * STG + (h ? ou1[j] : ou0[j]);
+        fh[j] = *reinterpret_cast<const bf16x8*>(st);
+        fl[j] = *reinterpret_cast<const bf16x8*>(st + IMG);
+      }
+    } else {
+      const char* st = smem + slot * STG + (h ? o1 : o0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        fh[j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 64);
+        fl[j] = *reinterpret_cast<const bf16x8*>(st + IMG + j * 32 * 64);
+      }
     }
   };
   // stage 0 in: its first chunk's fragments
@@ -244,6 +268,7 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
       // acc[j] += W fragment (hi / lo of buffer b, block j) x activation fragment (hi / lo) of chunk 2 ks + b
       auto mm = [&](auto b_, int j, bool w_lo, auto a_lo_) {
         constexpr int b = decltype(b_)::value, al = decltype(a_lo_)::value, c = 2 * ks + b;
+        if (EPI == KD_EPI_UNPATCH_NCHW && j >= 2) return;          // (N <= 64: two W blocks)
         const bf16x8& w = w_lo ? wl[b][j] : wh[b][j];
         if constexpr (AG) mfma_ag<8 * c + 4 * al>(acc[j], w);
         else mfma_a(acc[j], w, al ? a_lo[c] : a_hi[c]);
@@ -404,6 +429,29 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
           store_block(blk, n0 + 64 * vv + 32 * jj);
         }
       }
+    } else if (EPI == KD_EPI_UNPATCH_NCHW) {
+      // tokens -> NCHW image (image_transformer_v2.py:758-760) with the Denoiser's c_out * y + c_skip * x_in (layers.py:90): accumulator
+      // group 8 j + 2 g + lh of the lane's token = (py, channel), its 4 registers = the 4 pixels of that patch row
+      const int per = p.gh * p.gw, bb = rowc / per, rr = rowc - bb * per, ty = rr / p.gw, tx = rr - ty * p.gw;
+      float c_out = 1.f, c_skip = 0.f;
+      if (p.sigma) {
+        const float sg = p.sigma[bb], sd = p.sigma_data, var = sg * sg + sd * sd;
+        c_skip = sd * sd / var;
+        c_out = sg * sd / sqrtf(var);
+      }
+      const int Himg = 4 * p.gh, Wimg = 4 * p.gw;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int q = 8 * j + 2 * g + lh, py = q / p.chan, cch = q - py * p.chan;
+          if (q < 4 * p.chan && ok) {
+            const size_t o = (((size_t)bb * p.chan + cch) * Himg + 4 * ty + py) * Wimg + 4 * tx;
+            f32x4 v = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]} * (rs * c_out);
+            if (p.sigma) v = v + *reinterpret_cast<const f32x4*>(p.R + o) * c_skip;
+            *reinterpret_cast<f32x4*>(p.C + o) = v;
+          }
+        }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -789,20 +837,23 @@ int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc) {
   using namespace x3;
   if (!option("x3", 1)) return 1;
   if (d.precision != KD_PREC_SPLIT3 || d.a_mode != KD_A_PLAIN || !d.Wp || d.debug) return 1;
-  if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_QKV && d.epi != KD_EPI_GEGLU && d.epi != KD_EPI_RESIDUAL) return 1;
+  const bool unpatch = d.epi == KD_EPI_UNPATCH_NCHW;
+  if (unpatch && (d.K != 128 || !d.norm || d.ph != 4 || d.pw != 4 || d.N != 16 * d.chan || d.N > 64 || !option("x3_unpatch", 1))) return 1;
+  if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_QKV && d.epi != KD_EPI_GEGLU && d.epi != KD_EPI_RESIDUAL && !unpatch) return 1;
   // norm -> wide projection, or (round 3) the plain residual projection behind the attention core: C = R + A W^T
   // (on request, option "x3_res": gemm_x3r.hip takes that shape by default, 24.2 us.  K = 512 only: 25.3 vs 27.1 us at the headline shape; at K = 128 it is level with the round-1 tile kernel (both at the memory roof) and
   // at K = 256 slower, 32.0 vs 26.4 us -- a workgroup there pays a whole row prologue for one or two n-tiles: benchmarks/x3_bench.py)
   if (d.epi == KD_EPI_RESIDUAL ? (d.norm || !d.R || d.K != 512 || !option("x3_res", 0)) : !d.norm) return 1;
   if (d.K != 128 && d.K != 256 && d.K != 512) return 1;
   const int ncol = d.epi == KD_EPI_GEGLU ? 64 : 128;
-  if (d.N % ncol || d.M < 512 || (d.norm && d.rows_per_sample <= 0)) return 1;
+  if ((!unpatch && d.N % ncol) || d.M < 512 || (d.norm && d.rows_per_sample <= 0)) return 1;
   if (d.epi == KD_EPI_QKV && (!d.rope_pos || !d.rope_freq || d.n_heads > 16)) return 1;   // tables only / many heads: round-1 kernel
   if (d.c_split && (d.epi != KD_EPI_GEGLU || !d.C_lo || (d.N & 31))) return 1;
   XArgs a{};
   a.A = d.A; a.Wp = reinterpret_cast<const char*>(d.Wp); a.C = d.C;
   a.scale = d.norm ? d.scale : nullptr; a.R = d.R; a.scale_stride = d.scale_stride; a.rows_per_sample = d.rows_per_sample > 0 ? d.rows_per_sample : d.M; a.eps = d.eps;
-  a.M = d.M; a.N = d.N; a.n_tiles = d.N / ncol; a.n_splits = 1;
+  a.M = d.M; a.N = d.N; a.n_tiles = unpatch ? 1 : d.N / ncol; a.n_splits = 1;
+  a.sigma = d.sigma; a.sigma_data = d.sigma_data; a.gh = d.gh; a.gw = d.gw; a.chan = d.chan;
   a.n_heads = d.n_heads; a.qk_scale = d.qk_scale; a.pos = d.rope_pos; a.freq = d.rope_freq; a.qkv_packed = d.qkv_packed;
   a.out_add = d.out_add;
   a.Cl = reinterpret_cast<b16::u16*>(d.C_lo); a.c_split = d.c_split;
@@ -810,7 +861,7 @@ int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc) {
   a.clk = g_clk;
   const double n_eff = d.epi == KD_EPI_GEGLU ? 2.0 * d.N : (double)d.N;
   const double flops = 2.0 * d.M * n_eff * d.K;
-  const double bytes = 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N * (d.epi == KD_EPI_RESIDUAL ? 2 : 1));
+  const double bytes = 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N * (d.epi == KD_EPI_RESIDUAL || (unpatch && d.sigma) ? 2 : 1));
   char nm[96] = "gemm_x3_astat";
   if (prof_on()) snprintf(nm, sizeof(nm), "gemm_x3_astat<e%d> M=%d N=%d K=%d", d.epi, d.M, d.N, d.K);
   if (d.K == 256 && d.epi != KD_EPI_RESIDUAL && !d.c_split && option("x3_half", 1)) {      // two workgroups per CU, half tiles
@@ -826,6 +877,7 @@ int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc) {
   KD_X3(16, KD_EPI_STORE) KD_X3(16, KD_EPI_QKV) KD_X3(16, KD_EPI_GEGLU)
   KD_X3(32, KD_EPI_STORE) KD_X3(32, KD_EPI_QKV) KD_X3(32, KD_EPI_GEGLU)
   KD_X3(32, KD_EPI_RESIDUAL)
+  KD_X3(8, KD_EPI_UNPATCH_NCHW)
 #undef KD_X3
   return 1;
 }

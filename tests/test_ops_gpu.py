@@ -330,6 +330,32 @@ def test_token_merge_split(ops, gtol, golden):
     assert relerr(y, o["split.y"]) < gtol
 
 
+@pytest.mark.parametrize("C,H,W", [(3, 128, 128), (3, 72, 88), (1, 128, 64), (4, 64, 64)])
+def test_split3_patch_out_round3(KD, ops, monkeypatch, C, H, W):
+    """out_norm + out patch projection + NHWC -> NCHW + c_out * y + c_skip * x_in (image_transformer_v2.py:758-760, layers.py:90) on the
+    round-3 A-stationary kernel (W rows read in (py, channel, px) order: 16-byte image accesses) against the oracle and the round-1
+    kernel; 1, 3 and 4 channels, a ragged last row panel, with and without the Karras scalings."""
+    from k_diffusion_amd import _native as nat
+    monkeypatch.setenv("KDIFF_GEMM", "split3")
+    B, p, d = 3, 4, 128
+    img = rn(B, C, H, W, seed=1)
+    sigma = torch.tensor([0.05, 1.3, 70.0])
+    c_skip, c_out, _ = solvers.karras_scalings(sigma, 0.5)
+    x, scale, w_out = rn(B, H // p, W // p, d, seed=3), 1 + 0.1 * rn(d, seed=4), rn(C * p * p, d, seed=5) / d ** 0.5
+    inner = hdit.token_split(hdit.rms_norm(x, scale), w_out, p, p).movedim(-1, 1)
+    ref_d = inner * c_out.view(-1, 1, 1, 1) + img * c_skip.view(-1, 1, 1, 1)
+    y0 = ops.patch_out(g(x), g(scale), g(w_out), (p, p), C)
+    y1 = ops.patch_out(g(x), g(scale), g(w_out), (p, p), C, x_in=g(img), sigma=g(sigma), sigma_data=0.5)
+    assert relerr(y0, inner) < 1e-4 and relerr(y1, ref_d) < 1e-4
+    nat.set_option("x3_unpatch", 0)
+    try:
+        o0 = ops.patch_out(g(x), g(scale), g(w_out), (p, p), C)
+        o1 = ops.patch_out(g(x), g(scale), g(w_out), (p, p), C, x_in=g(img), sigma=g(sigma), sigma_data=0.5)
+    finally:
+        nat.set_option("x3_unpatch", 1)
+    assert relerr(y0, o0) < 1e-4 and relerr(y1, o1) < 1e-4
+
+
 @pytest.mark.parametrize("C,H,W,p,d", [(3, 16, 16, 2, 128), (1, 28, 28, 4, 64), (3, 32, 64, 4, 128)])
 def test_patch_in_out(ops, gtol, C, H, W, p, d):
     B = 3
