@@ -34,7 +34,7 @@ def family_of(symbol):
         outp = ("ffn_x3h_kernel<true" in symbol or "ffn_x3h_kernel<1" in symbol or ", true>" in symbol or ", 1>" in symbol
                 or "(bool)1" in symbol)
         return "ffn_x3+out" if outp else "ffn_x3"
-    for needle, name in (("x3::gemm_x3_astat_kernel", "gemm_x3_astat"), ("x3::gemm_x3h_kernel", "gemm_x3_astat"),
+    for needle, name in (("x3::gemm_x3_astat_kernel", "gemm_x3_astat"), ("x3::gemm_x3h_kernel", "gemm_x3_astat"), ("x3r::gemm_x3r_kernel", "gemm_x3r"),
                          ("x3a::attn_na2d_x3_kernel", "attn_na2d_x3"), ("x3a::attn_global_x3_kernel", "attn_global_x3"), ("x3t::gemm_x3_tiled_kernel", "gemm_x3_tiled"), ("norm_split_kernel", "norm_split_f32"),
                          ("b16::ffn_kernel", "ffn_bf16"), ("b16::unpatch4_kernel", "gemm_bf16_unpatch4"), ("b16::patchin4_kernel", "gemm_bf16_patchin4"),
                          ("b16::gemm_wstat_kernel", "gemm_bf16_wstat"), ("b16::gemm_astat_kernel", "gemm_bf16_astat"), ("b16::gemm_tiled_kernel", "gemm_bf16_tiled"),
