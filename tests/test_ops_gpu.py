@@ -743,7 +743,8 @@ def test_bf16_qkv_epilogue(ops, H, W, nh, B, K):
     assert relerr(qkv[..., 2, :, :], ref[..., 2, :, :]) < 1.2e-2
 
 
-@pytest.mark.parametrize("H,W,nh,B,K", [(64, 64, 2, 2, 128), (32, 32, 4, 2, 256), (32, 16, 4, 3, 256), (24, 24, 2, 1, 128), (20, 20, 2, 2, 128), (16, 16, 8, 4, 512)])
+@pytest.mark.parametrize("H,W,nh,B,K", [(64, 64, 2, 2, 128), (32, 32, 4, 2, 256), (32, 16, 4, 3, 256), (24, 24, 2, 1, 128), (20, 20, 2, 2, 128), (16, 16, 8, 4, 512),
+                                        (20, 20, 4, 3, 256), (12, 20, 8, 3, 512)])
 def test_split3_projections_round3(KD, ops, monkeypatch, H, W, nh, B, K):
     """The round-3 fp32-parity projections (gemm_x3.hip / gemm_x3t.hip: lane-owns-row epilogues, RoPE angles from positions /
     frequencies, qkv operands stored split for the attention cores) against the oracle's separate steps, and against the
