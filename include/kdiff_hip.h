@@ -124,8 +124,9 @@ int kd_gemm_f32(const KdGemm* desc, void* stream);
 int kd_gemm_bf16(const KdGemm* desc, void* stream);
 long long kd_packed_weight_bytes_bf16(int N, int K, int geglu);
 /* W [N or 2N (geglu), K] fp32 -> blocks [n-tile][k-step][128 rows][64 k] bf16 (16 KiB each, the kernels' swizzled LDS image).
- * `geglu` selects the layout: 0 plain, 1 GEGLU (value / gate rows interleaved per 32 outputs), 2 plain rows with the k order
- * of kd_ffn_bf16's down projection (inside every group of 16 k: 0-3, 8-11, 4-7, 12-15). */
+ * `geglu` selects the layout, as two bits: bit 0 = GEGLU rows (value / gate rows interleaved per 32 outputs), bit 1 = the k order in
+ * which an MFMA result holds a row (inside every group of 16 k: 0-3, 8-11, 4-7, 12-15): 2 = the down projection of kd_ffn_bf16,
+ * 3 = its up projection when the out projection is fused in front (KdFfn.attn). */
 int kd_pack_weight_bf16(const float* W, void* out, int N, int K, int geglu, void* stream);
 
 /* Fused feed-forward block in bf16 arithmetic:  out = x + down_proj(GEGLU(up_proj(AdaRMSNorm(x)))).
@@ -165,8 +166,8 @@ int kd_ffn_f32(const KdFfn* desc, void* stream);
 /* One-off packing of a weight for KD_PREC_SPLIT3 (weights are static during sampling): W [N or 2N (geglu == 1), K]
  * fp32 -> `out`, kd_packed_weight_bytes(N, K, geglu) bytes: [n-tile][k-step][hi|lo][128 rows][32 bf16] in the
  * kernel's swizzled LDS order, zero-padded.  N is the OUTPUT width (GEGLU: d_ff, W has 2*d_ff rows).
- * `geglu`: 0 plain, 1 GEGLU (value / gate rows interleaved per 32 outputs), 2 plain rows with the k order of kd_ffn_f32's down
- * projection (inside every group of 16 k: 0-3, 8-11, 4-7, 12-15). */
+ * `geglu`, two bits as for kd_pack_weight_bf16: 0 plain, 1 GEGLU rows, 2 the k order of kd_ffn_f32's down projection (inside every
+ * group of 16 k: 0-3, 8-11, 4-7, 12-15), 3 both (its up projection behind a fused out projection). */
 long long kd_packed_weight_bytes(int N, int K, int geglu);
 int kd_pack_weight_bf16x3(const float* W, void* out, int N, int K, int geglu, void* stream);
 
