@@ -146,10 +146,11 @@ typedef struct KdFfn {
   const void* Wp_up;
   const void* Wp_down;
   int M, K, d_ff;
-  /* kd_ffn_f32 only (round 3), both NULL or both set: the attention block's out projection fused in front of the block
-   * (image_transformer_v2.py:473-476 then :487-493):  x' = x + attn Wout^T;  out = x' + down(GEGLU(up(norm(x')))).
-   * attn = [M, K] fp32 (the attention core's output, heads merged), Wp_out = kd_pack_weight_bf16x3(out_proj.weight [K, K], N = K, K,
-   * geglu = 0), and Wp_up must then be packed with geglu = 3 (the k order in which an MFMA result holds a row). */
+  /* Both NULL or both set: the attention block's out projection fused in front of the block (image_transformer_v2.py:473-476 then
+   * :487-493):  x' = x + attn Wout^T;  out = x' + down(GEGLU(up(norm(x')))).  attn = [M, K] in the activation type of the call (the
+   * attention core's output, heads merged), Wp_out = the packed out_proj.weight [K, K] (N = K, K, geglu = 0) and Wp_up must then be packed
+   * with geglu = 3 (the k order in which an MFMA result holds a row).  kd_ffn_f32 takes it at K == 128 and K == 256 (fp32 attn,
+   * kd_pack_weight_bf16x3 images); kd_ffn_bf16 at K == 128 (bf16 attn, kd_pack_weight_bf16 images; other K: KD_EINVAL). */
   const void* attn;
   const void* Wp_out;
 } KdFfn;
@@ -173,8 +174,9 @@ int kd_pack_weight_bf16x3(const float* W, void* out, int N, int K, int geglu, vo
 
 /* AdaRMSNorm / RMSNorm (image_transformer_v2.py:98-103, :155-166) of fp32 rows, written as the two bf16 planes of an a_split GEMM
  * operand: y[m, :] = x[m, :] * (scale[b(m) * scale_stride + :] * rsqrt(mean(x[m, :]^2) + eps)), hi = bf16_rne(y), lo = bf16_rne(y - hi);
- * b(m) = m / rows_per_sample.  scale == NULL: plain split of x (no norm).  K % 8 == 0, K <= 2048.  Used where a row's fragments do not
- * fit the register file of the fused norm -> projection kernel (K = 512: the level-2 qkv / up projections of the headline config). */
+ * b(m) = m / rows_per_sample.  scale == NULL: plain split of x (no norm).  K % 8 == 0, K <= 2048.  Used for the widths the fused norm ->
+ * projection kernels (kd_gemm_f32 with norm = 1: K = 128 / 256 / 512, in registers) do not take -- 384, 640, ..., 2048 (K % 128 == 0):
+ * the planes then feed an a_split kd_gemm_f32.  None of the shipped configs has such a width; tests/test_model_gpu.py covers 384 and 1152. */
 int kd_norm_split_f32(const float* x, const float* scale, int scale_stride, int rows_per_sample, void* hi, void* lo, int M, int K,
                       float eps, void* stream);
 

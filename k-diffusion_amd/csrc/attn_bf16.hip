@@ -583,8 +583,8 @@ __global__ __launch_bounds__(256, 1) void attn_na2d_wide_bf16_kernel(const NArgs
 template <int KS>
 static int launch_na_wide(const NArgs& a, hipStream_t s) {
   auto k = attn_na2d_wide_bf16_kernel<KS>;
-  static bool set = false;
-  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, NaWide<KS>::LDS); set = true; }
+  static LdsAttr set;
+  set.ensure(reinterpret_cast<const void*>(k), NaWide<KS>::LDS);
   const long nb = (long)a.batch * a.nh * ((a.H + NA_TH - 1) / NA_TH) * ((a.W + NA_TW - 1) / NA_TW);
   char nm[64] = "attn_na2d_bf16";
   if (prof_on()) snprintf(nm, sizeof(nm), "attn_na2d_bf16 k%d %dx%d nh=%d", KS, a.H, a.W, a.nh);
@@ -597,8 +597,8 @@ template <int MODE, int NT, int QW>
 static int launch_dense(const DArgs& a, long nproblems, const char* name, hipStream_t s) {
   constexpr int LDS = NT * 32 * 256, NQB = (NT + QW - 1) / QW;
   auto k = attn_dense_bf16_kernel<MODE, NT, QW>;
-  static bool set = false;
-  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); set = true; }
+  static LdsAttr set;
+  set.ensure(reinterpret_cast<const void*>(k), LDS);
   const int n_slots = MODE == MODE_GLOBAL ? a.T : (1 << (2 * WinLog2<MODE>::v));
   LaunchScope prof(name, 4.0 * (double)nproblems * n_slots * n_slots * DH, 2.0 * (double)a.batch * a.T * a.nh * DH * 4.0, s);
   hipLaunchKernelGGL(k, dim3((unsigned)(nproblems * NQB)), dim3(QW * 64), LDS, s, a);
@@ -608,8 +608,8 @@ static int launch_dense(const DArgs& a, long nproblems, const char* name, hipStr
 template <int KS>
 static int launch_na(const NArgs& a, hipStream_t s) {
   auto k = attn_na2d_bf16_kernel<KS>;
-  static bool set = false;
-  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, NaGeo<KS>::LDS); set = true; }
+  static LdsAttr set;
+  set.ensure(reinterpret_cast<const void*>(k), NaGeo<KS>::LDS);
   const long nb = (long)a.batch * a.nh * ((a.H + NA_TH - 1) / NA_TH) * ((a.W + NA_TW - 1) / NA_TW);
   char nm[64] = "attn_na2d_bf16";
   if (prof_on()) snprintf(nm, sizeof(nm), "attn_na2d_bf16 k%d %dx%d nh=%d", KS, a.H, a.W, a.nh);
@@ -630,8 +630,8 @@ extern "C" int kd_attn_global_bf16(const void* qkv, void* out, int batch, int T,
   hipStream_t s = (hipStream_t)stream;
   const long nb = (long)batch * nh;
   if (T > 256) {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_long_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS); set = true; }
+    static LdsAttr set;
+    set.ensure(reinterpret_cast<const void*>(attn_long_bf16_kernel), GL_LDS);
     const long nqb = (T + GL_QW * 32 - 1) / (GL_QW * 32);
     LaunchScope prof("attn_global_bf16", 4.0 * (double)nb * T * T * DH, 2.0 * (double)batch * T * nh * DH * 4.0, s);
     hipLaunchKernelGGL(attn_long_bf16_kernel, dim3((unsigned)(nb * nqb)), dim3(GL_QW * 64), GL_LDS, s, a);

@@ -1165,8 +1165,8 @@ static int launch_global_long(const DenseArgs& a, int prep, hipStream_t s) {
 #define KD_GL(PM)                                                                                                                                   \
   {                                                                                                                                                \
     auto k = attn_global_long_kernel<PM>;                                                                                                          \
-    static bool set = false;                                                                                                                       \
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS); set = true; }   \
+    static LdsAttr set;                                                                                                                       \
+    set.ensure(reinterpret_cast<const void*>(k), GL_LDS);   \
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(GL_THR), GL_LDS, s, a);                                                                    \
   }
   if (prep == 1) KD_GL(1) else if (prep == 2) KD_GL(2) else KD_GL(0)
@@ -1184,8 +1184,8 @@ static int launch_global_split(const DenseArgs& a, int prep, long nblocks, hipSt
 #define KD_GS(PM)                                                                                                                                \
   {                                                                                                                                             \
     auto k = attn_global_split_kernel<MODE, NT, PM>;                                                                                            \
-    static bool set = false;                                                                                                                    \
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }   \
+    static LdsAttr set;                                                                                                                    \
+    set.ensure(reinterpret_cast<const void*>(k), lds);   \
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(NT * 64), lds, s, a);                                                                   \
   }
   if (prep == 1) KD_GS(1) else if (prep == 2) KD_GS(2) else KD_GS(0)
@@ -1202,13 +1202,13 @@ static int launch_dense(const DenseArgs& a, int prep, long nblocks, const char* 
   LaunchScope prof(name, flops, bytes, s);
   if (prep) {
     auto k = attn_dense_kernel<MODE, MAXT, true>;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    static LdsAttr set;
+    set.ensure(reinterpret_cast<const void*>(k), (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(MAXT * 64), lds, s, a);
   } else {
     auto k = attn_dense_kernel<MODE, MAXT, false>;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    static LdsAttr set;
+    set.ensure(reinterpret_cast<const void*>(k), (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(MAXT * 64), lds, s, a);
   }
   return check_launch(name);
@@ -1307,13 +1307,10 @@ extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, 
   char nm[64] = "attn_na2d";
   if (prof_on()) snprintf(nm, sizeof(nm), "attn_na2d %dx%d nh=%d", H, W, nh);
   LaunchScope prof(nm, 4.0 * batch * (double)H * W * nh * DH * ks * ks, 16.0 * batch * (double)H * W * nh * DH, s);
-  static bool attr_set = false;
-  if (!attr_set) {
-#define KD_NA_ATTR(PM, FU) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_kernel<PM, FU>), hipFuncAttributeMaxDynamicSharedMemorySize, NA_LDS);
-    KD_NA_ATTR(0, true) KD_NA_ATTR(0, false) KD_NA_ATTR(1, true) KD_NA_ATTR(1, false) KD_NA_ATTR(2, true) KD_NA_ATTR(2, false)
+  static LdsAttr attr_set[6];
+#define KD_NA_ATTR(I, PM, FU) attr_set[I].ensure(reinterpret_cast<const void*>(attn_na2d_kernel<PM, FU>), NA_LDS);
+  KD_NA_ATTR(0, 0, true) KD_NA_ATTR(1, 0, false) KD_NA_ATTR(2, 1, true) KD_NA_ATTR(3, 1, false) KD_NA_ATTR(4, 2, true) KD_NA_ATTR(5, 2, false)
 #undef KD_NA_ATTR
-    attr_set = true;
-  }
   const bool full = H >= NA_HR && W >= NA_HC;      // every halo key is inside the image
 #define KD_NA(PM)                                                                                              \
   {                                                                                                           \

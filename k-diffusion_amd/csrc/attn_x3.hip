@@ -412,11 +412,8 @@ template <int NT>
 static int launch_global(const GArgs& a, hipStream_t s) {
   constexpr int QW = NT < 4 ? NT : 4, T = 32 * NT, lds = T * ROWB;
   auto kern = attn_global_x3_kernel<NT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(kern), lds);
   const long nb = (long)a.batch * a.nh * (NT / QW);
   LaunchScope prof("attn_global_x3", 4.0 * (double)a.batch * a.nh * T * T * DH, 16.0 * (double)a.batch * T * a.nh * DH, s);
   hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(QW * 64), lds, s, a);
@@ -440,11 +437,8 @@ int attn_na2d_x3_try(const float* qkv, float* out, int batch, int H, int W, int 
   if (!option("attn_x3", 1)) return 1;
   NArgs a{qkv, out, batch, H, W, nh, option("code_warm", KD_CODE_WARM_DEFAULT)};
   const long nb = (long)batch * nh * ((H + NA_TH - 1) / NA_TH) * ((W + NA_TW - 1) / NA_TW);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_na2d_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(attn_na2d_x3_kernel), LDS);
   char nm[64] = "attn_na2d_x3";
   if (prof_on()) snprintf(nm, sizeof(nm), "attn_na2d_x3 %dx%d nh=%d", H, W, nh);
   LaunchScope prof(nm, 4.0 * batch * (double)H * W * nh * DH * KS * KS, 16.0 * batch * (double)H * W * nh * DH, s);

@@ -23,7 +23,9 @@ static std::vector<ProfRec> g_recs;
 
 bool prof_on() { return g_prof.load(std::memory_order_relaxed); }
 
-int prof_begin(const char* name, double flops, double bytes, hipStream_t s) {
+static unsigned g_gen = 0;                // bumped by kd_prof_reset: a scope that began before a reset must not touch the records after it
+
+ProfTicket prof_begin(const char* name, double flops, double bytes, hipStream_t s) {
   ProfRec r;
   r.name = name; r.flops = flops; r.bytes = bytes;
   (void)hipEventCreate(&r.e0);
@@ -31,16 +33,15 @@ int prof_begin(const char* name, double flops, double bytes, hipStream_t s) {
   (void)hipEventRecord(r.e0, s);
   std::lock_guard<std::mutex> lock(g_rec_mutex);
   g_recs.push_back(r);
-  return (int)g_recs.size() - 1;
+  return ProfTicket{(int)g_recs.size() - 1, g_gen};
 }
 
-void prof_end(int idx, hipStream_t s) {
-  hipEvent_t e1 = nullptr;
-  {
-    std::lock_guard<std::mutex> lock(g_rec_mutex);
-    if (idx >= 0 && idx < (int)g_recs.size()) e1 = g_recs[idx].e1;      // (a kd_prof_reset between begin and end drops the record)
-  }
-  if (e1) (void)hipEventRecord(e1, s);
+void prof_end(ProfTicket t, hipStream_t s) {
+  // The end event is recorded UNDER the lock: kd_prof_reset destroys the events under the same lock, so the handle cannot die between
+  // the look-up and the record.  A reset between begin and end changes the generation: index t.idx then names another launch's
+  // record (or none) and is left alone.
+  std::lock_guard<std::mutex> lock(g_rec_mutex);
+  if (t.gen == g_gen && t.idx >= 0 && t.idx < (int)g_recs.size()) (void)hipEventRecord(g_recs[t.idx].e1, s);
 }
 
 }  // namespace kd
@@ -114,5 +115,6 @@ extern "C" int kd_prof_reset(void) {
   std::lock_guard<std::mutex> lock(g_rec_mutex);
   for (auto& r : g_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   g_recs.clear();
+  ++g_gen;
   return KD_OK;
 }

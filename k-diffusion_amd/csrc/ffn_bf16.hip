@@ -489,11 +489,8 @@ extern "C" int kd_ffn_bf16(const KdFfn* dp, void* stream) {
   if (d.attn && d.K != 128) return fail(KD_EINVAL, "kd_ffn_bf16: the fused out projection needs K == 128 (K=%d)", d.K);
   if (d.K == 256) {
     constexpr int LDS256 = 9 * WBLK;
-    static bool attr256 = false;
-    if (!attr256) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
-      attr256 = true;
-    }
+    static LdsAttr attr256;
+    attr256.ensure(reinterpret_cast<const void*>(ffn256_kernel), LDS256);
     char nm2[96] = "ffn_bf16";
     if (prof_on()) snprintf(nm2, sizeof(nm2), "ffn_bf16 M=%d K=%d dff=%d", d.M, d.K, d.d_ff);
     LaunchScope prof2(nm2, 2.0 * d.M * (double)d.K * (3.0 * d.d_ff), 4.0 * d.M * (double)d.K + 6.0 * d.d_ff * (double)d.K, s);
@@ -512,13 +509,10 @@ extern "C" int kd_ffn_bf16(const KdFfn* dp, void* stream) {
   auto kern = outp ? ffn_kernel<8, false, true> : (variant == 3 ? ffn_kernel<8, true> : ffn_kernel<8, false>);
   const int panel = FF_NW * 32, threads = FF_NW * 64;
   const int LDS = (variant == 3 && !outp ? 10 : 9) * WBLK;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * WBLK);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 10 * WBLK);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * WBLK);
-    attr_set = true;
-  }
+  static LdsAttr attr_set[3];
+  attr_set[0].ensure(reinterpret_cast<const void*>(ffn_kernel<8, false>), 9 * WBLK);
+  attr_set[1].ensure(reinterpret_cast<const void*>(ffn_kernel<8, true>), 10 * WBLK);
+  attr_set[2].ensure(reinterpret_cast<const void*>(ffn_kernel<8, false, true>), 9 * WBLK);
   char nm[96] = "ffn_bf16";
   if (prof_on()) snprintf(nm, sizeof(nm), "%s M=%d K=%d dff=%d", outp ? "ffn_bf16+out" : "ffn_bf16", d.M, d.K, d.d_ff);
   const double flops = 2.0 * d.M * (double)d.K * (3.0 * d.d_ff + (outp ? d.K : 0));

@@ -956,11 +956,8 @@ template <bool OUTP>
 static int launch_ffn_half(const FArgs3& a, const char* nm, double flops, double bytes, hipStream_t s) {
   constexpr int LDS = 4 * STG + 4 * 1024 + 4 * 2048;
   auto kern = ffn_x3h_kernel<OUTP>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(kern), LDS);
   LaunchScope prof(nm, flops, bytes, s);
   hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + 127) / 128)), dim3(256), LDS, s, a);
   return check_launch("kd_ffn_f32");
@@ -971,11 +968,8 @@ static int launch_ffn(const FArgs3& a, const char* nm, double flops, double byte
   auto kern = ffn_x3_kernel<NC, OUTP>;
   constexpr int K = NC * 16;
   constexpr int LDS = 8 * STG + 4 * (K * 4 < 1024 ? 1024 : K * 4) + 4 * 2048;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(kern), LDS);
   LaunchScope prof(nm, flops, bytes, s);
   hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + 127) / 128)), dim3(256), LDS, s, a);
   return check_launch("kd_ffn_f32");

@@ -577,11 +577,8 @@ static int launch(const GemmP& d, hipStream_t s) {
   constexpr int NCOL = (EPI == KD_EPI_GEGLU) ? 64 : BN;
   const long tiles = (long)((d.M + BM - 1) / BM) * ((d.N + NCOL - 1) / NCOL);
   auto kern = gemm_kernel<AMODE, NORM, EPI, PREC, KS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(kern), (int)LDS_BYTES);
   const double n_eff = (EPI == KD_EPI_GEGLU) ? 2.0 * d.N : (double)d.N;
   char nm[96] = "gemm";
   if (prof_on()) snprintf(nm, sizeof(nm), "gemm_%s<a%d,n%d,e%d%s> M=%d N=%d K=%d", PREC == KD_PREC_SPLIT3 ? "bf16x3" : "f32", AMODE, (int)NORM, EPI, KS == 2 ? ",ks2" : "", d.M, d.N, d.K);

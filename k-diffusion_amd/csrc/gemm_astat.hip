@@ -272,11 +272,8 @@ template <int NC, int EPI, int NWV>
 static int launch(const GemmP& d, hipStream_t s) {
   auto kern = gemm_astat_kernel<NC, EPI, NWV>;
   constexpr int LDS_BYTES = lds_bytes(NWV), BMW = NWV * 32;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(kern), LDS_BYTES);
   const double n_eff = (EPI == KD_EPI_GEGLU) ? 2.0 * d.N : (double)d.N;
   char nm[96] = "gemm_astat";
   if (prof_on()) snprintf(nm, sizeof(nm), "gemm_astat<e%d> M=%d N=%d K=%d", EPI, d.M, d.N, d.K);

@@ -294,11 +294,8 @@ constexpr int WSTAT_LDS_MAX = 144 * 1024;
 template <int NC, int EPI, bool NORM, int NW, bool PF, bool PIPE>
 static int launch_wstat(const GArgs& a, int lds, const char* nm, double flops, double bytes, hipStream_t s) {
   auto kern = gemm_wstat_kernel<NC, EPI, NORM, NW, PF, PIPE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WSTAT_LDS_MAX);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(kern), WSTAT_LDS_MAX);
   const int chunks = (a.M + 31) / 32;
   int groups = cu_count() / a.n_slices;
   if (groups < 1) groups = 1;
@@ -591,11 +588,8 @@ template <int AMODE, int EPI, int BMT, bool DEEP = false>
 static int launch_tiled(const TArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {
   auto kern = gemm_tiled_kernel<AMODE, EPI, BMT, DEEP>;
   constexpr int LDS = (BMT == 1 ? (DEEP ? 4 : 2) : 3) * (128 * BMT * 128 + WBLK);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(kern), LDS);
   const long tiles = (long)((a.M + 128 * BMT - 1) / (128 * BMT)) * a.n_tiles_n;
   LaunchScope prof(nm, flops, bytes, s);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256 * BMT), LDS, s, a);
@@ -910,11 +904,8 @@ template <int NC, int EPI, int NWV>
 static int launch_astat_w(const GArgs& a, int splits, const char* nm, double flops, double bytes, hipStream_t s) {
   auto kern = gemm_astat_kernel<NC, EPI, NWV>;
   constexpr int LDS = (NWV == 4 ? 4 : 8) * WBLK + NWV * NC * 64;      // ring + one scale vector (K floats) per wave
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(kern), LDS);
   const int panels = (a.M + 32 * NWV - 1) / (32 * NWV);
   GArgs b = a;
   b.n_slices = splits;                                // (the astat kernel's use of this field: n-splits per panel)
@@ -1226,11 +1217,8 @@ template <int AMODE, int EPI>
 static int launch_generic(const KdGemm& d, hipStream_t s) {
   auto kern = gemm_generic_bf16_kernel<AMODE, EPI>;
   constexpr int LDS = 2 * WBLK + 128 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(kern), LDS);
   constexpr int NCOL = EPI == KD_EPI_GEGLU ? 64 : 128;
   const long tiles = (long)((d.M + 127) / 128) * ((d.N + NCOL - 1) / NCOL);
   const double n_eff = EPI == KD_EPI_GEGLU ? 2.0 * d.N : (double)d.N;

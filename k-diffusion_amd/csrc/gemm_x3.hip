@@ -778,11 +778,8 @@ static int launch(const XArgs& a0, const char* nm, double flops, double bytes, h
   auto kern = gemm_x3_astat_kernel<NC, EPI>;
   constexpr int K = NC * 16, NSTG = NC <= 8 ? 4 : 8;
   constexpr int LDS = NSTG * STG + 4 * (K * 4 < 1024 ? 1024 : K * 4) + 4 * 2048 + 1024;     // ring + scale vectors + store strips + per-head constants
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(kern), LDS);
   // n-splits of a panel: every workgroup pays the row prologue (about one n-tile's K loop) and then its share of the n-tiles; the grid
   // runs in ceil(workgroups / resident slots) rounds.  The divisor of n_tiles with the smallest rounds x (1 + tiles per split) wins
   // (ties: fewer splits = fewer redundant prologues).
@@ -807,11 +804,8 @@ template <int EPI>
 static int launch_half(const XArgs& a0, const char* nm, double flops, double bytes, hipStream_t s) {
   auto kern = gemm_x3h_kernel<EPI>;
   constexpr int LDS = 4 * STG + 4 * 1024 + 4 * 2048 + 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(kern), LDS);
   // the same cost model as launch() with two resident workgroups per CU; a prologue costs about two half tiles
   const int panels = (a0.M + 127) / 128, slots = 2 * cu_count();
   int best = 1;

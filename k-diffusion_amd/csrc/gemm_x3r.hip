@@ -260,11 +260,8 @@ template <int AMODE, int EPI>
 static int launch(const RArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {
   auto kern = gemm_x3r_kernel<AMODE, EPI>;
   constexpr int LDS = NSTG * STAGE + 4 * 2048;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(kern), LDS);
   const long tiles = (long)((a.M + 127) / 128) * (a.N / 128);
   LaunchScope prof(nm, flops, bytes, s);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), LDS, s, a);

@@ -303,11 +303,8 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const float* __restrict
 template <int EPI, bool CSPLIT>
 static int launch(const TArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {
   auto kern = gemm_x3_tiled_kernel<EPI, CSPLIT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(kern), LDS_BYTES);
   const long tiles = (long)((a.M + BMR - 1) / BMR) * a.n_tiles_n;
   LaunchScope prof(nm, flops, bytes, s);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), LDS_BYTES, s, a);

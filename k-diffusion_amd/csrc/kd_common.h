@@ -1,6 +1,7 @@
 // Shared host/device helpers for libkdiff_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -34,13 +35,30 @@ int option_at(int idx, int dflt);
 // ---- per-launch profiling (bench.py): hipEvent pairs around launches when enabled ---------------
 struct ProfRec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
 bool prof_on();
-int prof_begin(const char* name, double flops, double bytes, hipStream_t s);      // -> index of the record (thread-safe)
-void prof_end(int idx, hipStream_t s);
+struct ProfTicket { int idx; unsigned gen; };     // record index + the generation of the record list it belongs to (kd_prof_reset starts a new one)
+ProfTicket prof_begin(const char* name, double flops, double bytes, hipStream_t s);      // thread-safe
+void prof_end(ProfTicket t, hipStream_t s);
 
 struct LaunchScope {
-  hipStream_t s; int idx;
-  LaunchScope(const char* name, double flops, double bytes, hipStream_t st) : s(st), idx(prof_on() ? prof_begin(name, flops, bytes, st) : -1) {}
-  ~LaunchScope() { if (idx >= 0) prof_end(idx, s); }
+  hipStream_t s; ProfTicket t;
+  LaunchScope(const char* name, double flops, double bytes, hipStream_t st) : s(st), t(prof_on() ? prof_begin(name, flops, bytes, st) : ProfTicket{-1, 0}) {}
+  ~LaunchScope() { if (t.idx >= 0) prof_end(t, s); }
+};
+
+// hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, set ONCE PER KERNEL AND DEVICE from whichever host thread launches it first.
+// One function-local `static LdsAttr` per launch site (= per kernel instantiation): a bit per device ordinal.  hipFuncSetAttribute is
+// idempotent, so two threads racing on a kernel's first launch both set the same value before either publishes the device's bit; a thread
+// that reads the bit (acquire) launches after the attribute call that published it (release).
+struct LdsAttr {
+  std::atomic<unsigned long long> done{0};
+  void ensure(const void* kern, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+  }
 };
 
 inline int check_launch(const char* what) {

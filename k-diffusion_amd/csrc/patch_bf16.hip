@@ -239,19 +239,10 @@ static int cu_count_p() {
   return n;
 }
 
-template <typename Kern>
-static int launch_patch(Kern kern, const PArgs& a, int lds, const char* nm, double flops, double bytes, hipStream_t s) {
-  {   // once per kernel
-    static const void* seen[8];
-    static int n_seen = 0;
-    const void* kp = reinterpret_cast<const void*>(kern);
-    bool have = false;
-    for (int i = 0; i < n_seen; ++i) have |= seen[i] == kp;
-    if (!have) {
-      (void)hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      if (n_seen < 8) seen[n_seen++] = kp;
-    }
-  }
+template <auto kern>                  // (the kernel is a template ARGUMENT: one LdsAttr per kernel, although all of them share one function type)
+static int launch_patch(const PArgs& a, int lds, const char* nm, double flops, double bytes, hipStream_t s) {
+  static LdsAttr attr_set;
+  attr_set.ensure(reinterpret_cast<const void*>(kern), 64 * 1024);
   const int chunks = (a.M + 31) / 32;
   int groups = cu_count_p();
   const int need = (chunks + PNW - 1) / PNW;
@@ -278,8 +269,8 @@ int gemm_patch_try(const KdGemm& d, hipStream_t s, int* rc) {
     snprintf(nm, sizeof(nm), prof_on() ? "gemm_bf16_unpatch4 M=%d N=%d K=%d" : "gemm_unpatch4", d.M, d.N, d.K);
     const double flops = 2.0 * d.M * d.N * (double)d.K, bytes = 2.0 * d.M * d.K + (d.sigma ? 8.0 : 4.0) * d.M * d.N + 2.0 * d.N * d.K;
     const int lds = (d.K / 64) * WBLK;
-    if (d.K == 128) *rc = d.norm ? launch_patch(unpatch4_kernel<8, true>, a, lds, nm, flops, bytes, s) : launch_patch(unpatch4_kernel<8, false>, a, lds, nm, flops, bytes, s);
-    else *rc = d.norm ? launch_patch(unpatch4_kernel<16, true>, a, lds, nm, flops, bytes, s) : launch_patch(unpatch4_kernel<16, false>, a, lds, nm, flops, bytes, s);
+    if (d.K == 128) *rc = d.norm ? launch_patch<unpatch4_kernel<8, true>>(a, lds, nm, flops, bytes, s) : launch_patch<unpatch4_kernel<8, false>>(a, lds, nm, flops, bytes, s);
+    else *rc = d.norm ? launch_patch<unpatch4_kernel<16, true>>(a, lds, nm, flops, bytes, s) : launch_patch<unpatch4_kernel<16, false>>(a, lds, nm, flops, bytes, s);
     return 0;
   }
   if (d.a_mode == KD_A_PATCH_NCHW && d.epi == KD_EPI_STORE) {
@@ -287,7 +278,7 @@ int gemm_patch_try(const KdGemm& d, hipStream_t s, int* rc) {
     a.img = d.A; a.Ct = reinterpret_cast<u16*>(d.C);
     snprintf(nm, sizeof(nm), prof_on() ? "gemm_bf16_patchin4 M=%d N=%d K=%d" : "gemm_patchin4", d.M, d.N, d.K);
     const double flops = 2.0 * d.M * d.N * (double)d.K, bytes = 4.0 * d.M * d.K + 2.0 * d.M * d.N + 2.0 * d.N * d.K;
-    *rc = launch_patch(patchin4_kernel, a, (d.N / 128) * WBLK, nm, flops, bytes, s);
+    *rc = launch_patch<patchin4_kernel>(a, (d.N / 128) * WBLK, nm, flops, bytes, s);
     return 0;
   }
   return 1;

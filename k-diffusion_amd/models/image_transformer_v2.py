@@ -23,6 +23,7 @@ The plan (workspace + prebuilt launch descriptors) is cached per input shape.  T
 CPU path: calling ``forward`` without a ROCm device or without the built library raises.
 """
 import ctypes as C
+import itertools
 import os
 import math
 from dataclasses import dataclass
@@ -45,6 +46,19 @@ D_HEAD = 64
 SCHEDULE_TABLE_MAX_BYTES = 1 << 30
 SCHEDULES_KEPT = 4            # a run of a two-stage solver hints two tables; older records (and their tensors) are dropped
 SCHEDULE_CHAINS_KEPT = 2      # conditioning workspaces kept per plan, by schedule length (least recently used dropped)
+# environment switches read while a plan is built (name, default): part of the plan key
+PLAN_SWITCHES = (("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "0"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "1"), ("KDIFF_X3_PLANES", "1"),
+                 ("KDIFF_X3_DOWN", "0"))
+CLASS_IDS_KEPT = 4            # range-checked class_cond tensors remembered per plan (cond / uncond pairs of a guidance wrapper)
+
+
+_untracked = itertools.count(-1, -1)
+
+
+def _ver(t):
+    """Version counter of a tensor, or a value that never repeats for tensors made under torch.inference_mode() (they carry no
+    counter, so an in-place change cannot be seen: such a tensor is never recognised as 'the same data as last time')."""
+    return next(_untracked) if t.is_inference() else t._version
 
 
 def _graph_policy():
@@ -189,14 +203,14 @@ class _Schedule:
     """Scale tables of a whole sigma schedule: rows of ``sigma_table`` ([n, B], one row per model call) -> tables[i]."""
 
     def __init__(self, sigma_table, others, ident_others, tables, done):
-        self.base, self.version, self.n, self.B = sigma_table.data_ptr(), sigma_table._version, sigma_table.shape[0], sigma_table.shape[1]
+        self.base, self.version, self.n, self.B = sigma_table.data_ptr(), _ver(sigma_table), sigma_table.shape[0], sigma_table.shape[1]
         self.ident_others, self.tables, self.done = ident_others, tables, done
         # the record keeps the hinted tensors alive, so their addresses cannot be handed to other tensors while it exists
         self.keep = (sigma_table, others)
 
     def row_of(self, sigma):
         """Index of the table row ``sigma`` is a view of, or None."""
-        if sigma.dtype != torch.float32 or sigma.numel() != self.B or not sigma.is_contiguous() or sigma._version != self.version:
+        if sigma.dtype != torch.float32 or sigma.numel() != self.B or not sigma.is_contiguous() or _ver(sigma) != self.version:
             return None
         off = sigma.data_ptr() - self.base
         if off < 0 or off % (4 * self.B) or off // (4 * self.B) >= self.n:
@@ -235,7 +249,7 @@ class _Plan:
         self.g_x = self.g_out = self.capture_stream = None   # their fixed input / output images
         self.direct_runs = self.direct_cond_runs = 0
         self.graph_epoch = nat.option_epoch
-        self.class_checked = self.class_keep = None         # identity of the last range-checked class_cond tensor (_plan_for)
+        self.class_checked = {}                             # identities of the range-checked class_cond tensors (_plan_for) -> the tensor
         mw, mdff = m.mapping_spec.width, m.mapping_spec.d_ff
 
         # ---- static buffers -----------------------------------------------------------------
@@ -424,7 +438,9 @@ class _Plan:
                 # window / key tile of the attention cores would otherwise redo that work per use
                 # ... and, for the split-bf16x3 cores, already SPLIT (hi / lo bf16 chunks in the fp32 slots): the cores take
                 # their operands as stored instead of converting every halo / window / key-block element again
-                if xn is not None and prepass(d):
+                # (the tiled qkv epilogue keeps its per-head constants in a 16-head LDS table, csrc/gemm_x3t.hip: wider levels -- 1152 =
+                # 18 heads and up -- take the fp32-A norm -> projection kernels of round 1 like every shape the fused kernels refuse)
+                if xn is not None and prepass(d) and nh <= 16:
                     # AdaRMSNorm -> planes once, then a GEMM whose two operands both move by LDS-DMA
                     xn_planes = norm_split(prefix + "self_attn.norm", x, scale_ptr(prefix + "self_attn.norm")[1], T, d, rps)
                     dq = gemm(prefix + "qkv_proj", None, sa.qkv_proj.weight, qkv, T, 3 * d, d, epi=nat.EPI_QKV, rows_per_sample=rps, qk=qk,
@@ -642,7 +658,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
                                      for a, b in zip(levels[:-1], levels[1:])])
         self.out_norm = _rms_scale(levels[0].width)
         self.patch_out = _Holder(proj=_linear_weight(out_channels * ph * pw, levels[0].width, zero=True))
-        self._plans, self._fingerprint, self._packed = {}, None, {}
+        self._plans, self._fingerprint, self._packed, self._plans_epoch = {}, None, {}, None
 
     # ---- bookkeeping ---------------------------------------------------------------------------
     def _ada_norm_modules(self):
@@ -688,7 +704,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         return ent[1]
 
     def _weights_fingerprint(self):
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        return tuple((t.data_ptr(), 0 if t.is_inference() else t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     def param_groups(self, base_lr=5e-4, mapping_lr_scale=1 / 3):
         raise NotImplementedError("training is outside this package's scope (sampling hot path only)")
@@ -767,28 +783,45 @@ class ImageTransformerDenoiserModelV2(nn.Module):
                 return None
             self._plans, self._fingerprint, self._packed = {}, fp, {}
         has_class = self.class_emb is not None
-        key = (B, H, W, aug_cond is not None, has_class, self.mapping_cond_in_proj is not None, x.device, nat.default_precision(),
-               os.environ.get("KDIFF_QKV_PACKED", "1"), os.environ.get("KDIFF_GRAPH", "0"))
+        # Kernel selection is fixed when a plan is built: by the arithmetic mode, by the environment switches read in _Plan and by
+        # library options (kd_ffn_f32_supported follows "ffn_x3").  The switches are part of the key; a change of any library option
+        # (nat.option_epoch, bumped by set_option and by a changed KDIFF_OPTIONS / KDIFF_* variable) drops the cached plans, so an
+        # A/B run on ONE model object really compares two plans.
+        nat.lib()                                  # (syncs the environment-mapped options -> option_epoch)
+        if self._plans_epoch != nat.option_epoch:
+            if not create:
+                return None
+            self._plans, self._plans_epoch = {}, nat.option_epoch
+        key = (B, H, W, aug_cond is not None, has_class, self.mapping_cond_in_proj is not None, x.device, nat.default_precision()) \
+            + tuple(os.environ.get(k, d) for k, d in PLAN_SWITCHES)
         plan = self._plans.get(key)
         if plan is None and create:
             if self.patch_in.proj.weight.device != x.device:
                 raise RuntimeError(f"model weights are on {self.patch_in.proj.weight.device}, input on {x.device}")
-            plan = self._plans[key] = _Plan(self, B, H, W, key[3], has_class, key[5], x.device)
+            with torch.inference_mode(False):     # (workspaces made under inference_mode could not be written in place outside it later)
+                plan = self._plans[key] = _Plan(self, B, H, W, key[3], has_class, key[5], x.device)
         if plan is not None and has_class and class_cond is not None:
             # nn.Embedding raises on an out-of-range id (on every call); the HIP kernel would read past the table.  Checked whenever
             # the ids are a tensor this plan has not seen in this state (address, version): one device->host read per new id
             # tensor -- a sampling run passes the same tensor to every step, so the per-step path stays sync-free.
-            ident = (class_cond.data_ptr(), class_cond._version, tuple(class_cond.shape))
-            if plan.class_checked != ident:
+            # (tensors made under torch.inference_mode() carry no version counter: they cannot be recognised as unchanged and are
+            # re-checked on every call.  A few identities are remembered, so alternating id tensors -- cond / uncond calls of a
+            # guidance wrapper -- stay sync-free as well.)
+            tracked = not class_cond.is_inference()
+            ident = (class_cond.data_ptr(), _ver(class_cond), tuple(class_cond.shape))
+            if not tracked or ident not in plan.class_checked:
                 lo, hi = (int(class_cond.min()), int(class_cond.max())) if class_cond.numel() else (0, 0)
                 if lo < 0 or hi >= self.class_emb.weight.shape[0]:
                     raise IndexError(f"class_cond ids must lie in [0, {self.class_emb.weight.shape[0] - 1}] (got {lo}..{hi})")
-                plan.class_checked, plan.class_keep = ident, class_cond      # (kept alive: the address cannot be recycled under the record)
+                if tracked:
+                    plan.class_checked[ident] = class_cond        # (kept alive: the address cannot be recycled under the record)
+                    while len(plan.class_checked) > CLASS_IDS_KEPT:
+                        del plan.class_checked[next(iter(plan.class_checked))]
         return plan
 
     # ---- conditioning ahead of time ---------------------------------------------------------------
     def _cond_identity(self, sigma, aug_cond, class_cond, mapping_cond):
-        return tuple(None if t is None else (t.data_ptr(), t._version, tuple(t.shape)) for t in (sigma, aug_cond, class_cond, mapping_cond))
+        return tuple(None if t is None else (t.data_ptr(), _ver(t), tuple(t.shape)) for t in (sigma, aug_cond, class_cond, mapping_cond))
 
     def _hint_usable(self, x_like, class_cond, mapping_cond):
         if not x_like.is_cuda or x_like.dim() != 4:
@@ -812,7 +845,8 @@ class ImageTransformerDenoiserModelV2(nn.Module):
             return False                          # (a captured main chain is bound to the address of its scale table)
         chain = plan.schedule_chains.pop(n, None)
         if chain is None:
-            chain = plan.build_cond(n * B)
+            with torch.inference_mode(False):
+                chain = plan.build_cond(n * B)
         plan.schedule_chains[n] = chain                   # most recently used last; older lengths (and their workspaces) are dropped
         for old_n in list(plan.schedule_chains)[:-SCHEDULE_CHAINS_KEPT]:
             del plan.schedule_chains[old_n]

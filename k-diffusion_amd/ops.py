@@ -50,6 +50,7 @@ def pack_weight(W, N, K, geglu, cache=True, bf16=False):
     image of KD_PREC_BF16.  ``geglu``: 0 / False plain, 1 / True GEGLU rows, 2 the k order of the fused FF block's down projection.  Weights are static while sampling, so the image is cached per tensor OBJECT (weak reference +
     version counter: a new tensor that happens to reuse the address of a freed one never hits a stale image)."""
     geglu = int(geglu)
+    cache = cache and not W.is_inference()        # (no version counter to tell a rewritten tensor by: never cached)
     key = (id(W), bool(bf16), geglu)
     ent = _packed.get(key) if cache else None
     if ent is not None:

@@ -57,6 +57,71 @@ def test_ctypes_structs_mirror_the_header(KD):
         assert fields == mirror, (name, [a for a, b in zip(fields, mirror) if a != b][:3], len(fields), len(mirror))
 
 
+def _call_args(text, start):
+    """Top-level arguments of the call whose opening parenthesis is at ``text[start]`` (balanced (), [] and {})."""
+    depth, args, cur = 0, [], []
+    for ch in text[start:]:
+        if ch in "([{":
+            depth += 1
+            if depth == 1:
+                continue
+        elif ch in ")]}":
+            depth -= 1
+            if depth == 0:
+                break
+        if ch == "," and depth == 1:
+            args.append("".join(cur).strip())
+            cur = []
+        else:
+            cur.append(ch)
+    else:
+        raise AssertionError("unbalanced call")
+    last = "".join(cur).strip()
+    return args + ([last] if last else [])
+
+
+def header_prototypes():
+    """name -> argument count of every entry point include/kdiff_hip.h declares."""
+    src = open(os.path.join(REPO, "include", "kdiff_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(kd_[a-z0-9_]+)\s*\(", src):
+        args = _call_args(src, m.end() - 1)
+        out[m.group(1)] = 0 if args in ([], ["void"]) else len(args)
+    return out
+
+
+def test_integration_stubs_match_the_abi(KD):
+    """INTEGRATION.md shows the ctypes stubs a reference maintainer would paste.  Every ``_lib.kd_*(...)`` call in its code blocks, and
+    every prototype-style ``kd_*(a, b, ...)`` line in their comments, must pass exactly as many arguments as the header declares (and the
+    ctypes table binds): a missing argument shifts the stream pointer into the wrong slot without any error at the call site."""
+    protos = header_prototypes()
+    assert {k: len(v) for k, v in KD._native.SIGNATURES.items()} == protos        # the ctypes table agrees with the header
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    assert len(blocks) >= 4
+    checked = {}
+    for code in blocks:
+        for m in re.finditer(r"_lib\.(kd_[a-z0-9_]+)\(", code):
+            args = _call_args(code, m.end() - 1)
+            assert len(args) == protos[m.group(1)], (m.group(1), len(args), protos[m.group(1)], args)
+            checked[m.group(1)] = checked.get(m.group(1), 0) + 1
+        for line in code.splitlines():                       # "# global:  kd_attn_global_bf16(qkv, out, n, h*w, nh, stream)  (remark)"
+            if line.lstrip().startswith("#"):
+                for m in re.finditer(r"(?<![._a-z])(kd_[a-z0-9_]+)\(", line):
+                    args = _call_args(line, m.end() - 1)
+                    if args and "..." not in args[-1]:
+                        assert len(args) == protos[m.group(1)], (line.strip(), len(args), protos[m.group(1)])
+                        checked[m.group(1)] = checked.get(m.group(1), 0) + 1
+    for name in ("kd_attn_na2d_f32", "kd_attn_global_f32", "kd_attn_window_f32", "kd_attn_na2d_bf16", "kd_rmsnorm_f32", "kd_sampler_step_f32"):
+        assert checked.get(name), f"INTEGRATION.md no longer shows a stub for {name}"
+    # the argument in front of the stream of the fp32 attention cores is the arithmetic mode, by name
+    for name in ("kd_attn_na2d_f32", "kd_attn_global_f32", "kd_attn_window_f32"):
+        call = re.search(r"_lib\." + name + r"\(", text)
+        args = _call_args(text, call.end() - 1)
+        assert args[-2].startswith("KD_PREC_") and args[-1] == "_s()", (name, args[-2:])
+
+
 def test_schedule_rows_are_recognised_by_storage_and_version(KD):
     """prefetch_schedule bookkeeping (host logic, no GPU): a model call is served from a schedule's scale table only when its sigma
     argument IS a row of the hinted table -- same storage, same version counter, whole contiguous fp32 row."""
@@ -74,6 +139,13 @@ def test_schedule_rows_are_recognised_by_storage_and_version(KD):
     assert all(sch.row_of(table[i]) is None for i in range(6))
     # the record keeps the hinted tensors alive (their addresses cannot be recycled while it exists)
     assert sch.keep[0] is table
+    # tensors made under torch.inference_mode() have no version counter (reading it raises): they are never recognised as unchanged,
+    # so such a table is simply not used and its calls take the per-step chain
+    with torch.inference_mode():
+        itab = torch.linspace(80.0, 0.1, 6)[:, None].expand(6, 4).contiguous()
+    isch = mod._Schedule(itab, (None, None, None), (None, None, None), torch.zeros(6, 4, 8), None)
+    assert all(isch.row_of(itab[i]) is None for i in range(6))
+    assert mod._ver(itab) != mod._ver(itab) and mod._ver(table) == mod._ver(table)
 
 
 def test_every_option_name_used_in_the_sources_is_registered():
