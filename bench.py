@@ -63,6 +63,7 @@ def parse():
     p.add_argument("--no-kernel-events", action="store_true", help="do not record per-launch HIP events in the timed region")
     p.add_argument("--kernel-table", default=None, help="write the per-kernel event timings to this JSON file")
     p.add_argument("--no-other-configs", action="store_true", help="skip the short secondary measurement of the shifted-window config")
+    p.add_argument("--no-parity", action="store_true", help="skip the golden-vector parity block (5-step batch-32 run per measured mode)")
     return p.parse_args()
 
 
@@ -198,6 +199,53 @@ def _cpu_baseline(hdit, solvers, cfg, seed, sampler_steps, target_seconds):
                                  "sample": "k_diffusion (reference) sample_dpmpp_2m, config_oxford_flowers_shifted_window.json, fp32, 8 CPU cores "
                                            "(BASELINE.md section 3): the port above is 3-4x slower than the reference's own torch modules on a "
                                            "comparable core count -- GPU/CPU ratios should be taken against THIS figure"}}
+
+
+PARITY_CASE = "smp32_flowers_na_2m5"     # tests/golden/cases.SAMPLE_B32_CASES[0]: this workload's config at this batch, 5 DPM++2M steps
+
+
+def parity_vs_reference_golden(dev, modes):
+    """Distance of this build, on this box, to the REFERENCE's own images: the committed golden ``tests/golden/samples_r3.safetensors``
+    (recorded from the imported reference by oracle/make_golden_r3.py; the oracle is not involved) holds the reference's fp32 output of a
+    5-step DPM++2M run of config_oxford_flowers.json at batch 32 for images cases.B32_KEEP.  The same run (same weights seed, noise, sigmas)
+    goes through the HIP path in every mode; rel_err = max|got - ref| / max|ref|, north_star's measure.  The bf16 mode is also compared with
+    the reference's own torch.autocast(bfloat16) run of those images (samples_r4.safetensors, oracle/make_golden_r4.py)."""
+    from safetensors.torch import load_file
+    from tests.golden import cases
+    case, cfgname, sampler, steps, batch = next(c for c in cases.SAMPLE_B32_CASES if c[0] == PARITY_CASE)
+    ref = load_file(os.path.join(cases.GOLDEN_DIR, "samples_r3.safetensors"))[case]
+    r4 = os.path.join(cases.GOLDEN_DIR, "samples_r4.safetensors")
+    ref16 = load_file(r4).get(case + "_bf16") if os.path.exists(r4) else None
+    cfg = K.config.load_config(cases.raw_config(cfgname))
+    mc = cfg["model"]
+    model = K.config.make_model(cfg).eval().requires_grad_(False)
+    model.load_state_dict(K.synth.synth_state_dict(model.state_dict(), seed=cases.WEIGHT_SEED))
+    den = K.Denoiser(model.to(dev), sigma_data=mc["sigma_data"])
+    x, _ = cases.sample_inputs(cfg, batch)
+    x = x.to(dev)
+    sigmas = K.sampling.get_sigmas_karras(steps, mc["sigma_min"], mc["sigma_max"], rho=7., device=dev)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    out, saved = {}, os.environ.get("KDIFF_GEMM")
+    try:
+        for m in modes:
+            os.environ["KDIFF_GEMM"] = m
+            y = getattr(K.sampling, sampler)(den, x, sigmas, disable=True)[cases.B32_KEEP].float().cpu()
+            gate = 1e-3 if m != "bf16" else None         # north_star's tolerance applies to the fp32-parity modes
+            ent = {"rel_err_vs_reference_golden": round(rel(y, ref), 7), "gate": gate}
+            if gate is not None:
+                ent["pass"] = ent["rel_err_vs_reference_golden"] < gate
+            elif ref16 is not None:
+                ent["rel_err_vs_reference_autocast_bf16"] = round(rel(y, ref16), 7)
+                ent["reference_autocast_bf16_vs_reference_fp32"] = round(rel(ref16, ref), 7)
+            out[m] = ent
+    finally:
+        os.environ["KDIFF_GEMM"] = saved if saved is not None else "split3"
+    return {"case": f"{case}: {os.path.basename(CONFIG_OF[cfgname])} 256x256, {sampler} {steps} steps, batch {batch}, images {cases.B32_KEEP} "
+                    "against the reference's fp32 run (tests/golden/samples_r3.safetensors)",
+            "measure": "max|got - ref| / max|ref|", **out}
+
+
+CONFIG_OF = {"flowers_na": "configs/config_oxford_flowers.json", "flowers_sw": "configs/config_oxford_flowers_shifted_window.json"}
 
 
 MODE_DTYPE = {
@@ -420,6 +468,17 @@ def main():
                     "split3": other_config("sde", na, dev, args, "sample_dpmpp_sde", "split3", brownian=True),
                     "bf16+fp8w": other_config("sde", na, dev, args, "sample_dpmpp_sde", "bf16", fp8=True, brownian=True)},
             }
+        if args.gpus == 1 and not args.no_parity:
+            # parity magnitudes where the driver's record shows them: after the timed regions, every measured mode against the reference's golden
+            measured = [args.mode] + [m for m in result.get("modes", {}) if m != args.mode]
+            par = parity_vs_reference_golden(dev, measured)
+            head_par = par[args.mode]
+            result["parity"] = {"case": par["case"], "measure": par["measure"], "mode": args.mode,
+                                "rel_err": head_par["rel_err_vs_reference_golden"], "gate": head_par["gate"], "pass": head_par.get("pass"),
+                                "modes": {m: par[m] for m in measured}}
+        if "modes" in result:
+            # short copy of the per-mode throughputs (the full entries carry their rooflines: a truncated log tail may cut them off)
+            result["mode_values"] = {m: e["value"] for m, e in result["modes"].items()}
         if not args.no_cpu_baseline and args.gpus == 1:
             result["cpu_baseline"] = cpu_baseline(cfg, args.seed, args.sampler_steps, args.cpu_seconds)
         print(json.dumps(result), flush=True)

@@ -15,8 +15,11 @@
  *     unsupported size); kd_last_error() then describes it.  Nothing throws;
  *   - activations are token-major ("NHWC"): [batch, h, w, channels] row-major fp32;
  *     qkv buffers are [batch*h*w, 3, n_heads, 64] (feature index t*(nh*64) + head*64 + e,
- *     k_diffusion/models/image_transformer_v2.py:386,422,431,467); head dim is fixed at 64
- *     (every shipped config, k_diffusion/config.py:135-136).
+ *     k_diffusion/models/image_transformer_v2.py:386,422,431,467); the head dim is 64 in EVERY arithmetic mode (fp32-parity and bf16
+ *     alike: every shipped config, k_diffusion/config.py:135-136).  The reference's `d_head` (image_transformer_v2.py:355-363:
+ *     n_heads = d_model // d_head, RoPE on d_head // 2) is therefore not an argument of any entry point -- n_heads is, and the feature
+ *     width is n_heads * 64; the Python mirror's model constructor refuses other values with a ValueError that says so
+ *     (k-diffusion_amd/models/image_transformer_v2.py) instead of handing the kernels a layout they would misread.
  */
 #ifndef KDIFF_HIP_H
 #define KDIFF_HIP_H

@@ -624,7 +624,10 @@ class ImageTransformerDenoiserModelV2(nn.Module):
             if not isinstance(sa, (GlobalAttentionSpec, NeighborhoodAttentionSpec, ShiftedWindowAttentionSpec, NoAttentionSpec)):
                 raise ValueError(f"unsupported self attention spec {sa}")
             if not isinstance(sa, NoAttentionSpec) and sa.d_head != D_HEAD:
-                raise ValueError(f"the HIP attention cores are built for d_head == {D_HEAD} (got {sa.d_head})")
+                raise ValueError(f"d_head must be {D_HEAD} (got {sa.d_head}): the HIP kernels of both arithmetic modes -- qkv epilogue (cosine-sim "
+                                 f"norm + RoPE over {D_HEAD // 2} dims), attention cores, qkv layout [tokens, 3, n_heads, {D_HEAD}] of "
+                                 f"include/kdiff_hip.h -- are built for {D_HEAD}-dim heads, as every shipped config uses (config.py:137-138); "
+                                 f"the reference's other head sizes (image_transformer_v2.py:355-363) are not supported")
             if not isinstance(sa, NoAttentionSpec) and lv.width % sa.d_head:
                 raise ValueError(f"width {lv.width} is not a multiple of d_head {sa.d_head}")
         self.level_specs, self.mapping_spec = list(levels), mapping

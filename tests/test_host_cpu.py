@@ -234,6 +234,15 @@ def test_hot_path_has_no_cpu_fallback(KD):
         model(x, torch.ones(1))
 
 
+def test_unsupported_head_size_is_refused_with_a_reason(KD):
+    """The reference takes any d_head (image_transformer_v2.py:355-363); the HIP kernels of both arithmetic modes are built for 64 (the
+    only value the shipped configs use).  Anything else is refused at construction, by name, not misread by a kernel."""
+    raw = {"model": {"type": "image_transformer_v2", "input_channels": 3, "input_size": [32, 32], "patch_size": [2, 2], "depths": [1],
+                     "widths": [128], "self_attns": [{"type": "global", "d_head": 32}], "sigma_data": 0.5, "sigma_min": 1e-2, "sigma_max": 80}}
+    with pytest.raises(ValueError, match="d_head must be 64"):
+        KD.config.make_model(KD.config.load_config(raw))
+
+
 def test_product_package_never_imports_the_oracle():
     """oracle/ is test infrastructure: nothing under k-diffusion_amd/ or sample.py may import it."""
     offenders = []
