@@ -227,9 +227,11 @@ int kd_attn_window_f32(const float* qkv, float* out, int batch, int H, int W, in
                        int prep, const float* scale_h, const float* cos_t, const float* sin_t, float eps,
                        int precision, void* stream);
 
-/* 2-D neighbourhood attention, kernel ks x ks (ks == 7), window clamped inside the image,
- * dilation 1, heads-last.  Replaces natten.functional.na2d(q,k,v,7,scale=1.0)
- * image_transformer_v2.py:428 (and the unfused pair :437-439). */
+/* 2-D neighbourhood attention, kernel ks x ks, window clamped inside the image, dilation 1, heads-last.  Replaces
+ * natten.functional.na2d(q,k,v,kernel_size,scale=1.0) image_transformer_v2.py:428 (and the unfused pair :437-439; kernel_size is
+ * the block's constructor argument, :399-410).  ks: odd, 3 .. 13 with split-stored operands (prep = 2: what the package's fp32-parity
+ * mode runs -- 7 is the shipped size, 3 / 5 / 9 the same kernel with other constants, 11 / 13 a densely packed patch form);
+ * ks == 7 only for fp32 operands (prep 0 / 1) and with option "attn_x3" = 0.  H, W >= ks. */
 int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, int W, int nh, int ks,
                      int prep, const float* scale_h, const float* cos_t, const float* sin_t, float eps,
                      int precision, void* stream);

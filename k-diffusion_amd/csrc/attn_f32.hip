@@ -1288,20 +1288,24 @@ extern "C" int kd_attn_window_f32(const float* qkv, float* out, int batch, int H
   return launch_dense<MODE_WINDOW16, 8>(a, prep, nb, "attn_window_f32", s);
 }
 
-namespace kd { int attn_na2d_x3_try(const float* qkv, float* out, int batch, int H, int W, int nh, hipStream_t s, int* rc); }   // attn_x3.hip
+namespace kd { int attn_na2d_x3_try(const float* qkv, float* out, int batch, int H, int W, int nh, int ks, hipStream_t s, int* rc); }   // attn_x3.hip
 
 extern "C" int kd_attn_na2d_f32(const float* qkv, float* out, int batch, int H, int W, int nh, int ks, int prep,
                                 const float* scale_h, const float* cos_t, const float* sin_t, float eps, int precision, void* stream) {
   (void)precision;
   if (!qkv || !out || batch <= 0 || nh <= 0) return fail(KD_EINVAL, "kd_attn_na2d_f32: bad arguments");
-  if (ks != NA_K) return fail(KD_EINVAL, "kd_attn_na2d_f32: kernel_size %d unsupported (only 7)", ks);
+  if (ks < 3 || ks > 13 || !(ks & 1)) return fail(KD_EINVAL, "kd_attn_na2d_f32: kernel_size %d unsupported (odd sizes 3 .. 13)", ks);
   if (H < ks || W < ks) return fail(KD_EINVAL, "kd_attn_na2d_f32: grid %dx%d smaller than the %dx%d neighbourhood", H, W, ks, ks);
   if (int e = check_prep(prep, scale_h, cos_t, sin_t, "kd_attn_na2d_f32")) return e;
   hipStream_t s = (hipStream_t)stream;
-  if (prep == 2) {        // operands stored split by the qkv projection: the round-3 core (LDS-DMA halo, transposing V reads)
+  if (prep == 2) {        // operands stored split by the qkv projection: the round-3 cores (LDS-DMA halo, transposing V reads), every kernel size
     int rc = 0;
-    if (!attn_na2d_x3_try(qkv, out, batch, H, W, nh, s, &rc)) return rc;
+    if (!attn_na2d_x3_try(qkv, out, batch, H, W, nh, ks, s, &rc)) return rc;
   }
+  // the round-1 core below (fp32 operands, or split-stored ones with option "attn_x3" = 0) is built for the size the shipped configs use
+  if (ks != NA_K)
+    return fail(KD_EINVAL, "kd_attn_na2d_f32: kernel_size %d needs split-stored operands (prep = 2, KdGemm.qkv_packed) and option attn_x3; "
+                           "fp32 operands: kernel_size 7 only", ks);
   NaArgs a{qkv, out, scale_h, cos_t, sin_t, batch, H, W, nh, eps, option("code_warm", KD_CODE_WARM_DEFAULT)};
   const long nb = (long)batch * nh * ((H + NA_TH - 1) / NA_TH) * ((W + NA_TW - 1) / NA_TW);
   char nm[64] = "attn_na2d";

@@ -1,6 +1,7 @@
 // Attention cores of the fp32-parity ("split3") mode in the round-2 bf16 shape (attn_bf16.hip), gfx950.
 //
-//   neighbourhood attention, kernel size 7 (natten na2d, image_transformer_v2.py:428), for qkv STORED SPLIT by the qkv projection
+//   neighbourhood attention, kernel sizes 3 .. 13 (natten na2d, image_transformer_v2.py:399-410,428; 7 is what the shipped configs use,
+//   3 / 5 / 9 run the same kernel with other constants, 11 / 13 a densely packed patch), for qkv STORED SPLIT by the qkv projection
 //   (KdGemm.qkv_packed, prep = 2 of kd_attn_na2d_f32): every 4 head dims are 16 bytes [hi: 4 x bf16][lo: 4 x bf16], q and k already
 //   cosine-sim-scaled and rotated.  Every product is hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation (per-product
 //   error <= ~2^-15), scores / softmax / accumulators fp32, out fp32.
@@ -25,13 +26,20 @@ using b16::u32x2;
 using b16::u32x4;
 
 constexpr int DH = 64;
-constexpr int KS = 7, NA_TH = 8, NA_TW = 16;
-constexpr int HR = NA_TH + KS - 1, HC = NA_TW + KS - 1;      // 14 x 22 key halo of an 8 x 16 query tile
-constexpr int PR = 4 + KS - 1;                               // 10 patch rows of a wave (4 x 8 queries), 16 keys wide
-constexpr int NKT = (PR * 16 + 31) / 32;                     // 5 key tiles of 32
-constexpr int ROWS = ((HR * HC - KS + 9 + 3) / 4) * 4;       // image rows (a patch may poke past the halo's last key), 4 per LDS-DMA instruction
+constexpr int NA_TH = 8, NA_TW = 16;
 constexpr int ROWB = 256;                                    // bytes of an image row: 64 head dims as 16 chunks [hi4 | lo4]
-constexpr int LDS = ROWS * ROWB;                             // 79 872 B: two workgroups per CU
+// geometry of kernel size KS (3 .. 9): a wave's 4 x 8 queries see a patch of (4 + KS - 1) rows x (8 + KS - 1) <= 16 columns
+template <int KS>
+struct NaGeo {
+  static constexpr int HR = NA_TH + KS - 1, HC = NA_TW + KS - 1;      // key halo of an 8 x 16 query tile (KS = 7: 14 x 22)
+  static constexpr int PR = 4 + KS - 1;                               // patch rows of a wave, 16 keys wide
+  static constexpr int NKT = (PR * 16 + 31) / 32;                     // key tiles of 32 (KS = 7: 5)
+  // image rows, 4 per LDS-DMA instruction: a patch may poke past the halo's last key -- the highest row a fragment read touches is
+  // (HR - 1) HC + (HC - (8 + KS - 1)) + 15 = HR HC - KS + 8
+  static constexpr int ROWS = ((HR * HC - KS + 9 + 3) / 4) * 4;
+  static constexpr int LDS = ROWS * ROWB;                             // KS = 7: 79 872 B, two workgroups per CU (3, 5 too; 9: one)
+  static_assert(8 + KS - 1 <= 16, "16-key patch rows");
+};
 
 struct NArgs {
   const float* qkv; float* out;
@@ -58,7 +66,10 @@ __device__ __forceinline__ u32x2 tr_read(const char* img, int addr) {
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 __device__ __forceinline__ float min3f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 
-__global__ __launch_bounds__(256, 2) void attn_na2d_x3_kernel(const NArgs a) {
+template <int KS>
+__global__ __launch_bounds__(256, NaGeo<KS>::LDS <= 80 * 1024 ? 2 : 1) void attn_na2d_x3_kernel(const NArgs a) {
+  using G = NaGeo<KS>;
+  constexpr int HR = G::HR, HC = G::HC, PR = G::PR, NKT = G::NKT, ROWS = G::ROWS;
   extern __shared__ __attribute__((aligned(16))) char img[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h2 = lane >> 5;
   const auto warm = code_warm_begin<10240>((int)blockIdx.x < a.warm && tid < 64);
@@ -253,6 +264,182 @@ __global__ __launch_bounds__(256, 2) void attn_na2d_x3_kernel(const NArgs a) {
   }
 }
 
+// ---- neighbourhood core, kernel sizes 11 and 13 (no shipped config uses them: the form that covers the reference's interface,
+// image_transformer_v2.py:399-410, not a tuned one) ----------------------------------------------------------------------------------------
+// The 4 x 8 query block of a wave now needs a patch of (4 + KS - 1) rows x (8 + KS - 1) = 18 / 20 columns: no power-of-two width any
+// more, so the patch is walked DENSELY as in attn_bf16.hip's form of these sizes: local key kl = 20 r + c (columns padded to 20, a
+// multiple of 4: the 4-key groups of the V^T reads never straddle two patch rows), tiles of 32 keys, every key's (row, column) by constant
+// division, validity per accumulator register from those.  One workgroup per CU (127 / 150 KiB of halo image: K and V still share it).
+template <int KS>
+struct NaWide {
+  static constexpr int HR = NA_TH + KS - 1, HC = NA_TW + KS - 1;
+  static constexpr int PR = 4 + KS - 1, PC = 20;                            // patch rows; padded patch width
+  static constexpr int NKT = (PR * PC + 31) / 32;
+  static constexpr int ROWS = ((HR * HC + 2 * PC + 3) / 4) * 4;             // slack: padded columns and the last tile's tail poke past the halo
+  static constexpr int LDS = ROWS * ROWB;
+  static_assert(8 + KS - 1 <= PC && LDS <= 160 * 1024, "patch width / LDS");
+};
+
+template <int KS>
+__global__ __launch_bounds__(256, 1) void attn_na2d_x3_wide_kernel(const NArgs a) {
+  using G = NaWide<KS>;
+  constexpr int HR = G::HR, HC = G::HC, PR = G::PR, PC = G::PC, NKT = G::NKT, ROWS = G::ROWS;
+  extern __shared__ __attribute__((aligned(16))) char img[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h2 = lane >> 5;
+  const auto warm = code_warm_begin<16384>((int)blockIdx.x < a.warm && tid < 64);
+  const int wy_ = wid >> 1, wx_ = wid & 1;
+  const int tiles_x = (a.W + NA_TW - 1) / NA_TW, tiles_y = (a.H + NA_TH - 1) / NA_TH;
+  int r = blockIdx.x;
+  const int tx = r % tiles_x; r /= tiles_x;
+  const int ty = r % tiles_y; r /= tiles_y;
+  const int head = r % a.nh, b = r / a.nh;
+  const int T = a.H * a.W;
+  const size_t row_bytes = (size_t)3 * a.nh * DH * 4;
+  const char* base = reinterpret_cast<const char*>(a.qkv) + (size_t)b * T * row_bytes + head * (DH * 4);
+  const int ty0 = ty * NA_TH, tx0 = tx * NA_TW;
+  const int hy0 = max(0, min(ty0 - KS / 2, a.H - HR)), hx0 = max(0, min(tx0 - KS / 2, a.W - HC));
+  // image row 4 pc + (lane >> 4) = halo position (row / HC, row % HC); rows past the halo (the slack) take a real token: outside every window
+  auto stage = [&](int part_bytes) {
+    for (int pc = wid; pc < ROWS / 4; pc += 4) {
+      const int row = 4 * pc + (lane >> 4);
+      const int ky = min(hy0 + row / HC, a.H - 1), kx = min(hx0 + row % HC, a.W - 1);
+      const char* src = base + (size_t)(unsigned)((ky * a.W + kx) * (int)row_bytes + (((lane & 15) ^ rsw(row)) << 4));
+      glds16(src + part_bytes, img + pc * 1024);
+    }
+  };
+  stage(a.nh * DH * 4);                                  // K
+  const int qy_raw = ty0 + 4 * wy_ + (l31 >> 3), qx_raw = tx0 + 8 * wx_ + (l31 & 7);
+  const bool q_ok = qy_raw < a.H && qx_raw < a.W;
+  const int qy = min(qy_raw, a.H - 1), qx = min(qx_raw, a.W - 1);
+  const int q_tok = qy * a.W + qx;
+  bf16x8 qh[4], ql[4];
+  {
+    const u32x4* qp = reinterpret_cast<const u32x4*>(base + (size_t)q_tok * row_bytes + 32 * h2);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const u32x4 c0 = qp[4 * st], c1 = qp[4 * st + 1];
+      qh[st] = __builtin_bit_cast(bf16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
+      ql[st] = __builtin_bit_cast(bf16x8, u32x4{c0[2], c0[3], c1[2], c1[3]});
+    }
+  }
+  const int wy = max(0, min(qy - KS / 2, a.H - KS)) - hy0, wx = max(0, min(qx - KS / 2, a.W - KS)) - hx0;
+  const int row_lo = min(max(0, min(min(ty0 + 4 * wy_, a.H - 1) - KS / 2, a.H - KS)) - hy0, HR - PR);
+  const int col_lo = min(max(0, min(min(tx0 + 8 * wx_, a.W - 1) - KS / 2, a.W - KS)) - hx0, HC - (8 + KS - 1));
+  const int korg = row_lo * HC + col_lo;
+  const int r0 = wy - row_lo, c0w = wx - col_lo;
+  auto img_row = [&](int kl) -> int { return min(korg + (kl / PC) * HC + (kl % PC), ROWS - 1); };     // image row of local key kl
+  KD_WAIT_VM(0);
+  code_warm_end(warm);
+  KD_BARRIER();
+
+  // ---- S^T = K Q^T, tile by tile: local key 32 t + l31 ----------------------------------------------------------------------------------
+  f32x16 S[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    const int kr = img_row(32 * t + l31);
+    const int ka = kr * ROWB + (((2 * h2) ^ rsw(kr)) << 4);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const u32x4 c0 = *reinterpret_cast<const u32x4*>(img + (ka ^ (st << 6)));
+      const u32x4 c1 = *reinterpret_cast<const u32x4*>(img + (ka ^ (st << 6) ^ 16));
+      const bf16x8 kh = __builtin_bit_cast(bf16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
+      const bf16x8 kl = __builtin_bit_cast(bf16x8, u32x4{c0[2], c0[3], c1[2], c1[3]});
+      S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[st], S[t], 0, 0, 0);
+      S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[st], S[t], 0, 0, 0);
+      S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[st], S[t], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  KD_BARRIER();                                          // every wave has its K fragments: the image is free
+  stage(2 * a.nh * DH * 4);                              // V, in flight behind the softmax
+
+  // ---- window mask (accumulator register i of tile t: local key 32 t + (i & 3) + 8 (i >> 2) + 4 h2) + softmax ----------------------------
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kl = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h2;
+      const int pr = kl / PC, pcn = kl % PC;
+      const bool valid = (unsigned)(pr - r0) < (unsigned)KS && (unsigned)(pcn - c0w) < (unsigned)KS && pr < PR;
+      S[t][i] = valid ? S[t][i] : -INFINITY;
+    }
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) m = max3f(m, S[t][i], S[t][i + 1]);
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float l;
+  {
+    constexpr float LOG2E = 1.4426950408889634f;
+    const f32x2 mb = {-m * LOG2E, -m * LOG2E};
+    f32x2 l2 = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const f32x2 x = __builtin_elementwise_fma(f32x2{S[t][i], S[t][i + 1]}, f32x2{LOG2E, LOG2E}, mb);
+        const f32x2 pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+        S[t][i] = pv.x;
+        S[t][i + 1] = pv.y;
+        l2 += pv;
+      }
+    l = l2.x + l2.y;
+  }
+  l += __shfl_xor(l, 32, 64);
+  KD_WAIT_VM(0);
+  KD_BARRIER();                                          // V image complete
+
+  // ---- O^T = V^T P^T: k-slots of lane-half h2 at step (t, u) are local keys 32 t + 16 u + 4 h2 + {0..3} and the same + 8 -- two 4-key
+  // groups, each inside one patch row; the probabilities are split step by step --------------------------------------------------------------
+  f32x16 O[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) O[e][i] = 0.f;
+  const int vsub = (lane & 15) >> 2;
+  const int vc = (lane & 3) + 4 * ((lane >> 4) & 1);
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      u32x4 phi, plo;
+      x3::split8(f32x4{S[t][8 * u], S[t][8 * u + 1], S[t][8 * u + 2], S[t][8 * u + 3]},
+                 f32x4{S[t][8 * u + 4], S[t][8 * u + 5], S[t][8 * u + 6], S[t][8 * u + 7]}, phi, plo);
+      const bf16x8 ph = __builtin_bit_cast(bf16x8, phi), pl = __builtin_bit_cast(bf16x8, plo);
+      const int k0 = 32 * t + 16 * u + 4 * h2;
+      const int ra = min(img_row(k0) + vsub, ROWS - 1), rb = min(img_row(k0 + 8) + vsub, ROWS - 1);
+      bf16x8 vh[2], vl[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int a0 = ra * ROWB + (((vc + 8 * e) ^ rsw(ra)) << 4), a1 = rb * ROWB + (((vc + 8 * e) ^ rsw(rb)) << 4);
+        const u32x2 h0 = tr_read(img, a0), h1 = tr_read(img, a1), l0 = tr_read(img, a0 + 8), l1 = tr_read(img, a1 + 8);
+        vh[e] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+        vl[e] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+      }
+      O[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[0], ph, O[0], 0, 0, 0);
+      O[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[1], ph, O[1], 0, 0, 0);
+      O[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[0], pl, O[0], 0, 0, 0);
+      O[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[1], pl, O[1], 0, 0, 0);
+      O[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[0], ph, O[0], 0, 0, 0);
+      O[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[1], ph, O[1], 0, 0, 0);
+    }
+  if (q_ok) {
+    const float inv = 1.0f / l;
+    float* op = a.out + ((size_t)b * T + q_tok) * (a.nh * DH) + head * DH;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(op + e * 32 + 8 * g + 4 * h2) =
+            f32x4{O[e][4 * g], O[e][4 * g + 1], O[e][4 * g + 2], O[e][4 * g + 3]} * inv;
+  }
+}
+
 // ---- global attention, T = 32 NT keys (64, 128, 256) -----------------------------------------------------------------------------------------
 // SDPA / flash-attn of the global level (image_transformer_v2.py:383,392) on the same operand scheme: one workgroup per (sample, head,
 // block of 32 QW queries), QW = min(4, NT) waves; ALL keys of the (sample, head) go through one [T][256 B] image, K first, then V (64 KiB at
@@ -431,20 +618,41 @@ int attn_global_x3_try(const float* qkv, float* out, int batch, int T, int nh, h
   return 0;
 }
 
-// Called by kd_attn_na2d_f32 (attn_f32.hip) for prep == 2 (operands stored split), kernel size 7.  Returns 1 if not taken.
-int attn_na2d_x3_try(const float* qkv, float* out, int batch, int H, int W, int nh, hipStream_t s, int* rc) {
+template <int KS, bool WIDE>
+static int launch_na(const x3a::NArgs& a, hipStream_t s) {
+  using namespace x3a;
+  constexpr int lds = WIDE ? NaWide<(WIDE ? KS : 11)>::LDS : NaGeo<(WIDE ? 7 : KS)>::LDS;
+  const void* kern;
+  if constexpr (WIDE) kern = reinterpret_cast<const void*>(attn_na2d_x3_wide_kernel<KS>);
+  else kern = reinterpret_cast<const void*>(attn_na2d_x3_kernel<KS>);
+  static LdsAttr attr_set;
+  attr_set.ensure(kern, lds);
+  const long nb = (long)a.batch * a.nh * ((a.H + NA_TH - 1) / NA_TH) * ((a.W + NA_TW - 1) / NA_TW);
+  char nm[64] = "attn_na2d_x3";
+  if (prof_on()) {
+    if (KS == 7) snprintf(nm, sizeof(nm), "attn_na2d_x3 %dx%d nh=%d", a.H, a.W, a.nh);
+    else snprintf(nm, sizeof(nm), "attn_na2d_x3 k%d %dx%d nh=%d", KS, a.H, a.W, a.nh);
+  }
+  LaunchScope prof(nm, 4.0 * a.batch * (double)a.H * a.W * a.nh * DH * KS * KS, 16.0 * a.batch * (double)a.H * a.W * a.nh * DH, s);
+  if constexpr (WIDE) hipLaunchKernelGGL(attn_na2d_x3_wide_kernel<KS>, dim3((unsigned)nb), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(attn_na2d_x3_kernel<KS>, dim3((unsigned)nb), dim3(256), lds, s, a);
+  return check_launch("kd_attn_na2d_f32(x3)");
+}
+
+// Called by kd_attn_na2d_f32 (attn_f32.hip) for prep == 2 (operands stored split), kernel sizes 3 .. 13 (odd).  Returns 1 if not taken.
+int attn_na2d_x3_try(const float* qkv, float* out, int batch, int H, int W, int nh, int ks, hipStream_t s, int* rc) {
   using namespace x3a;
   if (!option("attn_x3", 1)) return 1;
   NArgs a{qkv, out, batch, H, W, nh, option("code_warm", KD_CODE_WARM_DEFAULT)};
-  const long nb = (long)batch * nh * ((H + NA_TH - 1) / NA_TH) * ((W + NA_TW - 1) / NA_TW);
-  static LdsAttr attr_set;
-  attr_set.ensure(reinterpret_cast<const void*>(attn_na2d_x3_kernel), LDS);
-  char nm[64] = "attn_na2d_x3";
-  if (prof_on()) snprintf(nm, sizeof(nm), "attn_na2d_x3 %dx%d nh=%d", H, W, nh);
-  LaunchScope prof(nm, 4.0 * batch * (double)H * W * nh * DH * KS * KS, 16.0 * batch * (double)H * W * nh * DH, s);
-  hipLaunchKernelGGL(attn_na2d_x3_kernel, dim3((unsigned)nb), dim3(256), LDS, s, a);
-  *rc = check_launch("kd_attn_na2d_f32(x3)");
-  return 0;
+  switch (ks) {
+    case 3: *rc = launch_na<3, false>(a, s); return 0;
+    case 5: *rc = launch_na<5, false>(a, s); return 0;
+    case 7: *rc = launch_na<7, false>(a, s); return 0;
+    case 9: *rc = launch_na<9, false>(a, s); return 0;
+    case 11: *rc = launch_na<11, true>(a, s); return 0;
+    case 13: *rc = launch_na<13, true>(a, s); return 0;
+    default: return 1;
+  }
 }
 
 }  // namespace kd
