@@ -40,8 +40,8 @@ const char* kd_last_error(void);
  *                  "gemm_debug" (0; profiling ablations of benchmarks/: 1 no C stores, 2 no MFMA, 8 GEGLU without erf)
  *                  "x3" (1; 0 = the round-1 / round-2 kernels for KD_PREC_SPLIT3 projections) "x3_splits" (0 = cost model)
  *                  "x3_half" (1; 0 = one workgroup per CU for the K = 256 projections) "x3_res" (0; 1 = the A-stationary kernel for the K = 512
- *                  residual projection) "x3r" (1; gemm_x3r.hip for projections without a norm where the tiles fit one round of the chip; 0 = round-1
- *                  kernel, 2 = every eligible shape) "ffn_x3" (1; 0 = kd_ffn_f32_supported answers no) "ffn_x3_half" (1; 0 = one workgroup per CU
+ *                  residual projection) "x3r" (1; gemm_x3r.hip for projections without a norm in front, K >= 256; 0 = round-1
+ *                  kernel, 2 = every eligible shape) "x3r_lw" (1; 0 = staging requests inside the compute waves' K loop instead of loader waves) "ffn_x3" (1; 0 = kd_ffn_f32_supported answers no) "ffn_x3_half" (1; 0 = one workgroup per CU
  *                  at K = 128) "attn_x3" (1; 0 = the round-1 attention cores also for split-stored operands)
  *   bf16 kernels : "bf16_fast" (1; 0 = generic kernel only) "wstat" (1) "wstat_waves" (0 = per shape) "wstat_max_slices" (24)
  *                  "wstat_prefetch" (0; 1 next-chunk prefetch, 2 software-pipelined tiles) "astat_bf16" (1) "astat_splits" (0 = auto)

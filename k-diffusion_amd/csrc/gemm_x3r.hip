@@ -13,6 +13,14 @@
 //     wave's LDS strip as 64-byte row runs;
 //   * the merge gather (image_transformer_v2.py:586-595: a coarse token's row is its four fine tokens' rows side by side) is address
 //     arithmetic of the staging requests: a 32-k stage lies inside ONE fine token's row.
+//
+// Round 4: LOADER WAVES (template flag LW, option "x3r_lw", default on).  With the staging requests inside the K loop a wave spent more
+// time ISSUING its 8 LDS-DMA instructions per stage than on the stage's 24 MFMAs (1 640 clocks per stage against 768 of MFMA: a request
+// costs the issuing wave 60 - 180 clocks while the address path takes it, and nothing else of that wave issues meanwhile -- its MFMAs
+// included).  The kernel uses 200 of a SIMD's 512 registers per lane, so the workgroup can carry a SECOND wave per SIMD that does nothing
+// but staging: waves 4..7 issue the requests of row group (wave - 4) and their quarter of the W stage, count them in (vmcnt) and meet the
+// compute waves at the ring's one barrier per stage; waves 0..3 keep only ds_read / split / MFMA in their loop.  The matrix pipe no longer
+// waits for the address path (MI355X_MICROARCH.md, "Two waves per SIMD": the pairing that nets is matrix beside memory).
 #include "x3_common.h"
 
 namespace kd {
@@ -33,11 +41,13 @@ struct RArgs {
   unsigned long long* clk;             // kd_prof_clock_buffer: stamps of one workgroup's stage 8
 };
 
-template <int AMODE, int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_x3r_kernel(const RArgs p) {
+template <int AMODE, int EPI, bool LW, bool PROBE>
+__global__ __launch_bounds__(LW ? 512 : 256, LW ? 2 : 1) void gemm_x3r_kernel(const RArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wid_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = LW && wid_all >= 4;                          // (wave-uniform)
+  const int wid = LW ? (wid_all & 3) : wid_all;                    // row group: rows 32 wid .. + 31 of the tile (compute AND staging role)
   const auto warm = code_warm_begin<12 * 1024>((int)blockIdx.x < p.warm && tid < 64);
   const int n_tiles = p.N / 128;
   int tile;
@@ -50,6 +60,12 @@ __global__ __launch_bounds__(256, 1) void gemm_x3r_kernel(const RArgs p) {
   const int nt = tile % n_tiles, mt = tile / n_tiles;
   const int m0 = mt * 128, n0 = nt * 128;
   const int nk = p.nk;
+  const bool probe = PROBE && p.clk && blockIdx.x == (gridDim.x * 5) / 8 && tid == 0;
+  if (probe) p.clk[13] = __builtin_amdgcn_s_memtime();             // kernel entry
+  // extended time line (benchmarks/x3r_bench.py sets clk[15] to the magic value and hands over 32 + 3 * grid entries): entry / exit of EVERY
+  // workgroup's first compute wave and exit of its first loader wave, in 100 MHz ticks
+  const bool wide = PROBE && p.clk && p.clk[15] == 0x4b44ull && lane == 0;
+  if (wide && wid_all == 0) p.clk[32 + 3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 
   f32x16 acc[4];
   // ---- staging requests of one stage: 4 pieces of this wave's OWN 32 rows of A (piece i: rows 32 w + 8 i .. + 7, lane = 8 * row + slot),
@@ -88,8 +104,28 @@ __global__ __launch_bounds__(256, 1) void gemm_x3r_kernel(const RArgs p) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp + (size_t)s * STG + i * 1024),
                                        (__attribute__((address_space(3))) void*)(slot + ASTG + wid * 4096 + i * 1024), 16, 0, 0);
   };
+  if constexpr (LW) {
+    if (loader) {
+      // ---- loader wave: the staging requests of row group `wid` and its quarter of every W stage, nothing else ------------------------------
 #pragma unroll
-  for (int s = 0; s < PDIST; ++s) issue(s);
+      for (int s = 0; s < PDIST; ++s) issue(s);
+      wait_vm(8 * (PDIST - 1));
+      KD_BARRIER();                                                // stage 0 in (the compute waves' first barrier)
+      for (int s = 0; s < nk; ++s) {
+        // stage s + 1 in before the barrier in the middle of stage s; behind that barrier every compute wave is past stage s - 1,
+        // whose slot takes stage s + PDIST
+        wait_vm(8 * (PDIST - 2));
+        KD_BARRIER();
+        issue(s + PDIST);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the clamped tail requests still target this workgroup's LDS
+      if (wide && wid_all == 4) p.clk[32 + 3 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+      return;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < PDIST; ++s) issue(s);
+  }
   // KD_EPI_RESIDUAL: the accumulators start from R (C layout: lane (l31, lh), block j, register 4 g + e <-> row l31, column 32 j + 8 g + 4 lh + e)
   {
     const int rrow = min(m0 + wid * 32 + l31, p.M - 1);
@@ -120,30 +156,38 @@ __global__ __launch_bounds__(256, 1) void gemm_x3r_kernel(const RArgs p) {
   const int rt = wid * 32 + l31;
   const int a0 = rt * 128 + (((2 * lh) ^ ((rt >> 1) & 7)) << 4);   // c = 1: ^ 64; second half of the pair: ^ 16
   const int o0 = swz64(l31, lh), o1 = swz64(l31, 2 + lh);
-  // The K loop is software-pipelined by 16-k chunks, as in gemm_x3.hip: while the 12 MFMAs of a chunk run, the 10 fragment reads of the
-  // NEXT chunk are in flight (also across the stage boundary, whose wait + barrier sits in the MIDDLE of a stage) and its fp32 row pieces
-  // are split into hi / lo; the 8 staging requests of stage s + 3 are issued one by one between the MFMAs of the stage's second chunk.
+  // The K loop is software-pipelined by 16-k chunks: while the 12 MFMAs of a chunk run, the 10 fragment reads of the NEXT chunk (also
+  // across the stage boundary, whose wait + barrier sits in the MIDDLE of a stage) and the hi / lo split of its fp32 row pieces are
+  // spread over the gaps between them, one gap = one MFMA + at most 7 other instructions (an MFMA's issue shadow holds ~6:
+  // profiles/r03_issue_model.md).  Round 4: the loop body is ONE basic block (the time stamps are a template flag) and every split piece
+  // is pinned where it is written (empty asm) -- with the run-time `if (probe)` blocks inside the loop the compiler had sunk both 32-instruction
+  // split sequences behind the last MFMA of their chunk, ~130 exposed clocks each (benchmarks/x3r_bench.py time line: 1 500 clocks per stage).
   f32x4 xr[2][2];                        // raw row pieces of a chunk, [buffer][half]
-  bf16x8 wh[2][4], wl[2][4], ah[2], al[2];
-  auto read_chunk = [&](int slot, int c, int buf) {
+  bf16x8 wh[2][4], wl[2][4];
+  u32x4 ahu[2], alu[2];
+  auto read_a = [&](int slot, int c, int buf) {
     const char* st = smem + slot * STAGE;
     xr[buf][0] = *reinterpret_cast<const f32x4*>(st + (a0 ^ (c << 6)));
     xr[buf][1] = *reinterpret_cast<const f32x4*>(st + (a0 ^ (c << 6) ^ 16));
-    const char* wst = st + ASTG + (c ? o1 : o0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      wh[buf][j] = *reinterpret_cast<const bf16x8*>(wst + j * 32 * 64);
-      wl[buf][j] = *reinterpret_cast<const bf16x8*>(wst + IMG + j * 32 * 64);
-    }
   };
-  auto split_chunk = [&](int buf) {
-    u32x4 hi, lo;
-    split8(xr[buf][0], xr[buf][1], hi, lo);
-    ah[buf] = __builtin_bit_cast(bf16x8, hi);
-    al[buf] = __builtin_bit_cast(bf16x8, lo);
+  auto read_w = [&](int slot, int c, int buf, int j) {
+    const char* wst = smem + slot * STAGE + ASTG + (c ? o1 : o0) + j * 32 * 64;
+    wh[buf][j] = *reinterpret_cast<const bf16x8*>(wst);
+    wl[buf][j] = *reinterpret_cast<const bf16x8*>(wst + IMG);
+  };
+  // piece q of the split of buffer `buf`: row elements 2 q, 2 q + 1 of the lane's 8 -> one register of the hi and of the lo fragment
+  auto split_piece = [&](int buf, int q) {
+    const float a = xr[buf][q >> 1][2 * (q & 1)], b = xr[buf][q >> 1][2 * (q & 1) + 1];
+    unsigned h = pack_bf16(a, b);
+    asm volatile("" : "+v"(h));          // (one v_cvt_pk: the shifts below read ITS result instead of converting a second time)
+    unsigned l = pack_bf16(a - b16::bf_lo(h), b - b16::bf_hi(h));
+    asm volatile("" : "+v"(l));          // materialised HERE: not sunk towards its first use in the next chunk
+    ahu[buf][q] = h;
+    alu[buf][q] = l;
   };
   auto mm = [&](int buf, int j, int term) {
-    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 0 ? wl[buf][j] : wh[buf][j], term == 1 ? al[buf] : ah[buf], acc[j], 0, 0, 0);
+    const bf16x8 a = __builtin_bit_cast(bf16x8, term == 1 ? alu[buf] : ahu[buf]);
+    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 0 ? wl[buf][j] : wh[buf][j], a, acc[j], 0, 0, 0);
   };
   auto issue_one = [&](int s_, int i) {                            // piece i (0..3: A, 4..7: W) of stage s_'s requests
     const int s = min(s_, nk - 1);
@@ -163,69 +207,49 @@ __global__ __launch_bounds__(256, 1) void gemm_x3r_kernel(const RArgs p) {
                                        (__attribute__((address_space(3))) void*)(slot + ASTG + wid * 4096 + (i - 4) * 1024), 16, 0, 0);
     }
   };
-  wait_vm(8 * (PDIST - 1));
+#define KD_GAP() __builtin_amdgcn_sched_barrier(0)
+  // the 12 MFMAs of the chunk in buffers `cur`; the reads and the split of chunk (rslot, rc) into buffers `nxt`; in the form without loader
+  // waves the second chunk of a stage also carries the 8 staging requests of stage s + PDIST (`req` >= 0), one per gap
+  auto chunk = [&](int cur, int nxt, int rslot, int rc, int req) {
+    mm(cur, 0, 0); read_a(rslot, rc, nxt); KD_GAP();
+    mm(cur, 1, 0); read_w(rslot, rc, nxt, 0); KD_GAP();
+    mm(cur, 2, 0); read_w(rslot, rc, nxt, 1); if (!LW && req >= 0) issue_one(req, 0); KD_GAP();
+    mm(cur, 3, 0); read_w(rslot, rc, nxt, 2); if (!LW && req >= 0) issue_one(req, 1); KD_GAP();
+    mm(cur, 0, 1); read_w(rslot, rc, nxt, 3); if (!LW && req >= 0) issue_one(req, 2); KD_GAP();
+    mm(cur, 1, 1); if (!LW && req >= 0) issue_one(req, 3); KD_GAP();
+    mm(cur, 2, 1); split_piece(nxt, 0); if (!LW && req >= 0) issue_one(req, 4); KD_GAP();
+    mm(cur, 3, 1); split_piece(nxt, 1); if (!LW && req >= 0) issue_one(req, 5); KD_GAP();
+    mm(cur, 0, 2); split_piece(nxt, 2); if (!LW && req >= 0) issue_one(req, 6); KD_GAP();
+    mm(cur, 1, 2); split_piece(nxt, 3); if (!LW && req >= 0) issue_one(req, 7); KD_GAP();
+    mm(cur, 2, 2); KD_GAP();
+    mm(cur, 3, 2); KD_GAP();
+  };
+  if constexpr (!LW) wait_vm(8 * (PDIST - 1));
   KD_BARRIER();
-  read_chunk(0, 0, 0);
-  split_chunk(0);
-  const bool probe = p.clk && blockIdx.x == (gridDim.x * 5) / 8 && tid == 0;
+  read_a(0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) read_w(0, 0, 0, j);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split_piece(0, q);
   if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
   for (int s = 0; s < nk; ++s) {
     const int slot = s % NSTG, nslot = (s + 1) % NSTG;
-    if (probe && s == 8) p.clk[8] = __builtin_amdgcn_s_memtime();
-    // ---- chunk 0 of stage s (buffer 0); chunk 1's fragments are requested behind its first MFMA -----------------------------------------
-    mm(0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_chunk(slot, 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(0, 1, 0); mm(0, 2, 0); mm(0, 3, 0);
-    mm(0, 0, 1); mm(0, 1, 1); mm(0, 2, 1); mm(0, 3, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    split_chunk(1);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(0, 0, 2); mm(0, 1, 2); mm(0, 2, 2); mm(0, 3, 2);
-    __builtin_amdgcn_sched_barrier(0);
+    if (PROBE && probe && s == 8) p.clk[8] = __builtin_amdgcn_s_memtime();
+    // ---- chunk 0 of stage s (buffers 0); chunk 1's fragments and split in its gaps ---------------------------------------------------------
+    chunk(0, 1, slot, 1, -1);
     // ---- stage s + 1 in for every wave, everyone past stage s - 1 -------------------------------------------------------------------------
-    if (probe && s == 8) p.clk[9] = __builtin_amdgcn_s_memtime();
-    wait_vm(8 * (PDIST - 2));
-    if (probe && s == 8) p.clk[10] = __builtin_amdgcn_s_memtime();
+    if (PROBE && probe && s == 8) p.clk[9] = __builtin_amdgcn_s_memtime();
+    if constexpr (!LW) wait_vm(8 * (PDIST - 2));
+    if (PROBE && probe && s == 8) p.clk[10] = __builtin_amdgcn_s_memtime();
     KD_BARRIER();
-    if (probe && s == 8) p.clk[11] = __builtin_amdgcn_s_memtime();
-    // ---- chunk 1 of stage s (buffer 1); the next stage's first chunk behind its first MFMA; the requests of stage s + 3 in between -------
-    mm(1, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_chunk(nslot, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(1, 1, 0);
-    issue_one(s + PDIST, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(1, 2, 0);
-    issue_one(s + PDIST, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(1, 3, 0); mm(1, 0, 1);
-    issue_one(s + PDIST, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(1, 1, 1);
-    issue_one(s + PDIST, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(1, 2, 1); mm(1, 3, 1);
-    issue_one(s + PDIST, 4);
-    __builtin_amdgcn_sched_barrier(0);
-    split_chunk(0);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(1, 0, 2);
-    issue_one(s + PDIST, 5);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(1, 1, 2);
-    issue_one(s + PDIST, 6);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(1, 2, 2);
-    issue_one(s + PDIST, 7);
-    mm(1, 3, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (probe && s == 8) p.clk[12] = __builtin_amdgcn_s_memtime();
+    if (PROBE && probe && s == 8) p.clk[11] = __builtin_amdgcn_s_memtime();
+    // ---- chunk 1 of stage s (buffers 1); the next stage's first chunk in its gaps (and, without loader waves, the requests of stage s + 3) ---
+    chunk(1, 0, nslot, 0, s + PDIST);
+    if (PROBE && probe && s == 8) p.clk[12] = __builtin_amdgcn_s_memtime();
   }
+#undef KD_GAP
   if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)nk; }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the clamped tail requests still target this workgroup's LDS
+  if constexpr (!LW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail requests still target this workgroup's LDS
 
   // ---- store through the wave's strip: 16 rows x 64 bytes per instruction ----------------------------------------------------------------
   char* strip = smem + NSTG * STAGE + wid * 2048;
@@ -254,18 +278,27 @@ __global__ __launch_bounds__(256, 1) void gemm_x3r_kernel(const RArgs p) {
         if (st_ok[it]) *reinterpret_cast<f32x4*>(st_row[it] + 32 * j + 16 * hb) = o;
       }
     }
+  if (probe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.clk[14] = __builtin_amdgcn_s_memtime(); }      // stores out
+  if (wide && wid_all == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.clk[32 + 3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); }
 }
 
-template <int AMODE, int EPI>
-static int launch(const RArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {
-  auto kern = gemm_x3r_kernel<AMODE, EPI>;
+template <int AMODE, int EPI, bool LW, bool PROBE>
+static int launch_lw(const RArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {
+  auto kern = gemm_x3r_kernel<AMODE, EPI, LW, PROBE>;
   constexpr int LDS = NSTG * STAGE + 4 * 2048;
   static LdsAttr attr_set;
   attr_set.ensure(reinterpret_cast<const void*>(kern), LDS);
   const long tiles = (long)((a.M + 127) / 128) * (a.N / 128);
   LaunchScope prof(nm, flops, bytes, s);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), LDS, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(LW ? 512 : 256), LDS, s, a);
   return check_launch("kd_gemm_f32(x3 residual / merge)");
+}
+template <int AMODE, int EPI>
+static int launch(const RArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {
+  // (the in-kernel time stamps of kd_prof_clock_buffer are their own instantiation: run-time `if (probe)` blocks inside the K loop split
+  // it into several basic blocks, which the instruction scheduler does not cross)
+  if (a.clk) return option("x3r_lw", 1) ? launch_lw<AMODE, EPI, true, true>(a, nm, flops, bytes, s) : launch_lw<AMODE, EPI, false, true>(a, nm, flops, bytes, s);
+  return option("x3r_lw", 1) ? launch_lw<AMODE, EPI, true, false>(a, nm, flops, bytes, s) : launch_lw<AMODE, EPI, false, false>(a, nm, flops, bytes, s);
 }
 
 }  // namespace x3r
@@ -279,21 +312,15 @@ int gemm_x3r_try(const GemmP& d, hipStream_t s, int* rc) {
   if (d.a_mode != KD_A_PLAIN && d.a_mode != KD_A_MERGE2x2) return 1;
   if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_RESIDUAL) return 1;
   if ((d.K & 31) || (d.N & 127) || d.M < 512 || d.out_add != 0.f) return 1;
-  // One workgroup per CU (136 KiB of LDS): taken where the tiles fit ONE round of the chip -- the level-2 projections and the merge
-  // into level 2 (M = 8192 at batch 32: 47-52 vs 59-62 us, 22-24 vs 28, 33-37 vs 50-52 us).  With more tiles than CUs the round-1 kernel's
-  // two resident workgroups per CU win (level-1 out projection 31 vs 27 us, level-0 merge 45 vs 38 us: benchmarks/x3_bench.py).
-  // Option "x3r" = 2 takes every eligible shape (A/B runs).  (A TokenSplit + lerp epilogue on this kernel -- scatter as row bases of the
-  // store runs, skip requested ahead of the K loop -- was measured slower than the round-1 kernel's, 57.9 vs 53.8 and 44.6 vs 41.4 us, and
-  // was not kept.)
-  {
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    static int cached = 0;
-    if (!cached) { if (hipDeviceGetAttribute(&cached, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cached <= 0) cached = 256; }
-    cus = cached;
-    const long tiles = (long)((d.M + 127) / 128) * (d.N / 128);
-    if (mode != 2 && tiles > cus) return 1;
-  }
+  // One workgroup per CU (136 KiB of LDS).  Round 3 took only grids of at most one tile per CU (the level-2 projections and the merge into
+  // level 2); with the loader waves and the one-basic-block K loop of round 4 the kernel is level with or ahead of the round-1 tile kernel's
+  // two workgroups per CU on every shape with K >= 256 (benchmarks/x3r_bench.py, batch 32: merge into level 1 31 vs 35 us, level-1 out
+  // projection 26 vs 26, level-1 down projection 45 vs 60, level 2 19 / 39 / 27 vs 27 / 58 / 47 us), so it takes them all; at K = 128 (the
+  // level-0 out projection, 4 stages: the prologue and the store tail are most of a tile's time) the round-1 kernel stays ahead, 39 vs 41 us.
+  // Option "x3r" = 2 takes every eligible shape, 0 none (A/B runs).  (A TokenSplit + lerp epilogue on this kernel -- scatter as row bases of
+  // the store runs, skip requested ahead of the K loop -- was measured slower than the round-1 kernel's in round 3, 57.9 vs 53.8 and 44.6 vs
+  // 41.4 us, and was not kept.)
+  if (mode != 2 && d.K < 256) return 1;
   if (d.a_mode == KD_A_MERGE2x2 && ((d.K >> 2) & 31)) return 1;
   RArgs a{};
   a.A = d.A; a.Wp = reinterpret_cast<const char*>(d.Wp); a.C = d.C; a.R = d.R;

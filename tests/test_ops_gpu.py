@@ -853,9 +853,16 @@ def test_split3_token_merge_round3(KD, ops, monkeypatch, B, H, W, C, N):
     finally:
         nat.set_option("x3r", 1)
     assert relerr(y, old) < 1e-4
+    nat.set_option("x3r", 2)
+    nat.set_option("x3r_lw", 0)               # the form without loader waves: the same products in the same order
+    try:
+        assert torch.equal(ops.token_merge(g(x), g(w)), y)
+    finally:
+        nat.set_option("x3r", 1)
+        nat.set_option("x3r_lw", 1)
 
 
-@pytest.mark.parametrize("M,K,N", [(1024, 512, 512), (1000, 512, 512), (8192, 512, 512), (2048, 256, 256), (640, 512, 256)])
+@pytest.mark.parametrize("M,K,N", [(1024, 512, 512), (1000, 512, 512), (8192, 512, 512), (2048, 256, 256), (640, 512, 256), (4096, 1536, 512), (520, 768, 256)])
 def test_split3_residual_projection_round3(KD, ops, monkeypatch, M, K, N):
     """out = residual + A W^T (the projection behind the attention core) on the round-3 kernels (gemm_x3r.hip where the tiles fit one
     round of the chip; the accumulators start from the residual); full and ragged row panels, in place (out is the residual) and not,
@@ -872,7 +879,8 @@ def test_split3_residual_projection_round3(KD, ops, monkeypatch, M, K, N):
     ops.gemm(g(a), g(w), inplace, M=M, N=N, K=K, epi=nat.EPI_RESIDUAL, residual=inplace)
     assert torch.equal(inplace, out)
     # the same projection on the A-stationary kernel (option x3_res, K = 512) and on the round-1 tile kernel (x3r = 0)
-    for name, val, back in (("x3_res", 1, 0), ("x3r", 0, 1), ("x3r", 2, 1)):
+    # ... and with the staging requests inside the compute waves' K loop instead of on loader waves (round 4: x3r_lw = 0)
+    for name, val, back in (("x3_res", 1, 0), ("x3r", 0, 1), ("x3r", 2, 1), ("x3r_lw", 0, 1)):
         nat.set_option(name, val)
         try:
             old = torch.empty_like(out)
