@@ -73,23 +73,46 @@ for name, B, H, W, d, dff in LEVELS:
     if name != "L2":
         wm = (torch.randn(2 * d, 4 * d, generator=g) * (4 * d) ** -0.5).to(dev)
         shapes.append(("merge", B * T // 4, 2 * d, 4 * d, x, wm, None, True))
+    if name != "L2":
+        # TokenSplit back into this level (image_transformer_v2.py:610-621): coarse tokens [B, H/2, W/2, 2d] -> 4 d columns -> lerp with the skip
+        xc = torch.randn(B, H // 2, W // 2, 2 * d, generator=g).to(dev)
+        ws = (torch.randn(4 * d, 2 * d, generator=g) * (2 * d) ** -0.5).to(dev)
+        skip = torch.randn(B, H, W, d, generator=g).to(dev)
+        facs = torch.tensor([0.37]).to(dev)
+        shapes.append(("split", B * T // 4, 4 * d, 2 * d, xc, ws, skip, "split"))
     for what, M_, N_, K_, a_, w_, r_, mg in shapes:
         outb = torch.empty(M_, N_, device=dev)
-        if mg:
+        if mg == "split":
+            outs = torch.empty_like(skip)
+            f = lambda: ops.token_split_lerp(xc, ws, skip, facs, out=outs)  # noqa: E731
+            fac = 0.37
+            rows = torch.randperm(M_, generator=g)[:256]
+            y = (xc.reshape(M_, K_)[rows.to(dev)].double() @ ws.double().T).view(-1, 2, 2, d)          # [rows, nh, nw, e]
+            bb, rr = rows // ((H // 2) * (W // 2)), rows % ((H // 2) * (W // 2))
+            hh, wwc = (rr // (W // 2)).to(dev), (rr % (W // 2)).to(dev)
+            bb = bb.to(dev)
+            sk = torch.stack([torch.stack([skip[bb, 2 * hh + i, 2 * wwc + j] for j in range(2)], 1) for i in range(2)], 1).double()
+            ref_split = sk + fac * (y - sk)
+
+            def check_split():
+                got = torch.stack([torch.stack([outs[bb, 2 * hh + i, 2 * wwc + j] for j in range(2)], 1) for i in range(2)], 1).double()
+                return float((got - ref_split).abs().max() / ref_split.abs().max())
+        elif mg:
             f = lambda: ops.gemm(a_, w_, outb, M=M_, N=N_, K=K_, a_mode=nat.A_MERGE2x2, grid=(H // 2, W // 2))  # noqa: E731
             a2 = a_.view(B, H // 2, 2, W // 2, 2, d).permute(0, 1, 3, 2, 4, 5).reshape(M_, K_)
         else:
             f = lambda: ops.gemm(a_, w_, outb, M=M_, N=N_, K=K_, epi=nat.EPI_RESIDUAL, residual=r_)  # noqa: E731
             a2 = a_.reshape(M_, K_)
-        rows = torch.randperm(M_, generator=g)[:256].to(dev)            # fp64 check on a row sample
-        ref = a2[rows].double() @ w_.double().T + (r_.reshape(M_, N_)[rows].double() if r_ is not None else 0)
+        if mg != "split":
+            rows = torch.randperm(M_, generator=g)[:256].to(dev)            # fp64 check on a row sample
+            ref = a2[rows].double() @ w_.double().T + (r_.reshape(M_, N_)[rows].double() if r_ is not None else 0)
         line = f"{name} {what:8s} M={M_:6d} N={N_:4d} K={K_:4d} tiles={-(-M_ // 128) * (N_ // 128):5d}"
         tl = ""
         for label, x3r, lw in (("loader waves", 2, 1), ("in-loop requests", 2, 0), ("round-1 tile kernel", 0, 0)):
             nat.set_option("x3r", x3r)
             nat.set_option("x3r_lw", lw)
             us = timed(f)
-            err = float(((outb[rows].double() - ref).abs().max() / ref.abs().max()))
+            err = check_split() if mg == "split" else float(((outb[rows].double() - ref).abs().max() / ref.abs().max()))
             line += f" | {label}: {us:6.1f} us ({6.0 * M_ * N_ * K_ / us * 1e-6 / 2500:.2f} of peak, err {err:.1e})"
             assert err < 1e-4, (name, what, label, err)
             if x3r:

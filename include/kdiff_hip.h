@@ -41,11 +41,12 @@ const char* kd_last_error(void);
  *                  "x3" (1; 0 = the round-1 / round-2 kernels for KD_PREC_SPLIT3 projections) "x3_splits" (0 = cost model)
  *                  "x3_half" (1; 0 = one workgroup per CU for the K = 256 projections) "x3_res" (0; 1 = the A-stationary kernel for the K = 512
  *                  residual projection) "x3r" (1; gemm_x3r.hip for projections without a norm in front, K >= 256; 0 = round-1
- *                  kernel, 2 = every eligible shape) "x3r_lw" (1; 0 = staging requests inside the compute waves' K loop instead of loader waves) "ffn_x3" (1; 0 = kd_ffn_f32_supported answers no) "ffn_x3_half" (1; 0 = one workgroup per CU
+ *                  kernel, 2 = every eligible shape) "x3r_lw" (1; 0 = staging requests inside the compute waves' K loop instead of loader waves)
+ *                  "x3r_split" (1; 0 = TokenSplit + lerp on the round-1 tile kernel) "ffn_x3" (1; 0 = kd_ffn_f32_supported answers no) "ffn_x3_half" (1; 0 = one workgroup per CU
  *                  at K = 128) "attn_x3" (1; 0 = the round-1 attention cores also for split-stored operands)
  *   bf16 kernels : "bf16_fast" (1; 0 = generic kernel only) "wstat" (1) "wstat_waves" (0 = per shape) "wstat_max_slices" (24)
  *                  "wstat_prefetch" (0; 1 next-chunk prefetch, 2 software-pipelined tiles) "astat_bf16" (1) "astat_splits" (0 = auto)
- *                  "tiled_bm" (0 = auto, 128, 256) "attn_global_qw" (8) "patch_fast" (1; 0 = patch-in / patch-out through the generic kernel)
+ *                  "tiled_bm" (0 = auto, 128, 256) "tiled_lw" (1; 0 = no loader waves in the tiled kernel at one tile per CU) "attn_global_qw" (8) "patch_fast" (1; 0 = patch-in / patch-out through the generic kernel)
  *                  "ffn_fused" (1; 0 = kd_ffn_bf16_supported answers no) "ffn_fused_256" (0)
  *                  "code_warm" (8: the first wave of that many workgroups of a launch -- one per XCD -- reads the kernel's own code
  *                  range into L2 at entry, so that a kernel that has not run for a while does not walk its code through one

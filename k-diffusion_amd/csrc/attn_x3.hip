@@ -19,6 +19,7 @@
 #include "x3_common.h"
 
 namespace kd {
+namespace x3 { extern unsigned long long* g_clk; }      // gemm_x3.hip (kd_prof_clock_buffer)
 namespace x3a {
 
 using b16::bf16x8;
@@ -45,6 +46,7 @@ struct NArgs {
   const float* qkv; float* out;
   int batch, H, W, nh;
   int warm;
+  unsigned long long* clk;       // kd_prof_clock_buffer: per-workgroup entry / exit stamps (x3_common.h: wg_stamp_begin)
 };
 
 #define KD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -53,9 +55,12 @@ __device__ __forceinline__ void glds16(const void* src, void* dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
 
-// chunk c (0..15) of image row r sits at slot c ^ rsw(r).  rsw swaps the two 2-bit fields of r & 15: 16 consecutive rows take 16
-// different slots for one chunk (the ds_read_b128 of a K fragment: 16 lanes, 16 rows), and FOUR consecutive rows differ in slot bits
+// chunk c (0..15) of an image row sits at slot c ^ rsw(r), r = the row's index in the global core and in the 11 / 13 neighbourhood form, its
+// halo COLUMN in the neighbourhood kernel (sizes 3 .. 9).  rsw swaps the two 2-bit fields of r & 15: 16 consecutive rows (columns) take 16
+// different slots for one chunk (the ds_read_b128 of a K fragment: 16 lanes, 16 rows), and FOUR consecutive ones differ in slot bits
 // 2-3, so the 4 rows x 4 chunks of a ds_read_b64_tr_b16 group land in 16 different slots.  rsw(r + 8) = rsw(r) ^ 2.
+// (Keys past the halo's last column -- a patch may poke 1 - 2 keys over -- then read another chunk of a real row: finite values, always
+// masked.)
 __device__ __forceinline__ int rsw(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 using s16x4 = short __attribute__((ext_vector_type(4)));
@@ -73,6 +78,7 @@ __global__ __launch_bounds__(256, NaGeo<KS>::LDS <= 80 * 1024 ? 2 : 1) void attn
   extern __shared__ __attribute__((aligned(16))) char img[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h2 = lane >> 5;
   const auto warm = code_warm_begin<10240>((int)blockIdx.x < a.warm && tid < 64);
+  const x3::WgStamp wgs = x3::wg_stamp_begin(a.clk);
   const int wy_ = wid >> 1, wx_ = wid & 1;
   const int tiles_x = (a.W + NA_TW - 1) / NA_TW, tiles_y = (a.H + NA_TH - 1) / NA_TH;
   int r;
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256, NaGeo<KS>::LDS <= 80 * 1024 ? 2 : 1) void attn
     int y = row / HC, x = row % HC;
     for (int pc = wid; pc < ROWS / 4; pc += 4) {
       const int ky = min(hy0 + y, a.H - 1), kx = min(hx0 + x, a.W - 1);
-      const char* src = base + (size_t)(unsigned)((ky * a.W + kx) * (int)row_bytes + (((lane & 15) ^ rsw(row)) << 4));
+      const char* src = base + (size_t)(unsigned)((ky * a.W + kx) * (int)row_bytes + (((lane & 15) ^ rsw(x)) << 4));
       glds16(src + part_bytes, img + pc * 1024);
       row += 16; x += 16;
       if (x >= HC) { x -= HC; ++y; }
@@ -109,13 +115,18 @@ __global__ __launch_bounds__(256, NaGeo<KS>::LDS <= 80 * 1024 ? 2 : 1) void attn
   const bool q_ok = qy_raw < a.H && qx_raw < a.W;
   const int qy = min(qy_raw, a.H - 1), qx = min(qx_raw, a.W - 1);
   const int q_tok = qy * a.W + qx;
-  bf16x8 qh[4], ql[4];
+  // Q operands per k-step: a stored chunk is [hi4 | lo4] of 4 head dims.  A K chunk goes into the MFMA AS IT IS READ (k-slots hi0..3, lo0..3 of
+  // its 4 dims) against qa = [qhi0..3, qhi0..3] of the same dims: K_hi Q_hi + K_lo Q_hi of those dims in one instruction, no regrouping of the
+  // K registers; the third term K_hi Q_lo takes the hi quads of both chunks (the only regrouped fragment: 4 moves per tile and step instead
+  // of 8) against ql = [qlo of chunk 0, qlo of chunk 1].
+  bf16x8 qa[4][2], ql[4];
   {
     const u32x4* qp = reinterpret_cast<const u32x4*>(base + (size_t)q_tok * row_bytes + 32 * h2);
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       const u32x4 c0 = qp[4 * st], c1 = qp[4 * st + 1];
-      qh[st] = __builtin_bit_cast(bf16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
+      qa[st][0] = __builtin_bit_cast(bf16x8, u32x4{c0[0], c0[1], c0[0], c0[1]});
+      qa[st][1] = __builtin_bit_cast(bf16x8, u32x4{c1[0], c1[1], c1[0], c1[1]});
       ql[st] = __builtin_bit_cast(bf16x8, u32x4{c0[2], c0[3], c1[2], c1[3]});
     }
   }
@@ -145,32 +156,33 @@ __global__ __launch_bounds__(256, NaGeo<KS>::LDS <= 80 * 1024 ? 2 : 1) void attn
   for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
-  int ka[NKT];
-  {
-    const int kr0 = korg + (l31 >> 4) * HC + (l31 & 15);
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      const int kr = kr0 + 2 * t * HC;
-      ka[t] = kr * ROWB + (((2 * h2) ^ rsw(kr)) << 4);      // chunk 2 h2 of the row; chunk + 1: ^ 16; step st: ^ (st << 6)
-    }
-  }
+  // (round 4: the chunk swizzle of an image row is a function of its halo COLUMN, not of its row index: a lane's column is the same in
+  // every patch row, so its fragment addresses differ from tile to tile by a compile-time constant -- immediate offsets of the LDS reads
+  // instead of ~250 address instructions per wave)
+  // The XOR part of an address (chunk pair of the k-step: bits 6 - 7, second chunk of the pair: bit 4) touches only bits below 8 and the tile
+  // stride is a multiple of 256: (ka0 + t * stride) ^ m == (ka0 ^ m) + t * stride, so ONE base register per (k-step, chunk) serves every tile.
+  const int kr0 = korg + (l31 >> 4) * HC + (l31 & 15);
+  const int ka0 = kr0 * ROWB + (((2 * h2) ^ rsw(col_lo + (l31 & 15))) << 4);      // chunk 2 h2 of the row; chunk + 1: ^ 16; step st: ^ (st << 6)
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
-    bf16x8 kh[NKT], kl[NKT];
+    bf16x8 kc0[NKT], kc1[NKT], kh[NKT];
+    const char* k0p = img + (ka0 ^ (st << 6));
+    const char* k1p = img + (ka0 ^ (st << 6) ^ 16);
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
-      const u32x4 c0 = *reinterpret_cast<const u32x4*>(img + (ka[t] ^ (st << 6)));
-      const u32x4 c1 = *reinterpret_cast<const u32x4*>(img + (ka[t] ^ (st << 6) ^ 16));
+      const u32x4 c0 = *reinterpret_cast<const u32x4*>(k0p + t * (2 * HC * ROWB));
+      const u32x4 c1 = *reinterpret_cast<const u32x4*>(k1p + t * (2 * HC * ROWB));
+      kc0[t] = __builtin_bit_cast(bf16x8, c0);
+      kc1[t] = __builtin_bit_cast(bf16x8, c1);
       kh[t] = __builtin_bit_cast(bf16x8, u32x4{c0[0], c0[1], c1[0], c1[1]});
-      kl[t] = __builtin_bit_cast(bf16x8, u32x4{c0[2], c0[3], c1[2], c1[3]});
     }
     // term-major: consecutive MFMAs go to different key tiles
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[t], qh[st], S[t], 0, 0, 0);
+    for (int t = 0; t < NKT; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc0[t], qa[st][0], S[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc1[t], qa[st][1], S[t], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < NKT; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[t], ql[st], S[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[t], qh[st], S[t], 0, 0, 0);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   KD_BARRIER();                                          // every wave has its K fragments: the image is free
@@ -230,16 +242,19 @@ __global__ __launch_bounds__(256, NaGeo<KS>::LDS <= 80 * 1024 ? 2 : 1) void attn
     for (int i = 0; i < 16; ++i) O[e][i] = 0.f;
   const int vr0 = korg + 4 * h2 + ((lane & 15) >> 2);
   const int vc = (lane & 3) + 4 * ((lane >> 4) & 1);
+  const int va0 = vr0 * ROWB + ((vc ^ rsw(col_lo + 4 * h2 + ((lane & 15) >> 2))) << 4);
+  // four base addresses (feature block e, rows / rows + 8): block e = 1: ^ 128; rows + 8: (^ 32) + 8 rows; the step (t, u) and the lo quad (+ 8)
+  // are immediate offsets (the same bits-below-8 argument as for the K fragments)
+  const int vb[2][2] = {{va0, (va0 ^ 32) + 8 * ROWB}, {va0 ^ 128, ((va0 ^ 128) ^ 32) + 8 * ROWB}};
 #pragma unroll
   for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int vr = vr0 + (2 * t + u) * HC;
-      const int va = vr * ROWB + ((vc ^ rsw(vr)) << 4);          // rows + 8: (^ 32) + 8 rows; block e = 1: ^ 128; lo quad: + 8
+      constexpr int step = HC * ROWB;
       bf16x8 vh[2], vl[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int a0 = va ^ (e << 7), a1 = (a0 ^ 32) + 8 * ROWB;
+        const int a0 = vb[e][0] + (2 * t + u) * step, a1 = vb[e][1] + (2 * t + u) * step;
         const u32x2 h0 = tr_read(img, a0), h1 = tr_read(img, a1), l0 = tr_read(img, a0 + 8), l1 = tr_read(img, a1 + 8);
         vh[e] = __builtin_bit_cast(bf16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
         vl[e] = __builtin_bit_cast(bf16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
@@ -262,6 +277,7 @@ __global__ __launch_bounds__(256, NaGeo<KS>::LDS <= 80 * 1024 ? 2 : 1) void attn
         *reinterpret_cast<f32x4*>(op + e * 32 + 8 * g + 4 * h2) =
             f32x4{O[e][4 * g], O[e][4 * g + 1], O[e][4 * g + 2], O[e][4 * g + 3]} * inv;
   }
+  x3::wg_stamp_end(wgs);
 }
 
 // ---- neighbourhood core, kernel sizes 11 and 13 (no shipped config uses them: the form that covers the reference's interface,
@@ -451,6 +467,7 @@ struct GArgs {
   const float* qkv; float* out;
   int batch, T, nh;
   int warm;
+  unsigned long long* clk;
 };
 
 template <int NT>
@@ -459,6 +476,7 @@ __global__ __launch_bounds__((NT < 4 ? NT : 4) * 64, 2) void attn_global_x3_kern
   extern __shared__ __attribute__((aligned(16))) char img[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h2 = lane >> 5;
   const auto warm = code_warm_begin<10240>((int)blockIdx.x < a.warm && tid < 64);
+  const x3::WgStamp wgs = x3::wg_stamp_begin(a.clk);
   int r;
   {   // XCD-aware order: the query blocks of one (sample, head) -- same K, V -- run on ONE L2
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
@@ -593,6 +611,7 @@ __global__ __launch_bounds__((NT < 4 ? NT : 4) * 64, 2) void attn_global_x3_kern
         *reinterpret_cast<f32x4*>(op + e * 32 + 8 * g + 4 * h2) =
             f32x4{O[e][4 * g], O[e][4 * g + 1], O[e][4 * g + 2], O[e][4 * g + 3]} * inv;
   }
+  x3::wg_stamp_end(wgs);
 }
 
 template <int NT>
@@ -613,7 +632,7 @@ static int launch_global(const GArgs& a, hipStream_t s) {
 int attn_global_x3_try(const float* qkv, float* out, int batch, int T, int nh, hipStream_t s, int* rc) {
   using namespace x3a;
   if (!option("attn_x3", 1) || (T != 64 && T != 128 && T != 256)) return 1;
-  GArgs a{qkv, out, batch, T, nh, option("code_warm", KD_CODE_WARM_DEFAULT)};
+  GArgs a{qkv, out, batch, T, nh, option("code_warm", KD_CODE_WARM_DEFAULT), x3::g_clk};
   *rc = T == 256 ? launch_global<8>(a, s) : (T == 128 ? launch_global<4>(a, s) : launch_global<2>(a, s));
   return 0;
 }
@@ -643,7 +662,7 @@ static int launch_na(const x3a::NArgs& a, hipStream_t s) {
 int attn_na2d_x3_try(const float* qkv, float* out, int batch, int H, int W, int nh, int ks, hipStream_t s, int* rc) {
   using namespace x3a;
   if (!option("attn_x3", 1)) return 1;
-  NArgs a{qkv, out, batch, H, W, nh, option("code_warm", KD_CODE_WARM_DEFAULT)};
+  NArgs a{qkv, out, batch, H, W, nh, option("code_warm", KD_CODE_WARM_DEFAULT), x3::g_clk};
   switch (ks) {
     case 3: *rc = launch_na<3, false>(a, s); return 0;
     case 5: *rc = launch_na<5, false>(a, s); return 0;

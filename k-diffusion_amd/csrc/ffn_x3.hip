@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
   const int T = p.n_tiles, total = T * UNIT;
   const bool probe = p.clk && blockIdx.x == (gridDim.x * 5) / 8 && tid == 0;      // a workgroup of a later round: the chip under load
   if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
+  const WgStamp wgs = wg_stamp_begin(p.clk);
 
   // The weight stream: tile t contributes UNIT stages -- u < NKU: up block (t, u); else down block (n-tile (u - NKU) / 2, k-step
   // 2 t + (u - NKU) % 2).  Stage (t, u) sits in ring slot (t UNIT + u) % NSTG.  Requests past the end re-request the last stage (uniform
@@ -499,6 +500,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
     }
   });
   if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)total; }
+  wg_stamp_end(wgs);
 }
 
 
@@ -549,6 +551,7 @@ __global__ __launch_bounds__(256, 2) void ffn_x3h_kernel(const FArgs3 p) {
   const int T2 = 2 * p.n_tiles;                                 // half tiles
   const bool probe = p.clk && blockIdx.x == (gridDim.x * 5) / 8 && tid == 0;
   if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
+  const WgStamp wgs = wg_stamp_begin(p.clk);
 
   // stage (th, u): u < 2: sub-stages 2 u, 2 u + 1 of half tile th's up rows (piece j: sub-stage j >> 1, hi / lo image j & 1: this wave's
   // KiB of that 4 KiB run); u == 2: the down block of k-step th (this wave's 4 KiB of it).  Requests past the end repeat the last stage.
@@ -948,6 +951,7 @@ __global__ __launch_bounds__(256, 2) void ffn_x3h_kernel(const FArgs3 p) {
     }
   });
   if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)(T2 * UNIT); }
+  wg_stamp_end(wgs);
 }
 
 extern unsigned long long* g_clk;      // gemm_x3.hip (kd_prof_clock_buffer)

@@ -410,13 +410,21 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {
 
 // DEEP (BMT = 1 only): 4-slot ring, one workgroup per CU -- for grids of at most one tile per CU (the level-2 shapes: 8192 rows),
 // where the second workgroup of the 2-slot form does not exist and every K step would wait a full L2 round trip for its blocks.
-template <int AMODE, int EPI, int BMT, bool DEEP = false>
-__global__ __launch_bounds__(256 * BMT, (BMT == 1 && !DEEP) ? 2 : 1) void gemm_tiled_kernel(const TArgs p) {
+// LW (round 4; BMT = 1, DEEP ring, one workgroup per CU): LOADER WAVES as in csrc/gemm_x3r.hip.  The level-2 shapes (8192 rows: one tile per
+// CU) ran ~1 800 clocks per 64-wide K step against 512 of MFMA: every wave issued its 8 LDS-DMA requests of the next step in one burst behind
+// the barrier, and a wave that is issuing requests issues nothing else.  The kernel needs 114 - 178 of a SIMD's 512 registers per lane, so the
+// workgroup carries four more waves that do only the staging (requests, counted vmcnt, the step's barrier); the compute waves' K loop is
+// ds_read + MFMA + the one barrier per step.
+template <int AMODE, int EPI, int BMT, bool DEEP = false, bool LW = false>
+__global__ __launch_bounds__(LW ? 512 : 256 * BMT, (BMT == 1 && (!DEEP || LW)) ? 2 : 1) void gemm_tiled_kernel(const TArgs p) {
+  static_assert(!LW || (BMT == 1 && DEEP), "loader waves: 128-row tiles, 4-slot ring");
   constexpr int NWV = 4 * BMT, BMR = 128 * BMT;
   constexpr int A_IMG = BMR * 128, STG = A_IMG + WBLK, NSTG = BMT == 1 ? (DEEP ? 4 : 2) : 3;
-  constexpr int WPC = 16 / NWV;                      // weight pieces (1 KiB) per wave per step
+  constexpr int WPC = 16 / NWV;                      // weight pieces (1 KiB) per staging wave per step
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wid_all = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
+  const bool loader = LW && wid_all >= NWV;          // (wave-uniform)
+  const int wid = LW ? (wid_all & (NWV - 1)) : wid_all;      // compute role: position in the tile; staging role: which pieces
   const auto warm = code_warm_begin<(EPI == KD_EPI_SPLIT_LERP ? 6 : 4) * 1024>((int)blockIdx.x < p.warm && tid < 64);
   const int wc = wid & 1, wr = wid >> 1;
   int tile;
@@ -499,10 +507,70 @@ __global__ __launch_bounds__(256 * BMT, (BMT == 1 && !DEEP) ? 2 : 1) void gemm_t
       }
     }
   }
+  if constexpr (LW) {
+    // The step's barrier sits in the MIDDLE of the step (as in the split3 kernels): behind it step kt + 1 is in LDS and everyone is past
+    // step kt - 1, so the compute waves read the next step's first fragments during the last MFMAs of this one -- no LDS round trip is
+    // exposed behind a barrier -- while step kt + 2 (requested one barrier earlier) has two more half steps to land.
+    if (loader) {
+      // ---- loader wave: the requests of its 4 activation pieces and its quarter of the weight block of every step, nothing else ----------
 #pragma unroll
-  for (int kt = 0; kt < NSTG - 1; ++kt)
-    if (kt < nk) issue(kt);
-  for (int kt = 0; kt < nk; ++kt) {
+      for (int kt = 0; kt < NSTG - 1; ++kt)
+        if (kt < nk) issue(kt);
+      wait_vm_dyn((4 + WPC) * min(NSTG - 2, nk - 1));            // step 0 in
+      KD_BARRIER();
+      for (int kt = 0; kt < nk; ++kt) {
+        wait_vm_dyn(kt + 2 <= nk - 1 ? 4 + WPC : 0);              // step kt + 1 in; step kt + 2 may stay in flight
+        KD_BARRIER();                                            // mid step kt: the compute waves are done with step kt - 1, whose slot takes step kt + 3
+        if (kt + NSTG - 1 < nk) issue(kt + NSTG - 1);
+      }
+      return;                                                    // (every request was waited for: the last wait is vmcnt(0))
+    }
+    const char* ab0 = smem + (wr * 64) * 128;
+    const char* wb0 = smem + A_IMG + (wc * 64) * 128;
+    bf16x8 af[2][2], wf[2][2];
+    auto read_chunk = [&](int kt, int cc, int buf) {
+      const int so = (kt % NSTG) * STG;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        af[buf][u] = *reinterpret_cast<const bf16x8*>(ab0 + so + u * 32 * 128 + off4[cc]);
+        wf[buf][u] = *reinterpret_cast<const bf16x8*>(wb0 + so + u * 32 * 128 + off4[cc]);
+      }
+    };
+    auto mma = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[buf][i], af[buf][j], acc[i][j], 0, 0, 0);
+    };
+    KD_BARRIER();                                                // step 0 in
+    read_chunk(0, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      read_chunk(kt, 1, 1);
+      mma(0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_chunk(kt, 2, 0);
+      mma(1);
+      __builtin_amdgcn_sched_barrier(0);
+      KD_BARRIER();                                              // step kt + 1 in; everyone past step kt - 1
+      if (HAS_R && kt == max(nk - 2, 0)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) load_block_raw(p.R + roff[i][j], rraw[i][j], lh);
+      }
+      read_chunk(kt, 3, 1);
+      mma(0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_chunk(min(kt + 1, nk - 1), 0, 0);                      // (past the end: a slot nobody refills any more; never used)
+      mma(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#pragma unroll
+    for (int kt = 0; kt < NSTG - 1; ++kt)
+      if (kt < nk) issue(kt);
+  }
+  for (int kt = 0; !LW && kt < nk; ++kt) {
     wait_vm_dyn((4 + WPC) * min(NSTG - 2, nk - 1 - kt));      // the steps requested after kt may stay in flight
     KD_BARRIER();                 // every wave's pieces of step kt are in; everyone is done reading the slot refilled next
     if (kt + NSTG - 1 < nk) issue(kt + NSTG - 1);
@@ -584,15 +652,15 @@ __global__ __launch_bounds__(256 * BMT, (BMT == 1 && !DEEP) ? 2 : 1) void gemm_t
   }
 }
 
-template <int AMODE, int EPI, int BMT, bool DEEP = false>
+template <int AMODE, int EPI, int BMT, bool DEEP = false, bool LW = false>
 static int launch_tiled(const TArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {
-  auto kern = gemm_tiled_kernel<AMODE, EPI, BMT, DEEP>;
+  auto kern = gemm_tiled_kernel<AMODE, EPI, BMT, DEEP, LW>;
   constexpr int LDS = (BMT == 1 ? (DEEP ? 4 : 2) : 3) * (128 * BMT * 128 + WBLK);
   static LdsAttr attr_set;
   attr_set.ensure(reinterpret_cast<const void*>(kern), LDS);
   const long tiles = (long)((a.M + 128 * BMT - 1) / (128 * BMT)) * a.n_tiles_n;
   LaunchScope prof(nm, flops, bytes, s);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256 * BMT), LDS, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(LW ? 512 : 256 * BMT), LDS, s, a);
   return check_launch("kd_gemm_bf16(tiled)");
 }
 
@@ -620,10 +688,13 @@ int gemm_tiled_try(const KdGemm& d, hipStream_t s, int* rc) {
   // 4-slot ring for grids of at most one tile per CU: measured no better than the 2-slot form (level-2 shapes 10.2 vs 9.5 us,
   // 21.5 vs 21.5: the block latency is not what those steps wait for) -- on request only
   const bool deep = !big && tiles128 <= cu_count() && option("tiled_deep", 0);
+  // round 4: grids of at most ONE tile per CU (the level-2 shapes) on the loader-wave form (4-slot ring, 4 compute + 4 staging waves)
+  const bool lw = !big && tiles128 <= cu_count() && option("tiled_lw", 1);
 #define KD_TL(AM, EP)                                                                       \
   if (d.a_mode == AM && d.epi == EP) {                                                      \
     *rc = big ? launch_tiled<AM, EP, 2>(a, nm, flops, bytes, s)                             \
-              : (deep ? launch_tiled<AM, EP, 1, true>(a, nm, flops, bytes, s) : launch_tiled<AM, EP, 1>(a, nm, flops, bytes, s)); \
+              : (lw ? launch_tiled<AM, EP, 1, true, true>(a, nm, flops, bytes, s)           \
+                    : (deep ? launch_tiled<AM, EP, 1, true>(a, nm, flops, bytes, s) : launch_tiled<AM, EP, 1>(a, nm, flops, bytes, s))); \
     return 0;                                                                               \
   }
   KD_TL(KD_A_PLAIN, KD_EPI_STORE)

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
   const int m0 = panel * 128;
   const bool probe = p.clk && blockIdx.x == 0 && tid == 0;
   if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
+  const WgStamp wgs = wg_stamp_begin(p.clk);
 
   // KD_EPI_RESIDUAL (out projection: no norm, + x): the accumulators START from the residual, read straight into the C layout (lane
   // (l31, lh), block j, register 4 g + e <-> row l31, feature 32 j + 8 g + 4 lh + e: 16 bytes per load, 32 contiguous bytes per row and
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail requests still target this workgroup's LDS
   if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)total; }
+  wg_stamp_end(wgs);
 }
 
 // ===========================================================================================================================================
@@ -511,6 +513,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(const XArgs p) {
   const int m0 = panel * 128;
   const bool probe = p.clk && blockIdx.x == (gridDim.x * 5) / 8 && tid == 0;
   if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
+  const WgStamp wgs = wg_stamp_begin(p.clk);
 
   // stage q of this workgroup's stream: half tile ht_begin + q / 4, sub-stages 2 (q % 4), + 1 of its n-tile; piece j: sub-stage j >> 1, hi / lo
   // image j & 1 -- this wave's KiB of the half tile's 4 KiB run.  Past the end: the last stage again (never read).
@@ -759,6 +762,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(const XArgs p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped tail requests still target this workgroup's LDS
   if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)total; }
+  wg_stamp_end(wgs);
 }
 
 unsigned long long* g_clk = nullptr;

@@ -36,7 +36,8 @@ constexpr int NSTG = 4, PDIST = NSTG - 1;
 struct RArgs {
   const float* A; const char* Wp; float* C; const float* R;
   int M, N, K, nk;                      // nk = K / 32
-  int gh, gw;                           // merge: the COARSE token grid (A is [B, 2 gh, 2 gw, K / 4])
+  int gh, gw;                           // merge / split: the COARSE token grid (merge: A is [B, 2 gh, 2 gw, K / 4]; split: C and R are [B, 2 gh, 2 gw, N / 4])
+  const float* fac;                     // KD_EPI_SPLIT_LERP: the lerp weight (device scalar)
   int warm;
   unsigned long long* clk;             // kd_prof_clock_buffer: stamps of one workgroup's stage 8
 };
@@ -126,20 +127,38 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 2 : 1) void gemm_x3r_kernel(co
 #pragma unroll
     for (int s = 0; s < PDIST; ++s) issue(s);
   }
-  // KD_EPI_RESIDUAL: the accumulators start from R (C layout: lane (l31, lh), block j, register 4 g + e <-> row l31, column 32 j + 8 g + 4 lh + e)
+  // KD_EPI_SPLIT_LERP (TokenSplit, image_transformer_v2.py:610-621): output column n = quadrant * cout + e of coarse token gm is feature e of the
+  // fine token (2 h + (quadrant >> 1), 2 w + (quadrant & 1)); an n-tile of 128 columns lies inside ONE quadrant (cout % 128 == 0), so a tile row
+  // is 128 contiguous floats of one fine token's row, for the result and for the skip operand alike.  Offset (floats) of tile row `gm`:
+  auto out_row = [&](int gm) -> size_t {
+    if constexpr (EPI == KD_EPI_SPLIT_LERP) {
+      const int cout = p.N >> 2, qd = n0 / cout, e0 = n0 - qd * cout;
+      const int hw = p.gh * p.gw, b = gm / hw, rr = gm - b * hw, h = rr / p.gw, w = rr - h * p.gw;
+      return (((size_t)b * (2 * p.gh) + 2 * h + (qd >> 1)) * (2 * p.gw) + 2 * w + (qd & 1)) * cout + e0;
+    } else {
+      return (size_t)gm * p.N + n0;
+    }
+  };
+  // KD_EPI_RESIDUAL: the accumulators start from R (C layout: lane (l31, lh), block j, register 4 g + e <-> row l31, column 32 j + 8 g + 4 lh + e).
+  // KD_EPI_SPLIT_LERP: the skip operand is read the same way, into registers of its own (lerp is not a sum), ahead of the K loop.
+  f32x16 skp[EPI == KD_EPI_SPLIT_LERP ? 4 : 1];
   {
     const int rrow = min(m0 + wid * 32 + l31, p.M - 1);
-    if constexpr (EPI == KD_EPI_RESIDUAL) {
-      const float* rp = p.R + (size_t)rrow * p.N + n0 + 4 * lh;
+    if constexpr (EPI == KD_EPI_RESIDUAL || EPI == KD_EPI_SPLIT_LERP) {
+      const float* rp = p.R + out_row(rrow) + 4 * lh;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(rp + 32 * j + 8 * g);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[j][4 * g + e] = v[e];
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (EPI == KD_EPI_RESIDUAL) acc[j][4 * g + e] = v[e];
+            else skp[j][4 * g + e] = v[e];
+          }
         }
-    } else {
+    }
+    if constexpr (EPI != KD_EPI_RESIDUAL) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -150,6 +169,7 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 2 : 1) void gemm_x3r_kernel(co
   // (consumed HERE as far as the compiler knows: its wait for the residual loads lands in front of the loop -- together with the first
   // stages, which are needed at once anyway -- and not as a conservative vmcnt inside it)
   asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+  if constexpr (EPI == KD_EPI_SPLIT_LERP) asm volatile("" : "+v"(skp[0]), "+v"(skp[1]), "+v"(skp[2]), "+v"(skp[3]));
   code_warm_end(warm);
 
   // fragment addresses inside a stage: this lane's row of the A sub-tile (chunk pair 4 c + 2 lh, + 1 of chunk c), W rows 32 j + l31
@@ -259,7 +279,17 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 2 : 1) void gemm_x3r_kernel(co
   for (int it = 0; it < 2; ++it) {
     const int r = m0 + wid * 32 + 16 * it + (lane >> 2);
     st_ok[it] = r < p.M;
-    st_row[it] = p.C + (size_t)min(r, p.M - 1) * p.N + n0 + 4 * (lane & 3);
+    st_row[it] = p.C + out_row(min(r, p.M - 1)) + 4 * (lane & 3);
+  }
+  if constexpr (EPI == KD_EPI_SPLIT_LERP) {                          // torch.lerp(skip, x, fac), ATen's two-branch form
+    const float fac = *p.fac;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float skip = skp[j][r], diff = acc[j][r] - skip;
+        acc[j][r] = (fabsf(fac) < 0.5f) ? skip + fac * diff : acc[j][r] - diff * (1.0f - fac);
+      }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -310,28 +340,31 @@ int gemm_x3r_try(const GemmP& d, hipStream_t s, int* rc) {
   if (!mode) return 1;
   if (d.precision != KD_PREC_SPLIT3 || d.norm || !d.Wp || d.debug || d.a_split || d.c_split) return 1;
   if (d.a_mode != KD_A_PLAIN && d.a_mode != KD_A_MERGE2x2) return 1;
-  if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_RESIDUAL) return 1;
+  if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_RESIDUAL && d.epi != KD_EPI_SPLIT_LERP) return 1;
+  if (d.epi == KD_EPI_SPLIT_LERP && (d.a_mode != KD_A_PLAIN || !d.R || !d.fac || ((d.N >> 2) & 127) || d.gh <= 0 || d.gw <= 0 || d.M % (d.gh * d.gw) || !option("x3r_split", 1)))
+    return 1;                        // (an n-tile inside one quadrant: cout % 128 == 0)
   if ((d.K & 31) || (d.N & 127) || d.M < 512 || d.out_add != 0.f) return 1;
   // One workgroup per CU (136 KiB of LDS).  Round 3 took only grids of at most one tile per CU (the level-2 projections and the merge into
   // level 2); with the loader waves and the one-basic-block K loop of round 4 the kernel is level with or ahead of the round-1 tile kernel's
   // two workgroups per CU on every shape with K >= 256 (benchmarks/x3r_bench.py, batch 32: merge into level 1 31 vs 35 us, level-1 out
   // projection 26 vs 26, level-1 down projection 45 vs 60, level 2 19 / 39 / 27 vs 27 / 58 / 47 us), so it takes them all; at K = 128 (the
   // level-0 out projection, 4 stages: the prologue and the store tail are most of a tile's time) the round-1 kernel stays ahead, 39 vs 41 us.
-  // Option "x3r" = 2 takes every eligible shape, 0 none (A/B runs).  (A TokenSplit + lerp epilogue on this kernel -- scatter as row bases of
-  // the store runs, skip requested ahead of the K loop -- was measured slower than the round-1 kernel's in round 3, 57.9 vs 53.8 and 44.6 vs
-  // 41.4 us, and was not kept.)
+  // Option "x3r" = 2 takes every eligible shape, 0 none (A/B runs).  The TokenSplit + lerp epilogue (scatter as row bases of the store runs,
+  // skip requested ahead of the K loop) lost to the round-1 kernel's on round 3's loop, 57.9 vs 53.8 and 44.6 vs 41.4 us; on this loop it is
+  // back (option "x3r_split", benchmarks/x3r_bench.py).
   if (mode != 2 && d.K < 256) return 1;
   if (d.a_mode == KD_A_MERGE2x2 && ((d.K >> 2) & 31)) return 1;
   RArgs a{};
   a.A = d.A; a.Wp = reinterpret_cast<const char*>(d.Wp); a.C = d.C; a.R = d.R;
-  a.M = d.M; a.N = d.N; a.K = d.K; a.nk = d.K / 32; a.gh = d.gh; a.gw = d.gw;
+  a.M = d.M; a.N = d.N; a.K = d.K; a.nk = d.K / 32; a.gh = d.gh; a.gw = d.gw; a.fac = d.fac;
   a.warm = d.warm;
   a.clk = x3::g_clk;
   const double flops = 2.0 * d.M * (double)d.N * d.K;
-  const double bytes = 4.0 * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N * (d.epi == KD_EPI_RESIDUAL ? 2 : 1));
+  const double bytes = 4.0 * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N * (d.epi == KD_EPI_STORE ? 1 : 2));
   char nm[96] = "gemm_x3r";
   if (prof_on()) snprintf(nm, sizeof(nm), "gemm_x3r<a%d,e%d> M=%d N=%d K=%d", d.a_mode, d.epi, d.M, d.N, d.K);
   if (d.a_mode == KD_A_PLAIN && d.epi == KD_EPI_RESIDUAL) *rc = launch<KD_A_PLAIN, KD_EPI_RESIDUAL>(a, nm, flops, bytes, s);
+  else if (d.epi == KD_EPI_SPLIT_LERP) *rc = launch<KD_A_PLAIN, KD_EPI_SPLIT_LERP>(a, nm, flops, bytes, s);
   else if (d.a_mode == KD_A_PLAIN) *rc = launch<KD_A_PLAIN, KD_EPI_STORE>(a, nm, flops, bytes, s);
   else if (d.epi == KD_EPI_STORE) *rc = launch<KD_A_MERGE2x2, KD_EPI_STORE>(a, nm, flops, bytes, s);
   else return 1;

@@ -19,6 +19,28 @@ __device__ __forceinline__ int swz64(int row, int c) { return row * 64 + ((c ^ (
 
 #define KD_BARRIER() asm volatile("s_barrier" ::: "memory")
 
+// ---- per-workgroup time line (benchmarks/wg_timeline.py) ---------------------------------------------------------------------------------------
+// kd_prof_clock_buffer hands the kernels a buffer of 16 stamps of ONE workgroup.  When the caller sets entry 15 to the magic value below the
+// buffer holds 32 + 3 * grid entries and EVERY workgroup's first thread writes its entry / exit time (s_memrealtime: 100 MHz ticks, one clock
+// for the whole chip) to entries 32 + 3 * blockIdx.x, + 1: launch ramp, rounds, tail and the spread of the workgroups' durations become
+// visible.  Outside every loop; nothing is read or written when no buffer is set.
+constexpr unsigned long long KD_WG_STAMP_MAGIC = 0x4b44ull;
+struct WgStamp { unsigned long long* slot; };
+__device__ __forceinline__ WgStamp wg_stamp_begin(unsigned long long* clk) {
+  WgStamp w{nullptr};
+  if (clk && threadIdx.x == 0 && clk[15] == KD_WG_STAMP_MAGIC) {
+    w.slot = clk + 32 + 3 * blockIdx.x;
+    w.slot[0] = __builtin_amdgcn_s_memrealtime();
+  }
+  return w;
+}
+__device__ __forceinline__ void wg_stamp_end(const WgStamp& w) {
+  if (w.slot) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's stores are out
+    w.slot[1] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
 // s_waitcnt vmcnt(n) for a run-time n (6-bit counter: anything above 60 waits for 60 outstanding, which is only more conservative)
 __device__ __forceinline__ void wait_vm(int n) {
   switch (n < 60 ? n : 60) {

@@ -306,15 +306,26 @@ def test_residual_in_place_multi_tile(ops, monkeypatch, M, K, N):
     assert relerr(ops.linear(g(x), g(w), residual=xin, out=xin), x @ w.T + r) < 1e-4
 
 
-@pytest.mark.parametrize("B,h,w,K,C", [(2, 16, 16, 256, 128), (1, 32, 16, 512, 256), (3, 16, 12, 128, 64)])
+@pytest.mark.parametrize("B,h,w,K,C", [(2, 16, 16, 256, 128), (1, 32, 16, 512, 256), (3, 16, 12, 128, 64), (3, 20, 12, 256, 128), (5, 16, 16, 512, 256)])
 def test_token_split_multi_tile(ops, monkeypatch, B, h, w, K, C):
-    """TokenSplit (Linear -> depth-to-space -> lerp with the skip) at multi-tile shapes (several m- and n-tiles)."""
+    """TokenSplit (Linear -> depth-to-space -> lerp with the skip) at multi-tile shapes (several m- and n-tiles; a ragged last row panel).
+    Round 4: with C % 128 == 0 and K >= 256 the split runs on gemm_x3r.hip (loader waves; the scatter is the row base of its store runs, the skip
+    operand is read ahead of the K loop): checked against the reference formula AND against the round-1 kernel it replaces (x3r_split = 0)."""
+    from k_diffusion_amd import _native as nat
     monkeypatch.setenv("KDIFF_GEMM", "split3")
     x, wt, skip = rn(B, h, w, K, seed=1), rn(4 * C, K, seed=2) / K ** 0.5, rn(B, 2 * h, 2 * w, C, seed=3)
     for fac in (0.3, 0.75):
         ref = torch.lerp(skip, hdit.token_split(x, wt, 2, 2), torch.tensor([fac]))
         y = ops.token_split_lerp(g(x), g(wt), g(skip), g(torch.tensor([fac])))
         assert relerr(y, ref) < 1e-4
+        nat.set_option("x3r_split", 0)
+        try:
+            old = ops.token_split_lerp(g(x), g(wt), g(skip), g(torch.tensor([fac])))
+        finally:
+            nat.set_option("x3r_split", 1)
+        assert relerr(y, old) < 1e-4
+        xin = g(skip.clone())                             # in place, as the model uses it (the result overwrites the skip)
+        assert torch.equal(ops.token_split_lerp(g(x), g(wt), xin, g(torch.tensor([fac])), out=xin), y)
 
 
 def test_token_merge_split(ops, gtol, golden):
