@@ -148,7 +148,7 @@ def pmc_traffic(kernel_family):
     passes, gfx950 FETCH x2 correction: profiles/summarize_pmc.py); None when the summary has no matching entry."""
     if not kernel_family:
         return None
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):        # newest committed summary that knows the kernel
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):        # newest committed summary that knows the kernel
         path = os.path.join(REPO, "profiles", name)
         try:
             table = json.load(open(path))
