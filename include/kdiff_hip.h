@@ -320,7 +320,11 @@ int kd_prof_reset(void);
  * entry / exit (shader clock under load = ([2]-[0]) / ([3]-[1]) x 100 MHz), [4] end of the row prologue / first blocks in,
  * [5] end of the first tile's K loop (tiled, ffn: of the whole loop), [6] end of its epilogue, [7] number of ring blocks / tiles.
  * kd_ffn_f32 also stamps its third d_ff tile: [8] start, [9] up projection done, [10] GEGLU done, [11] down k-steps done, and [12]
- * the end of the tile loop.  NULL switches it off.  Not for concurrent launches. */
+ * the end of the tile loop.  NULL switches it off.  Not for concurrent launches.
+ * Extended form (round 4; the fp32-parity kernels of gemm_x3.hip, gemm_x3r.hip, ffn_x3.hip, attn_x3.hip): when entry [15] holds 0x4b44 the buffer
+ * must provide 32 + 3 * grid entries, and EVERY workgroup's first thread writes s_memrealtime (100 MHz ticks) at its entry to [32 + 3 b] and at
+ * its exit to [32 + 3 b + 1] (b = blockIdx.x; [.. + 2]: exit of the workgroup's first loader wave where there is one): launch ramp, rounds,
+ * tail and the spread of the workgroups' lifetimes (benchmarks/wg_timeline.py, benchmarks/x3r_bench.py). */
 int kd_prof_clock_buffer(void* dev_ptr);
 
 #ifdef __cplusplus
