@@ -986,7 +986,17 @@ using namespace kd;
 
 extern "C" int kd_ffn_f32_supported(int M, int K, int d_ff) {
   if (!option("ffn_x3", 1)) return 0;
-  return (K == 128 || K == 256) && d_ff > 0 && d_ff % 64 == 0 && M >= 2048;
+  if (!((K == 128 || K == 256) && d_ff > 0 && d_ff % 64 == 0)) return 0;
+  // Where it is the FASTER form.  Width 128 (two workgroups per CU, ~55 us per workgroup): from 16 row panels on.  Width 256 runs ONE workgroup per CU
+  // for ~120 us whatever the grid, so below a chip-filling grid the two-launch form (GEGLU projection with n-splits + residual projection, both of which
+  // spread over the CUs) wins: at batch 4 of the headline config (32 panels) the fused block took 95 us where the pair takes ~35
+  // (profiles/r04_small_batch.log).  Option "ffn_x3_min_panels_256": panels needed at width 256 (default: 7/8 of the CUs).
+  if (K == 128) return M >= 2048;
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int need = option("ffn_x3_min_panels_256", cus - cus / 8);
+  return (M + 127) / 128 >= need;
 }
 
 extern "C" int kd_ffn_f32(const KdFfn* dp, void* stream) {

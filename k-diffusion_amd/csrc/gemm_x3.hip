@@ -844,7 +844,7 @@ int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc) {
   if (d.epi == KD_EPI_RESIDUAL ? (d.norm || !d.R || d.K != 512 || !option("x3_res", 0)) : !d.norm) return 1;
   if (d.K != 128 && d.K != 256 && d.K != 512) return 1;
   const int ncol = d.epi == KD_EPI_GEGLU ? 64 : 128;
-  if ((!unpatch && d.N % ncol) || d.M < 512 || (d.norm && d.rows_per_sample <= 0)) return 1;
+  if ((!unpatch && d.N % ncol) || d.M < option("x3_min_rows", 512) || (d.norm && d.rows_per_sample <= 0)) return 1;
   if (d.epi == KD_EPI_QKV && (!d.rope_pos || !d.rope_freq || d.n_heads > 16)) return 1;   // tables only / many heads: round-1 kernel
   if (d.c_split && (d.epi != KD_EPI_GEGLU || !d.C_lo || (d.N & 31))) return 1;
   XArgs a{};

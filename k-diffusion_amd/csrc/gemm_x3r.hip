@@ -343,7 +343,7 @@ int gemm_x3r_try(const GemmP& d, hipStream_t s, int* rc) {
   if (d.epi != KD_EPI_STORE && d.epi != KD_EPI_RESIDUAL && d.epi != KD_EPI_SPLIT_LERP) return 1;
   if (d.epi == KD_EPI_SPLIT_LERP && (d.a_mode != KD_A_PLAIN || !d.R || !d.fac || ((d.N >> 2) & 127) || d.gh <= 0 || d.gw <= 0 || d.M % (d.gh * d.gw) || !option("x3r_split", 1)))
     return 1;                        // (an n-tile inside one quadrant: cout % 128 == 0)
-  if ((d.K & 31) || (d.N & 127) || d.M < 512 || d.out_add != 0.f) return 1;
+  if ((d.K & 31) || (d.N & 127) || d.M < option("x3r_min_rows", 128) || d.out_add != 0.f) return 1;
   // One workgroup per CU (136 KiB of LDS).  Round 3 took only grids of at most one tile per CU (the level-2 projections and the merge into
   // level 2); with the loader waves and the one-basic-block K loop of round 4 the kernel is level with or ahead of the round-1 tile kernel's
   // two workgroups per CU on every shape with K >= 256 (benchmarks/x3r_bench.py, batch 32: merge into level 1 31 vs 35 us, level-1 out
