@@ -97,16 +97,26 @@ __global__ __launch_bounds__(256, NaGeo<KS>::LDS <= 80 * 1024 ? 2 : 1) void attn
   const int hy0 = max(0, min(ty0 - KS / 2, a.H - HR)), hx0 = max(0, min(tx0 - KS / 2, a.W - HC));
 
   // ---- halo rows -> image: image row 4 pc + (lane >> 4) = halo position (y, x), 16 rows per round of the 4 waves.  Rows past the halo's
-  // last key and out-of-image positions (images smaller than the halo) take a real token: they lie outside every window ---------------
-  auto stage = [&](int part_bytes) {
+  // last key and out-of-image positions (images smaller than the halo) take a real token: they lie outside every window.  The byte offsets of
+  // this lane's pieces are computed ONCE (the K pass) and kept for the V pass: the same rows, `nh * 256` bytes further ------------------------------
+  constexpr int NPC = (ROWS / 4 + 3) / 4;                // staging rounds of a wave
+  unsigned soff[NPC];
+  {
     int row = 4 * wid + (lane >> 4);
     int y = row / HC, x = row % HC;
-    for (int pc = wid; pc < ROWS / 4; pc += 4) {
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
       const int ky = min(hy0 + y, a.H - 1), kx = min(hx0 + x, a.W - 1);
-      const char* src = base + (size_t)(unsigned)((ky * a.W + kx) * (int)row_bytes + (((lane & 15) ^ rsw(x)) << 4));
-      glds16(src + part_bytes, img + pc * 1024);
-      row += 16; x += 16;
+      soff[i] = (unsigned)((ky * a.W + kx) * (int)row_bytes + (((lane & 15) ^ rsw(x)) << 4));
+      x += 16;
       if (x >= HC) { x -= HC; ++y; }
+    }
+  }
+  auto stage = [&](int part_bytes) {
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int pc = wid + 4 * i;
+      if (pc < ROWS / 4) glds16(base + (size_t)soff[i] + part_bytes, img + pc * 1024);
     }
   };
   stage(a.nh * DH * 4);                                  // K

@@ -220,6 +220,17 @@ def test_bad_arguments_are_rejected_without_a_gpu(KD):
     assert lib.kd_brownian_f32(1, 1, 1, 8, 0.0, 1.0, 0.5, 0.4, 1.0, 36, None) == -1            # t0 > t1
 
 
+def test_fused_ff_is_advised_only_where_it_is_the_faster_form(KD):
+    """kd_ffn_f32_supported (no launch, runs without a GPU): the width-128 fused FF block from 16 row panels on; the width-256 one (one workgroup per CU
+    for ~120 us whatever the grid) only from a chip-filling grid on -- at batch 4 of the headline config it ran 32 workgroups for 95 us where the
+    two-launch form takes ~35 (profiles/r04_small_batch.log)."""
+    lib = KD._native.lib()
+    assert lib.kd_ffn_f32_supported(2048, 128, 384) == 1 and lib.kd_ffn_f32_supported(1024, 128, 384) == 0
+    assert lib.kd_ffn_f32_supported(32768, 256, 768) == 1            # batch 32 of the headline config: 256 panels
+    assert lib.kd_ffn_f32_supported(4096, 256, 768) == 0 and lib.kd_ffn_f32_supported(16384, 256, 768) == 0
+    assert lib.kd_ffn_f32_supported(32768, 256, 100) == 0 and lib.kd_ffn_f32_supported(32768, 512, 1536) == 0
+
+
 def test_hot_path_has_no_cpu_fallback(KD):
     cfg = KD.config.load_config(os.path.join(REPO, "configs", "config_mnist_transformer.json"))
     model = KD.config.make_model(cfg)
