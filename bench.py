@@ -63,6 +63,7 @@ def parse():
     p.add_argument("--no-kernel-events", action="store_true", help="do not record per-launch HIP events in the timed region")
     p.add_argument("--kernel-table", default=None, help="write the per-kernel event timings to this JSON file")
     p.add_argument("--no-other-configs", action="store_true", help="skip the short secondary measurement of the shifted-window config")
+    p.add_argument("--no-power", action="store_true", help="skip the socket power / shader clock samples (a few extra untimed passes with rocm-smi beside them)")
     p.add_argument("--no-parity", action="store_true", help="skip the golden-vector parity block (5-step batch-32 run per measured mode)")
     return p.parse_args()
 
@@ -246,6 +247,42 @@ def parity_vs_reference_golden(dev, modes):
 
 
 CONFIG_OF = {"flowers_na": "configs/config_oxford_flowers.json", "flowers_sw": "configs/config_oxford_flowers_shifted_window.json"}
+
+
+def power_and_clock(one_pass, passes=16):
+    """Socket power and shader clock while the path runs: `passes` more untimed passes with rocm-smi sampled from a side thread (the timed
+    region is not touched).  On MI355X the fp32-parity path runs INTO the chip's power limit (~1.2 kW average, every fused projection / FF kernel
+    1.3 - 1.4 kW) and is clocked down to ~2.0 of 2.4 GHz: DESIGN.md section 5 A, profiles/r04_power_clock.log.  None if rocm-smi is unavailable."""
+    import re
+    import subprocess
+    import threading
+    stop, out = threading.Event(), []
+
+    def sample():
+        while not stop.is_set():
+            try:
+                txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+            except Exception:
+                return
+            p = re.search(r"Socket Graphics Package Power \(W\): ([0-9.]+)", txt)
+            c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
+            if p and c:
+                out.append((float(p.group(1)), int(c.group(1))))
+            time.sleep(0.1)
+    th = threading.Thread(target=sample, daemon=True)
+    th.start()
+    for _ in range(passes):
+        one_pass()
+    torch.cuda.synchronize()
+    stop.set()
+    th.join(timeout=10)
+    body = out[len(out) // 3:-1] if len(out) > 5 else out          # (the first second still rides the boost after an idle gap: the steady state follows)
+    if not body:
+        return None
+    return {"socket_power_w": round(sum(p for p, _ in body) / len(body), 1), "shader_clock_mhz": round(sum(c for _, c in body) / len(body)),
+            "max_shader_clock_mhz": 2400, "samples": len(body),
+            "note": "rocm-smi sampled every ~0.15 s during extra untimed passes of this mode right after its timed region; a clock below the part's "
+                    "2400 MHz at ~1.2 kW means the power limit, not a pipe, sets the pace"}
 
 
 MODE_DTYPE = {
@@ -468,6 +505,9 @@ def main():
                     "split3": other_config("sde", na, dev, args, "sample_dpmpp_sde", "split3", brownian=True),
                     "bf16+fp8w": other_config("sde", na, dev, args, "sample_dpmpp_sde", "bf16", fp8=True, brownian=True)},
             }
+        if args.gpus == 1 and not args.no_power:
+            os.environ["KDIFF_GEMM"] = args.mode
+            result["power"] = power_and_clock(compute_only)
         if args.gpus == 1 and not args.no_parity:
             # parity magnitudes where the driver's record shows them: after the timed regions, every measured mode against the reference's golden
             measured = [args.mode] + [m for m in result.get("modes", {}) if m != args.mode]
