@@ -689,7 +689,9 @@ int gemm_tiled_try(const KdGemm& d, hipStream_t s, int* rc) {
   // 21.5 vs 21.5: the block latency is not what those steps wait for) -- on request only
   const bool deep = !big && tiles128 <= cu_count() && option("tiled_deep", 0);
   // round 4: grids of at most ONE tile per CU (the level-2 shapes) on the loader-wave form (4-slot ring, 4 compute + 4 staging waves)
-  const bool lw = !big && tiles128 <= cu_count() && option("tiled_lw", 1);
+  // (from 12 K steps on: with fewer the launch's fixed cost decides and the smaller 2-slot form is ahead -- level-2 out projection 13.8 vs 14.2 us,
+  // the 256-wide MNIST / CIFAR levels +4 us per launch: profiles/r04_tiled_bf16_bench.log, r04_small_batch.log)
+  const bool lw = !big && tiles128 <= cu_count() && d.K >= 768 && option("tiled_lw", 1);
 #define KD_TL(AM, EP)                                                                       \
   if (d.a_mode == AM && d.epi == EP) {                                                      \
     *rc = big ? launch_tiled<AM, EP, 2>(a, nm, flops, bytes, s)                             \
