@@ -596,6 +596,7 @@ namespace kd { int gemm_x3_try(const GemmP& d, hipStream_t s, int* rc); }       
 namespace kd { int gemm_x3t_try(const GemmP& d, hipStream_t s, int* rc); }      // gemm_x3t.hip
 namespace kd { int gemm_skinny_try(const GemmP& d, hipStream_t s, int* rc); }   // gemm_skinny.hip
 namespace kd { int gemm_x3r_try(const GemmP& d, hipStream_t s, int* rc); }      // gemm_x3r.hip
+namespace kd { int gemm_x3s_try(const GemmP& d, hipStream_t s, int* rc); }      // gemm_x3s.hip
 
 using namespace kd;
 
@@ -639,6 +640,7 @@ extern "C" int kd_gemm_f32(const KdGemm* dp, void* stream) {
     const bool skinny_on = option("skinny", 1) != 0;
     int rc = 0;
     if (skinny_on && !gemm_skinny_try(e, s, &rc)) return rc;   // <= 128 rows (one per sample): the conditioning chain
+    if (!gemm_x3s_try(e, s, &rc)) return rc;                   // few rows (small batches), split3: the latency form, gemm_x3s.hip
   }
   {
     const bool astat_on = option("astat", 1) != 0;

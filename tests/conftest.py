@@ -10,6 +10,7 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "few_rows: runs with the few-rows latency kernel (csrc/gemm_x3s.hip) at its default threshold")
 
 
 @pytest.fixture(scope="session")

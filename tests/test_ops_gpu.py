@@ -28,6 +28,32 @@ def gtol(request, monkeypatch):
     return 2e-5 if request.param == "exact" else 1e-4
 
 
+@pytest.fixture(autouse=True)
+def throughput_kernels(request, KD):
+    """The tests of this file were written against the throughput kernels, also at their ragged / few-row shapes: the few-rows latency
+    kernel (round 4, csrc/gemm_x3s.hip: projections of at most 1024 rows) is switched off for them and has its own tests
+    (marked `few_rows`, which run with the library's defaults)."""
+    if request.node.get_closest_marker("few_rows"):
+        yield
+        return
+    KD._native.set_option("x3s_max_rows", 0)
+    try:
+        yield
+    finally:
+        KD._native.set_option("x3s_max_rows", -2 ** 31)       # back to the built-in default
+
+
+def _prof_names(nat):
+    """Names of the launches recorded since kd_prof_reset (kd_prof_enable(1)): which kernel served each call."""
+    import ctypes as C
+    lib, out = nat.lib(), []
+    name, ms, fl, by = C.create_string_buffer(128), C.c_float(), C.c_double(), C.c_double()
+    for i in range(lib.kd_prof_count()):
+        nat.check(lib.kd_prof_get(i, name, 128, C.byref(ms), C.byref(fl), C.byref(by)), "kd_prof_get")
+        out.append(name.value.decode())
+    return out
+
+
 def rn(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
 
@@ -842,6 +868,89 @@ def test_split3_projections_round3(KD, ops, monkeypatch, H, W, nh, B, K):
     finally:
         nat.set_option("x3", 1)
     assert relerr(qkv, old) < 1e-4 and (B * T < 512 or K >= 512 or not torch.equal(qkv, old))      # (another kernel really ran)
+
+
+@pytest.mark.few_rows
+@pytest.mark.parametrize("H,W,nh,B,K", [(16, 16, 8, 1, 512), (7, 7, 4, 4, 256), (32, 32, 4, 1, 256), (9, 12, 2, 3, 128), (16, 16, 18, 2, 384), (6, 6, 1, 4, 64)])
+def test_split3_few_rows_latency_kernel(KD, ops, monkeypatch, request, H, W, nh, B, K):
+    """The few-rows form of the fp32-parity projections (round 4, csrc/gemm_x3s.hip: 32 rows x one half tile per workgroup, K split over
+    its 8 waves, operands straight into registers, partial sums reduced in wave order) at batch-1 shapes of the headline config, the
+    MNIST shape (49 tokens per sample: a 32-row group spans samples), ragged row counts, 18 heads and K = 64: every epilogue against the
+    oracle at split-bf16x3 accuracy, against the throughput kernels it stands in for, and bit-identical from run to run."""
+    from k_diffusion_amd import _native as nat
+    monkeypatch.setenv("KDIFF_GEMM", "split3")
+    T, d, M = H * W, nh * 64, B * H * W
+    assert 128 < M <= 1024
+    x, scale = rn(B, T, K, seed=8), 1 + 0.2 * rn(B, K, seed=9)
+    xn = hdit.rms_norm(x, scale[:, None, :])
+    w = rn(3 * d, K, seed=10, scale=K ** -0.5)
+    qs = torch.linspace(5.0, 12.0, nh)
+    pos, freqs = hdit.axial_pos(H, W).reshape(T, 2), hdit.rope_freqs(nh)
+    cos, sin = _tables(H, W, nh)
+    qk = (g(qs), g(cos), g(sin), nh, g(pos.contiguous()), g((freqs / (2 * np.pi)).contiguous()))
+    theta = hdit.rope_theta(hdit.axial_pos(H, W), freqs)
+    wg = rn(2 * 3 * K, K, seed=11, scale=K ** -0.5)
+    ws = rn(256, K, seed=12, scale=K ** -0.5)
+    wd = rn(K, 3 * K, seed=13, scale=(3 * K) ** -0.5)
+    hid, res = rn(B, T, 3 * K, seed=15), rn(B, T, K, seed=14)
+
+    def run_all():
+        out = {}
+        out["qkv"] = ops.norm_linear(g(x), g(scale), g(w), rows_per_sample=T, epi=nat.EPI_QKV, qk=qk)
+        out["packed"] = ops.norm_linear(g(x), g(scale), g(w), rows_per_sample=T, epi=nat.EPI_QKV, qk=qk, qkv_packed=True)
+        out["geglu"] = ops.norm_linear(g(x), g(scale), g(wg), rows_per_sample=T, epi=nat.EPI_GEGLU)
+        out["shared"] = ops.norm_linear(g(x), g(scale[0].contiguous()), g(ws), rows_per_sample=T)
+        out["plain"] = ops.gemm(g(hid), g(wd), torch.empty(M, K, device=DEV), M=M, N=K, K=3 * K, out_add=0.5)
+        out["res"] = ops.gemm(g(hid), g(wd), torch.empty(M, K, device=DEV), M=M, N=K, K=3 * K, epi=nat.EPI_RESIDUAL, residual=g(res))
+        inplace = g(res).clone()
+        ops.gemm(g(hid), g(wd), inplace, M=M, N=K, K=3 * K, epi=nat.EPI_RESIDUAL, residual=inplace)
+        out["inplace"] = inplace
+        return out
+
+    nat.set_option("x3s_max_wgs", 1 << 20)        # (by default the kernel takes grids of at most 512 workgroups: here every shape)
+    request.addfinalizer(lambda: nat.set_option("x3s_max_wgs", -2 ** 31))
+    nat.lib().kd_prof_reset()
+    nat.lib().kd_prof_enable(1)
+    try:
+        got = run_all()
+        torch.cuda.synchronize()
+        names = _prof_names(nat)
+    finally:
+        nat.lib().kd_prof_enable(0)
+        nat.lib().kd_prof_reset()
+    assert sum(n.startswith("gemm_x3s") for n in names) == 7, names           # every one of them ran on the few-rows kernel
+    qkv = got["qkv"].cpu().view(B, H, W, 3, nh, 64)
+    ref = (xn @ w.T).view(B, H, W, 3, nh, 64)
+    q_ref, k_ref = hdit.cosine_sim_scale(ref[..., 0, :, :], ref[..., 1, :, :], qs)
+    assert relerr(qkv[..., 0, :, :], hdit.apply_rope(q_ref, theta)) < 1e-4
+    assert relerr(qkv[..., 1, :, :], hdit.apply_rope(k_ref, theta)) < 1e-4
+    assert relerr(qkv[..., 2, :, :], ref[..., 2, :, :]) < 1e-4
+    pw = got["packed"].view(torch.int32).view(-1, 4)
+    hi = torch.stack([(pw[:, 0] << 16), (pw[:, 0] & -65536), (pw[:, 1] << 16), (pw[:, 1] & -65536)], dim=1).view(torch.float32)
+    lo = torch.stack([(pw[:, 2] << 16), (pw[:, 2] & -65536), (pw[:, 3] << 16), (pw[:, 3] & -65536)], dim=1).view(torch.float32)
+    assert relerr((hi + lo).cpu().view_as(qkv), qkv) < 2.0 ** -15
+    assert relerr(got["geglu"], hdit.linear_geglu(xn, wg)) < 1e-4
+    assert relerr(got["shared"], hdit.rms_norm(x, scale[0]) @ ws.T) < 1e-4
+    assert relerr(got["plain"], hid.view(M, -1) @ wd.T + 0.5) < 1e-4
+    assert relerr(got["res"], hid.view(M, -1) @ wd.T + res.view(M, -1)) < 1e-4
+    assert torch.equal(got["inplace"].view(M, K), got["res"])
+    # GEGLU result as bf16 hi / lo planes (the pre-split operand of gemm_x3t.hip)
+    hh, hl = torch.empty(B, T, 3 * K, device=DEV, dtype=torch.bfloat16), torch.empty(B, T, 3 * K, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(g(x), g(wg), None, M=M, N=3 * K, K=K, epi=nat.EPI_GEGLU, norm_scale=g(scale), scale_stride=K, rows_per_sample=T, c_planes=(hh, hl))
+    assert relerr(hh.float().cpu() + hl.float().cpu(), hdit.linear_geglu(xn, wg)) < 1e-4
+    # run to run: the reduction over the 8 waves is in wave order
+    again = run_all()
+    assert all(torch.equal(got[k], again[k]) for k in got)
+    # against the throughput kernels (another summation order: close, not equal)
+    nat.set_option("x3s_max_rows", 0)
+    try:
+        old = run_all()
+    finally:
+        nat.set_option("x3s_max_rows", -2 ** 31)
+    for k in got:
+        a, b = (got[k], old[k]) if k != "packed" else (got["qkv"], old["qkv"])
+        assert relerr(a, b) < 1e-4, k
+    assert not torch.equal(got["qkv"], old["qkv"])
 
 
 @pytest.mark.parametrize("B,H,W,C,N", [(2, 32, 32, 128, 256), (3, 16, 24, 256, 512), (1, 48, 40, 64, 128)])
