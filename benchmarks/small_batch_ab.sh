@@ -2,7 +2,7 @@
 # Small-batch A/B of the kernel-selection thresholds (fp32-parity mode): ms per forward at batch 1 .. 16 for a few KDIFF_OPTIONS settings.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp
-for OPT in "" "x3r_min_rows=128" "x3r_min_rows=128,x3_min_rows=128" "x3r_min_rows=128,x3_min_rows=256" "ffn_x3_min_panels_256=16"; do
+for OPT in ${OPTS:-"" "x3s_max_rows=0"}; do
   for B in 1 2 4 8 16; do
     KDIFF_OPTIONS=$OPT KDIFF_GEMM=split3 python $R/benchmarks/small_batch.py $R/configs/config_oxford_flowers.json $B sample_dpmpp_2m 20 2>/dev/null | python -c "
 import sys, json

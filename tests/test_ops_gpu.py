@@ -907,7 +907,7 @@ def test_split3_few_rows_latency_kernel(KD, ops, monkeypatch, request, H, W, nh,
         out["inplace"] = inplace
         return out
 
-    nat.set_option("x3s_max_wgs", 1 << 20)        # (by default the kernel takes grids of at most 512 workgroups: here every shape)
+    nat.set_option("x3s_max_wgs", 1 << 20)        # (by default the kernel takes a shape where its cost estimate wins: here every shape)
     request.addfinalizer(lambda: nat.set_option("x3s_max_wgs", -2 ** 31))
     nat.lib().kd_prof_reset()
     nat.lib().kd_prof_enable(1)
@@ -941,6 +941,13 @@ def test_split3_few_rows_latency_kernel(KD, ops, monkeypatch, request, H, W, nh,
     # run to run: the reduction over the 8 waves is in wave order
     again = run_all()
     assert all(torch.equal(got[k], again[k]) for k in got)
+    # the scale vector through LDS (option x3s_scale_lds; taken where a workgroup's 32 rows share it): the same products in the same order
+    nat.set_option("x3s_scale_lds", 1)
+    try:
+        lds = run_all()
+    finally:
+        nat.set_option("x3s_scale_lds", -2 ** 31)
+    assert all(torch.equal(got[k], lds[k]) for k in got)
     # against the throughput kernels (another summation order: close, not equal)
     nat.set_option("x3s_max_rows", 0)
     try:
