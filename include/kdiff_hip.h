@@ -44,6 +44,12 @@ const char* kd_last_error(void);
  *                  kernel, 2 = every eligible shape) "x3r_lw" (1; 0 = staging requests inside the compute waves' K loop instead of loader waves)
  *                  "x3r_split" (1; 0 = TokenSplit + lerp on the round-1 tile kernel) "ffn_x3" (1; 0 = kd_ffn_f32_supported answers no) "ffn_x3_half" (1; 0 = one workgroup per CU
  *                  at K = 128) "attn_x3" (1; 0 = the round-1 attention cores also for split-stored operands)
+ *                  "x3_min_rows" (512) "x3r_min_rows" (128) "ffn_x3_min_panels_256" (7/8 of the CUs): row counts from which the throughput
+ *                  kernels are chosen / advised
+ *                  "x3s_max_rows" (4096; 0 = off) the few-rows latency form of the KD_PREC_SPLIT3 projections (gemm_x3s.hip: 32 rows x one
+ *                  half tile per workgroup, K split over 8 waves), taken up to that many rows where its cost estimate beats the
+ *                  throughput kernel's; "x3s_max_wgs" (-1; >= 0 replaces the estimate by a cap on the grid) "x3s_scale_lds" (0; 1 = the
+ *                  AdaRMSNorm scale vector through LDS where a workgroup's rows share it: same results, measured level)
  *   bf16 kernels : "bf16_fast" (1; 0 = generic kernel only) "wstat" (1) "wstat_waves" (0 = per shape) "wstat_max_slices" (24)
  *                  "wstat_prefetch" (0; 1 next-chunk prefetch, 2 software-pipelined tiles) "astat_bf16" (1) "astat_splits" (0 = auto)
  *                  "tiled_bm" (0 = auto, 128, 256) "tiled_lw" (1; 0 = no loader waves in the tiled kernel at one tile per CU) "attn_global_qw" (8) "patch_fast" (1; 0 = patch-in / patch-out through the generic kernel)
