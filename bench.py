@@ -64,6 +64,7 @@ def parse():
     p.add_argument("--kernel-table", default=None, help="write the per-kernel event timings to this JSON file")
     p.add_argument("--no-other-configs", action="store_true", help="skip the short secondary measurement of the shifted-window config")
     p.add_argument("--no-power", action="store_true", help="skip the socket power / shader clock samples (a few extra untimed passes with rocm-smi beside them)")
+    p.add_argument("--no-small-batch", action="store_true", help="skip the batch-1 / batch-4 latency entries (`small_batch`)")
     p.add_argument("--no-parity", action="store_true", help="skip the golden-vector parity block (5-step batch-32 run per measured mode)")
     return p.parse_args()
 
@@ -244,6 +245,38 @@ def parity_vs_reference_golden(dev, modes):
     return {"case": f"{case}: {os.path.basename(CONFIG_OF[cfgname])} 256x256, {sampler} {steps} steps, batch {batch}, images {cases.B32_KEEP} "
                     "against the reference's fp32 run (tests/golden/samples_r3.safetensors)",
             "measure": "max|got - ref| / max|ref|", **out}
+
+
+def small_batch_latency(cfg, model, dev, args, measured_modes, batches=(1, 4)):
+    """Latency regime of the same path (review item: batch 1 - 4): the headline sampler at small batches, 2 warm-up + 3 timed runs each,
+    launch lists issued directly.  ms per forward = run time / model calls.  Not part of `value`."""
+    mc = cfg["model"]
+    den = K.Denoiser(model, sigma_data=mc["sigma_data"])
+    sampler = getattr(K.sampling, args.sampler)
+    sigmas = K.sampling.get_sigmas_karras(args.sampler_steps, mc["sigma_min"], mc["sigma_max"], rho=7., device=dev)
+    shape = (mc["input_channels"], *mc["input_size"])
+    nfe = {"sample_dpmpp_sde": 2 * args.sampler_steps - 1, "sample_heun": 2 * args.sampler_steps - 1}.get(args.sampler, args.sampler_steps)
+    out, saved = {}, os.environ.get("KDIFF_GEMM")
+    try:
+        for m in measured_modes:
+            os.environ["KDIFF_GEMM"] = m
+            ent = {}
+            for b in batches:
+                x = K.synth.synth_noise_batch(shape, args.seed, 0, b, mc["sigma_max"]).to(dev)
+                extra = {"class_cond": (torch.arange(b) % cfg["dataset"]["num_classes"]).to(dev)} if cfg["dataset"]["num_classes"] else {}
+                for _ in range(2):
+                    sampler(den, x, sigmas, extra_args=extra, disable=True)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(3):
+                    sampler(den, x, sigmas, extra_args=extra, disable=True)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t) / 3
+                ent[f"batch_{b}"] = {"ms_per_forward": round(dt * 1e3 / nfe, 4), "images_per_s": round(b / dt, 2)}
+            out[m] = ent
+    finally:
+        os.environ["KDIFF_GEMM"] = saved if saved is not None else "split3"
+    return {"workload": f"{os.path.basename(args.config)}, {args.sampler} {args.sampler_steps} steps, 3 timed runs per entry", **out}
 
 
 CONFIG_OF = {"flowers_na": "configs/config_oxford_flowers.json", "flowers_sw": "configs/config_oxford_flowers_shifted_window.json"}
@@ -516,6 +549,8 @@ def main():
             result["parity"] = {"case": par["case"], "measure": par["measure"], "mode": args.mode,
                                 "rel_err": head_par["rel_err_vs_reference_golden"], "gate": head_par["gate"], "pass": head_par.get("pass"),
                                 "modes": {m: par[m] for m in measured}}
+        if args.gpus == 1 and not args.no_small_batch:
+            result["small_batch"] = small_batch_latency(cfg, model, dev, args, measured_modes=[args.mode] + [m for m in result.get("modes", {}) if m != args.mode and m != "exact"])
         if "modes" in result:
             # short copy of the per-mode throughputs (the full entries carry their rooflines: a truncated log tail may cut them off)
             result["mode_values"] = {m: e["value"] for m, e in result["modes"].items()}

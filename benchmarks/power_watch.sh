@@ -4,7 +4,7 @@
 MODE=${1:-split3}
 STEPS=${2:-40}
 R=${GRAFT_REPO_ROOT:-/root/repo}
-python $R/bench.py --steps $STEPS --warmup 3 --mode $MODE --no-cpu-baseline --no-other-modes --no-other-configs --no-parity --no-power --no-kernel-events > /tmp/pw_bench.json 2>/dev/null &
+python $R/bench.py --steps $STEPS --warmup 3 --mode $MODE --no-cpu-baseline --no-other-modes --no-other-configs --no-parity --no-small-batch --no-power --no-kernel-events > /tmp/pw_bench.json 2>/dev/null &
 BP=$!
 sleep 4
 while kill -0 $BP 2>/dev/null; do

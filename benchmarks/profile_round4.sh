@@ -11,8 +11,8 @@ rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --steps 20 --warmup 5 --kernel-table $OUT/kt.json > $OUT/bench_line.json 2> $OUT/bench_line.err
 tail -c 400 $OUT/bench_line.err
-SHORT="--steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-other-configs --no-other-modes --no-power --no-parity"
-TINY="--steps 1 --warmup 0 --sampler-steps 3 --no-cpu-baseline --no-kernel-events --no-other-configs --no-other-modes --no-power --no-parity"
+SHORT="--steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-other-configs --no-other-modes --no-power --no-parity --no-small-batch"
+TINY="--steps 1 --warmup 0 --sampler-steps 3 --no-cpu-baseline --no-kernel-events --no-other-configs --no-other-modes --no-power --no-parity --no-small-batch"
 for MODE in split3 bf16; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$MODE -o st -- python $R/bench.py --mode $MODE $SHORT > $OUT/stats_$MODE.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$MODE -o f -- python $R/bench.py --mode $MODE $TINY > $OUT/pmc_fetch_$MODE.log 2>&1
