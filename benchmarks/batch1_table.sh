@@ -1,12 +1,12 @@
 #!/bin/bash
 # Batch-1 (or $B) latency of the headline config, fp32-parity mode: ms per forward and the per-kernel event table for a few KDIFF_OPTIONS settings.
-#   bash benchmarks/batch1_table.sh [batch] ["opt list" ...]
+#   [MODE=bf16] bash benchmarks/batch1_table.sh [batch] ["opt list" ...]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 B=${1:-1}; shift
 [ $# -eq 0 ] && set -- "" "x3_min_rows=256" "x3_min_rows=128"
 cd /tmp
 for OPT in "$@"; do
-  KDIFF_OPTIONS=$OPT python $R/bench.py --batch $B --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-other-modes --no-power --no-parity --no-small-batch --kernel-table /tmp/kt.json > /tmp/b1.json 2>/dev/null
+  KDIFF_OPTIONS=$OPT python $R/bench.py --mode ${MODE:-split3} --batch $B --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-other-modes --no-power --no-parity --no-small-batch --kernel-table /tmp/kt.json > /tmp/b1.json 2>/dev/null
   python - "$OPT" <<'P'
 import json, sys
 line = [l for l in open('/tmp/b1.json') if l.startswith('{')][-1]

@@ -333,6 +333,28 @@ int kd_prof_reset(void);
  * tail and the spread of the workgroups' lifetimes (benchmarks/wg_timeline.py, benchmarks/x3r_bench.py). */
 int kd_prof_clock_buffer(void* dev_ptr);
 
+/* A forward's launch list in ONE host call (round 4).  The Python mirror issues the ~110 launches of a model call one ctypes call at a
+ * time (~6.5 us of host time each): at batch 1 - 2 that, not the device, set the pace of the bf16 mode (0.71 ms per forward against 0.55 ms
+ * of kernels).  kd_run_list walks an array of calls and invokes the entry point each one names with the arguments it carries, in order, on
+ * `stream`; it stops at the first failure, returns that entry point's code and stores the index in *failed (if not NULL).  Descriptors are
+ * passed by ADDRESS (p[0]) and read at the call, so a caller may keep patching them between runs.  Arguments of the other entry points:
+ * their pointer arguments in declaration order in p[], their int arguments in declaration order in i[], their one float (eps) in f.
+ *   KD_OP_GEMM_F32 / KD_OP_GEMM_BF16 : p[0] = const KdGemm*          KD_OP_FFN_F32 / KD_OP_FFN_BF16 : p[0] = const KdFfn*
+ *   KD_OP_ATTN_GLOBAL_F32 : p = qkv, out, scale_h, cos_t, sin_t; i = batch, T, nh, prep, precision; f = eps
+ *   KD_OP_ATTN_WINDOW_F32 : p as above; i = batch, H, W, nh, ws, shift, prep, precision        KD_OP_ATTN_NA2D_F32 : i = batch, H, W, nh, ks, prep, precision
+ *   KD_OP_ATTN_GLOBAL_BF16 : p = qkv, out; i = batch, T, nh      KD_OP_ATTN_WINDOW_BF16 : i = batch, H, W, nh, ws, shift      KD_OP_ATTN_NA2D_BF16 : i = batch, H, W, nh, ks
+ *   KD_OP_NORM_SPLIT_F32 : p = x, scale, hi, lo; i = scale_stride, rows_per_sample, M, K; f = eps */
+enum { KD_OP_GEMM_F32 = 0, KD_OP_GEMM_BF16 = 1, KD_OP_FFN_F32 = 2, KD_OP_FFN_BF16 = 3,
+       KD_OP_ATTN_GLOBAL_F32 = 4, KD_OP_ATTN_WINDOW_F32 = 5, KD_OP_ATTN_NA2D_F32 = 6,
+       KD_OP_ATTN_GLOBAL_BF16 = 7, KD_OP_ATTN_WINDOW_BF16 = 8, KD_OP_ATTN_NA2D_BF16 = 9, KD_OP_NORM_SPLIT_F32 = 10 };
+typedef struct {
+  int op;             /* KD_OP_* */
+  float f;
+  const void* p[5];
+  int i[8];
+} KdCall;
+int kd_run_list(const KdCall* calls, int n, void* stream, int* failed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,11 @@ class KdFfn(C.Structure):
     ]
 
 
+class KdCall(C.Structure):
+    """include/kdiff_hip.h KdCall: one launch of a kd_run_list list (entry point + its arguments)."""
+    _fields_ = [("op", C.c_int), ("f", C.c_float), ("p", C.c_void_p * 5), ("i", C.c_int * 8)]
+
+
 _vp, _i, _f, _ll, _d = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_double
 
 # name -> argtypes; every symbol declared in include/kdiff_hip.h
@@ -111,7 +116,46 @@ SIGNATURES = {
     "kd_prof_get": [_i, C.c_char_p, _i, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "kd_prof_reset": [],
     "kd_prof_clock_buffer": [_vp],
+    "kd_run_list": [C.POINTER(KdCall), _i, _vp, C.POINTER(C.c_int)],
 }
+
+# entry points a kd_run_list entry can name (include/kdiff_hip.h: KD_OP_*)
+RUN_LIST_OPS = {"kd_gemm_f32": 0, "kd_gemm_bf16": 1, "kd_ffn_f32": 2, "kd_ffn_bf16": 3, "kd_attn_global_f32": 4, "kd_attn_window_f32": 5,
+                "kd_attn_na2d_f32": 6, "kd_attn_global_bf16": 7, "kd_attn_window_bf16": 8, "kd_attn_na2d_bf16": 9, "kd_norm_split_f32": 10}
+
+
+def encode_call(call, name, args):
+    """Fill the KdCall ``call`` from an entry point's name and its positional arguments WITHOUT the trailing stream: pointers (None, int
+    addresses, c_void_p, or a ctypes Structure = its address) go to ``p`` in order, ints to ``i`` in order, the float to ``f`` -- the rule
+    kd_run_list unpacks by.  An argument with a ``bind_call(call, index)`` method (a pointer the caller patches per run) is told where it
+    lives.  Returns False if the entry point cannot be named in a list."""
+    op = RUN_LIST_OPS.get(name)
+    if op is None:
+        return False
+    kinds = SIGNATURES[name][:-1]
+    if len(kinds) != len(args):
+        raise ValueError(f"{name}: {len(args)} arguments for {len(kinds)} parameters")
+    call.op = op
+    n_p = n_i = 0
+    for kind, a in zip(kinds, args):
+        if kind is _i:
+            call.i[n_i] = int(a)
+            n_i += 1
+        elif kind is _f:
+            call.f = a.value if isinstance(a, C.c_float) else float(a)
+        else:
+            if hasattr(a, "bind_call"):
+                a.bind_call(call, n_p)
+                v = a.scale
+            elif isinstance(a, C.Structure):
+                v = C.addressof(a)
+            elif isinstance(a, C.c_void_p):
+                v = a.value
+            else:
+                v = a
+            call.p[n_p] = v
+            n_p += 1
+    return True
 
 _lib = None
 

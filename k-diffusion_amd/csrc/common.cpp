@@ -59,7 +59,7 @@ Opt g_opts[] = {{"skinny", {0}, {false}}, {"astat", {0}, {false}}, {"ksplit", {0
                 {"wstat_waves", {0}, {false}}, {"wstat_max_slices", {0}, {false}}, {"wstat_prefetch", {0}, {false}}, {"astat_bf16", {0}, {false}},
                 {"astat_splits", {0}, {false}}, {"tiled_bm", {0}, {false}}, {"attn_global_qw", {0}, {false}},
                 {"patch_fast", {0}, {false}}, {"ffn_fused", {0}, {false}}, {"ffn_fused_256", {0}, {false}}, {"astat_rows", {0}, {false}}, {"tiled_deep", {0}, {false}}, {"code_warm", {0}, {false}}, {"ffn_variant", {0}, {false}},
-                {"x3", {0}, {false}}, {"x3_splits", {0}, {false}}, {"ffn_x3", {0}, {false}}, {"ffn_x3_half", {0}, {false}}, {"x3_res", {0}, {false}}, {"attn_x3", {0}, {false}}, {"x3_half", {0}, {false}}, {"x3r", {0}, {false}}, {"x3_unpatch", {0}, {false}}, {"x3r_lw", {0}, {false}}, {"x3r_split", {0}, {false}}, {"tiled_lw", {0}, {false}}, {"x3_min_rows", {0}, {false}}, {"x3r_min_rows", {0}, {false}}, {"ffn_x3_min_panels_256", {0}, {false}}, {"x3s_max_rows", {0}, {false}}, {"x3s_max_wgs", {0}, {false}}, {"x3s_scale_lds", {0}, {false}}};
+                {"x3", {0}, {false}}, {"x3_splits", {0}, {false}}, {"ffn_x3", {0}, {false}}, {"ffn_x3_half", {0}, {false}}, {"x3_res", {0}, {false}}, {"attn_x3", {0}, {false}}, {"x3_half", {0}, {false}}, {"x3r", {0}, {false}}, {"x3_unpatch", {0}, {false}}, {"x3r_lw", {0}, {false}}, {"x3r_split", {0}, {false}}, {"tiled_lw", {0}, {false}}, {"x3_min_rows", {0}, {false}}, {"x3r_min_rows", {0}, {false}}, {"ffn_x3_min_panels_256", {0}, {false}}, {"x3s_max_rows", {0}, {false}}, {"x3s_max_wgs", {0}, {false}}, {"x3s_scale_lds", {0}, {false}}, {"b16s_max_rows", {0}, {false}}, {"b16s_max_wgs", {0}, {false}}, {"ffn_bf16_min_rows", {0}, {false}}};
 constexpr int N_OPTS = sizeof(g_opts) / sizeof(g_opts[0]);
 }  // namespace
 int option_index(const char* name) {
@@ -116,5 +116,46 @@ extern "C" int kd_prof_reset(void) {
   for (auto& r : g_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   g_recs.clear();
   ++g_gen;
+  return KD_OK;
+}
+
+// ---- a launch list in one host call (include/kdiff_hip.h: kd_run_list) ------------------------------------------------------------------------
+extern "C" int kd_run_list(const KdCall* calls, int n, void* stream, int* failed) {
+  if (!calls || n < 0) return kd::fail(KD_EINVAL, "kd_run_list: null list");
+  for (int k = 0; k < n; ++k) {
+    const KdCall& c = calls[k];
+    const int* i = c.i;
+    int rc;
+    switch (c.op) {
+      case KD_OP_GEMM_F32: rc = kd_gemm_f32(static_cast<const KdGemm*>(c.p[0]), stream); break;
+      case KD_OP_GEMM_BF16: rc = kd_gemm_bf16(static_cast<const KdGemm*>(c.p[0]), stream); break;
+      case KD_OP_FFN_F32: rc = kd_ffn_f32(static_cast<const KdFfn*>(c.p[0]), stream); break;
+      case KD_OP_FFN_BF16: rc = kd_ffn_bf16(static_cast<const KdFfn*>(c.p[0]), stream); break;
+      case KD_OP_ATTN_GLOBAL_F32:
+        rc = kd_attn_global_f32(static_cast<const float*>(c.p[0]), static_cast<float*>(const_cast<void*>(c.p[1])), i[0], i[1], i[2], i[3], static_cast<const float*>(c.p[2]),
+                                static_cast<const float*>(c.p[3]), static_cast<const float*>(c.p[4]), c.f, i[4], stream);
+        break;
+      case KD_OP_ATTN_WINDOW_F32:
+        rc = kd_attn_window_f32(static_cast<const float*>(c.p[0]), static_cast<float*>(const_cast<void*>(c.p[1])), i[0], i[1], i[2], i[3], i[4], i[5], i[6],
+                                static_cast<const float*>(c.p[2]), static_cast<const float*>(c.p[3]), static_cast<const float*>(c.p[4]), c.f, i[7], stream);
+        break;
+      case KD_OP_ATTN_NA2D_F32:
+        rc = kd_attn_na2d_f32(static_cast<const float*>(c.p[0]), static_cast<float*>(const_cast<void*>(c.p[1])), i[0], i[1], i[2], i[3], i[4], i[5],
+                              static_cast<const float*>(c.p[2]), static_cast<const float*>(c.p[3]), static_cast<const float*>(c.p[4]), c.f, i[6], stream);
+        break;
+      case KD_OP_ATTN_GLOBAL_BF16: rc = kd_attn_global_bf16(c.p[0], const_cast<void*>(c.p[1]), i[0], i[1], i[2], stream); break;
+      case KD_OP_ATTN_WINDOW_BF16: rc = kd_attn_window_bf16(c.p[0], const_cast<void*>(c.p[1]), i[0], i[1], i[2], i[3], i[4], i[5], stream); break;
+      case KD_OP_ATTN_NA2D_BF16: rc = kd_attn_na2d_bf16(c.p[0], const_cast<void*>(c.p[1]), i[0], i[1], i[2], i[3], i[4], stream); break;
+      case KD_OP_NORM_SPLIT_F32:
+        rc = kd_norm_split_f32(static_cast<const float*>(c.p[0]), static_cast<const float*>(c.p[1]), i[0], i[1], const_cast<void*>(c.p[2]), const_cast<void*>(c.p[3]), i[2], i[3],
+                               c.f, stream);
+        break;
+      default: rc = kd::fail(KD_EINVAL, "kd_run_list: entry %d names no entry point (op %d)", k, c.op);
+    }
+    if (rc != KD_OK) {
+      if (failed) *failed = k;
+      return rc;
+    }
+  }
   return KD_OK;
 }

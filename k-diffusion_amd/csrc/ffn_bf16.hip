@@ -466,7 +466,8 @@ using namespace kd::b16;
 
 extern "C" int kd_ffn_bf16_supported(int M, int K, int d_ff) {
   // below ~16k rows the panels do not fill the chip and the two-kernel form (row-parallel over more, smaller units) is faster
-  if (!(M >= 16384 && d_ff > 0 && d_ff % 64 == 0 && option("ffn_fused", 1))) return 0;
+  // (option "ffn_bf16_min_rows": A/B runs at small batches)
+  if (!(M >= option("ffn_bf16_min_rows", 16384) && d_ff > 0 && d_ff % 64 == 0 && option("ffn_fused", 1))) return 0;
   // K = 256: correct, but measured level with the two-kernel form (65.1 vs 65.6 us at the level-1 shape; 8 300 clocks per tile for 3 072
   // matrix clocks with one wave per SIMD) -- on request only ("ffn_fused_256")
   return (K == 128 || (K == 256 && option("ffn_fused_256", 0))) ? 1 : 0;

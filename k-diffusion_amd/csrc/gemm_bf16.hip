@@ -1342,6 +1342,7 @@ __global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* __re
 }
 
 int gemm_patch_try(const KdGemm& d, hipStream_t s, int* rc);      // patch_bf16.hip
+int gemm_b16s_try(const KdGemm& d, hipStream_t s, int* rc);       // gemm_b16s.hip
 
 }  // namespace b16
 }  // namespace kd
@@ -1394,6 +1395,7 @@ extern "C" int kd_gemm_bf16(const KdGemm* dp, void* stream) {
     return fail(KD_EINVAL, "kd_gemm_bf16: no generic kernel for a_mode=%d epi=%d N=%d", d.a_mode, d.epi, d.N);
   }
   if ((d.a_mode == KD_A_PATCH_NCHW || d.epi == KD_EPI_UNPATCH_NCHW) && !b16::gemm_patch_try(d, s, &rc)) return rc;
+  if (!b16::gemm_b16s_try(d, s, &rc)) return rc;                   // few rows (small batches): the latency form, gemm_b16s.hip
   const bool small_k = d.K == 128 || (d.K == 384 && d.N <= 128);
   if (small_k && !b16::gemm_wstat_try(d, s, &rc)) return rc;
   if (!b16::gemm_astat_try(d, s, &rc)) return rc;

@@ -37,18 +37,16 @@ from .. import ops
 from . import axial_rope
 
 D_HEAD = 64
-# KDIFF_GRAPH=1: replay the main and the per-step conditioning chain of a forward from captured hipGraphs (one host call per
-# forward) instead of issuing their 60-odd launches one by one.  Off by default: replay measured 2 % slower at batch 32 (the
-# host stays ahead of the GPU there anyway) and no faster at batch 1..8, where a forward costs ~1 ms whatever the batch --
-# ~15 us per DEPENDENT kernel on the device, which a graph of the same kernels does not shorten
-# (profiles/r02_small_batch_graph.log).
+# KDIFF_GRAPH: replay the main and the per-step conditioning chain of a forward from captured hipGraphs (one host call per forward)
+# instead of issuing their ~110 launches (see _graph_policy: `auto`, the default, does so for the bf16 mode at batch 1 - 2 only; replay is
+# 2 - 6 % slower wherever the device sets the pace -- profiles/r04_small_batch.log, profiles/r02_small_batch_graph.log).
 # Largest [steps, B, scale_width] scale table kept per sigma schedule (prefetch_schedule); longer schedules use the per-step chain.
 SCHEDULE_TABLE_MAX_BYTES = 1 << 30
 SCHEDULES_KEPT = 4            # a run of a two-stage solver hints two tables; older records (and their tensors) are dropped
 SCHEDULE_CHAINS_KEPT = 2      # conditioning workspaces kept per plan, by schedule length (least recently used dropped)
 # environment switches read while a plan is built (name, default): part of the plan key
-PLAN_SWITCHES = (("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "0"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "1"), ("KDIFF_X3_PLANES", "1"),
-                 ("KDIFF_X3_DOWN", "0"))
+PLAN_SWITCHES = (("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "auto"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "1"), ("KDIFF_X3_PLANES", "1"),
+                 ("KDIFF_X3_DOWN", "0"), ("KDIFF_RUN_LIST", "1"))
 CLASS_IDS_KEPT = 4            # range-checked class_cond tensors remembered per plan (cond / uncond pairs of a guidance wrapper)
 
 
@@ -61,11 +59,19 @@ def _ver(t):
     return next(_untracked) if t.is_inference() else t._version
 
 
-def _graph_policy():
-    mode = os.environ.get("KDIFF_GRAPH", "0").lower()
-    if mode not in ("0", "1"):
-        raise ValueError(f"KDIFF_GRAPH={mode!r}: expected 0 or 1")
-    return mode == "1"
+GRAPH_AUTO_MAX_TOKENS = 8192          # level-0 tokens of a forward (batch x grid) up to which `auto` replays the bf16 mode from graphs
+
+
+def _graph_policy(bf16, tokens):
+    """KDIFF_GRAPH: 0 = issue the launch lists directly, 1 = replay them from captured hipGraphs, auto (default) = replay where it was
+    measured faster: the bf16 mode up to GRAPH_AUTO_MAX_TOKENS level-0 tokens (batch 1 - 2 at 256 x 256).  There the kernels of a forward
+    take ~0.55 ms while the host needs ~0.72 ms to issue their ~110 launches (~6.5 us each, most of it inside hipLaunchKernel: handing the
+    list over in one call, kd_run_list, only saves 2 - 6 %): replay 0.56 against 0.72 ms at batch 1, 0.68 against 0.74 at batch 2, level at
+    batch 4.  The fp32-parity mode is device-bound from batch 1 on (0.72 ms of kernels) and replay costs it 6 % (0.77): direct."""
+    mode = os.environ.get("KDIFF_GRAPH", "auto").lower()
+    if mode not in ("0", "1", "auto"):
+        raise ValueError(f"KDIFF_GRAPH={mode!r}: expected 0, 1 or auto")
+    return mode == "1" or (mode == "auto" and bf16 and tokens <= GRAPH_AUTO_MAX_TOKENS)
 
 
 # ---------------------------------------------------------------------------------- configuration
@@ -158,10 +164,11 @@ def _rms_scale(n):
 # ---------------------------------------------------------------------------------- the plan
 
 class _Launch:
-    __slots__ = ("fn", "args", "what")
+    __slots__ = ("fn", "args", "what", "enc")
 
-    def __init__(self, fn, args, what):
-        self.fn, self.args, self.what = fn, args, what
+    def __init__(self, fn, args, what, enc=None):
+        # enc: (entry point name, its arguments without the stream) for a kd_run_list entry; None = only callable from Python
+        self.fn, self.args, self.what, self.enc = fn, args, what, enc
 
 
 def _ptr(t):
@@ -244,7 +251,7 @@ class _Plan:
             grids.append((gh // 2, gw // 2))
         self.B, self.grids = B, grids
         self.out_shape = (B, m.out_channels, H, W)
-        self.use_graph = _graph_policy()
+        self.use_graph = _graph_policy(bf, B * grids[0][0] * grids[0][1])
         self.graphs, self.cond_graphs = {}, {}              # captured main chains / conditioning chains (see replay())
         self.g_x = self.g_out = self.capture_stream = None   # their fixed input / output images
         self.direct_runs = self.direct_cond_runs = 0
@@ -322,11 +329,12 @@ class _Plan:
                 if len(qk) >= 6:                                     # split3: positions / frequencies for the round-3 kernels (gemm_x3*.hip)
                     d.rope_pos, d.rope_freq = qk[4].data_ptr(), qk[5].data_ptr()
             (self.keep if main else chain.keep).append(d)
-            target.append(_Launch(lib.kd_gemm_bf16 if d.precision == nat.PREC_BF16 else lib.kd_gemm_f32, (C.byref(d),), what))
+            target.append(_Launch(lib.kd_gemm_bf16 if d.precision == nat.PREC_BF16 else lib.kd_gemm_f32, (C.byref(d),), what,
+                                  enc=("kd_gemm_bf16" if d.precision == nat.PREC_BF16 else "kd_gemm_f32", (d,))))
             return d
 
         def call(what, fn, *args):
-            target.append(_Launch(fn, args, what))
+            target.append(_Launch(fn, args, what, enc=(fn.__name__, args)))
 
         def build_cond(rows):
             """The conditioning chain (image_transformer_v2.py:734-740, :569-581) for ``rows`` rows: FourierFeatures ->
@@ -391,7 +399,21 @@ class _Plan:
             return ("table", 4 * offsets[name])
 
         class _ScaleRef:                                    # patched per run like the descriptors in norm_descs
-            scale = None
+            def __init__(self):
+                self._scale, self._call, self._index = None, None, 0
+
+            def bind_call(self, call, index):               # (nat.encode_call: this pointer lives in a kd_run_list entry too)
+                self._call, self._index = call, index
+
+            @property
+            def scale(self):
+                return self._scale
+
+            @scale.setter
+            def scale(self, v):
+                self._scale = v
+                if self._call is not None:
+                    self._call.p[self._index] = v
 
         def norm_split(what, x_t, table_off, T_, d_, rps_):
             """AdaRMSNorm of the fp32 rows of ``x_t`` -> (hi, lo) bf16 planes in ``xn`` (kd_norm_split_f32)."""
@@ -400,7 +422,7 @@ class _Plan:
             hi_p, lo_p = xn.data_ptr(), xn.data_ptr() + 2 * T_ * d_
             xp = x_t.data_ptr()
             target.append(_Launch(lambda stream, ref=ref: lib.kd_norm_split_f32(xp, ref.scale, total, rps_, hi_p, lo_p, T_, d_, 1e-6, stream),
-                                  (), what + " (split)"))
+                                  (), what + " (split)", enc=("kd_norm_split_f32", (xp, ref, total, rps_, hi_p, lo_p, T_, d_, 1e-6))))
             return (hi_p, lo_p)
 
         packed_qkv = precision == nat.PREC_SPLIT3 and os.environ.get("KDIFF_QKV_PACKED", "1") != "0"
@@ -481,7 +503,7 @@ class _Plan:
                 fd.M, fd.K, fd.d_ff = T, d, lv.d_ff
                 self.norm_descs.append((fd, scale_ptr(prefix + "ff.norm")[1]))
                 self.keep.append(fd)
-                target.append(_Launch(lib.kd_ffn_f32, (C.byref(fd),), prefix + "ff"))
+                target.append(_Launch(lib.kd_ffn_f32, (C.byref(fd),), prefix + "ff", enc=("kd_ffn_f32", (fd,))))
             elif ffn_bf:
                 # the whole FeedForwardBlock (:487-493) in one kernel: the d_ff-wide hidden activation stays on the chip (width 128: with
                 # the attention block's out projection in front of it)
@@ -496,7 +518,7 @@ class _Plan:
                 fd.M, fd.K, fd.d_ff = T, d, lv.d_ff
                 self.norm_descs.append((fd, scale_ptr(prefix + "ff.norm")[1]))
                 self.keep.append(fd)
-                target.append(_Launch(lib.kd_ffn_bf16, (C.byref(fd),), prefix + "ff"))
+                target.append(_Launch(lib.kd_ffn_bf16, (C.byref(fd),), prefix + "ff", enc=("kd_ffn_bf16", (fd,))))
             else:
                 # hidden activation as planes when the down projection's tiled form fills the chip (256-row x 128-feature tiles)
                 hid_planes = None
@@ -531,6 +553,7 @@ class _Plan:
         self.d_patch_out = gemm("patch_out", xs[0], m.patch_out.proj.weight, None, toks[0], m.out_channels * ph * pw, levels[0].width,
                                 epi=nat.EPI_UNPATCH_NCHW, scale_ptr=m.out_norm.scale.data_ptr(), scale_stride=0,
                                 rows_per_sample=grids[0][0] * grids[0][1], grid=grids[0], patch=(ph, pw, m.out_channels))
+        self._encode_launches()
 
     def run_cond(self, buf, stream):
         """Per-step conditioning chain into scale table ``buf`` on ``stream``; its inputs were filled by the caller on the
@@ -553,10 +576,28 @@ class _Plan:
             pin.sigma, pout.sigma, pout.R = sp, sp, x.data_ptr()
             pin.sigma_data = pout.sigma_data = float(sigma_data)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if self.calls is not None:
+            # the whole list in one host call (kd_run_list): ~6.5 us of Python / ctypes per launch otherwise, which at batch 1 - 2 is more
+            # than the kernels of the bf16 mode take
+            rc = self.run_list(self.calls, len(self.launches), stream, C.byref(self.failed))
+            if rc:
+                nat.check(rc, self.launches[self.failed.value].what)
+            return
         for ln in self.launches:
             rc = ln.fn(*ln.args, stream)
             if rc:
                 nat.check(rc, ln.what)
+
+    def _encode_launches(self):
+        """The main chain as a kd_run_list array, if every launch of it can be named there (and KDIFF_RUN_LIST is not 0)."""
+        self.calls, self.failed, self.run_list = None, C.c_int(0), nat.lib().kd_run_list
+        if os.environ.get("KDIFF_RUN_LIST", "1") == "0" or not self.launches or any(ln.enc is None for ln in self.launches):
+            return
+        calls = (nat.KdCall * len(self.launches))()
+        for call, ln in zip(calls, self.launches):
+            if not nat.encode_call(call, *ln.enc):
+                return
+        self.calls = calls
 
     # ---- hipGraph replay (launch-bound batch sizes only: ``use_graph``) ---------------------------------------------------
     def _capture(self, issue):

@@ -540,3 +540,32 @@ def test_oracle_brownian_tree_stands_in_for_torchsde():
 def ob_ref_available():
     from oracle import ref_import
     return ref_import.available()
+
+
+def test_run_list_entries_are_packed_by_the_rule_the_library_unpacks_by():
+    """kd_run_list (include/kdiff_hip.h): pointer arguments in declaration order in p[], int arguments in i[], the float in f; a descriptor
+    goes in by address; an argument patched per run is told its slot.  Host logic only: no launch."""
+    import ctypes as C
+    import k_diffusion_amd as K
+    nat = K._native
+    assert C.sizeof(nat.KdCall) == 80 and nat.KdCall.p.offset == 8 and nat.KdCall.i.offset == 48        # the C struct's layout
+    c = nat.KdCall()
+    assert nat.encode_call(c, "kd_attn_window_f32", (C.c_void_p(16), C.c_void_p(32), 2, 8, 16, 4, 8, 4, 2, None, None, None, C.c_float(1e-6), 1))
+    assert c.op == 5 and list(c.i) == [2, 8, 16, 4, 8, 4, 2, 1] and [c.p[k] for k in range(5)] == [16, 32, None, None, None] and abs(c.f - 1e-6) < 1e-12
+    d = nat.KdGemm()
+    assert nat.encode_call(c, "kd_gemm_bf16", (d,)) and c.op == 1 and c.p[0] == C.addressof(d)
+
+    class Ref:
+        scale = 4096
+
+        def bind_call(self, call, index):
+            self.where = (call, index)
+    r = Ref()
+    assert nat.encode_call(c, "kd_norm_split_f32", (64, r, 128, 256, 512, 1024, 256, 128, 1e-6))
+    assert c.op == 10 and r.where[1] == 1 and [c.p[k] for k in range(4)] == [64, 4096, 512, 1024] and list(c.i)[:4] == [128, 256, 256, 128]
+    assert not nat.encode_call(c, "kd_rmsnorm_f32", (1, 2, 3, 4, 5, 1e-6))             # not an entry point a list can name
+    with pytest.raises(ValueError):
+        nat.encode_call(c, "kd_gemm_f32", (d, 1))
+    # every name in the table is a declared entry point whose last parameter is the stream
+    for name in nat.RUN_LIST_OPS:
+        assert nat.SIGNATURES[name][-1] is C.c_void_p

@@ -37,10 +37,12 @@ def throughput_kernels(request, KD):
         yield
         return
     KD._native.set_option("x3s_max_rows", 0)
+    KD._native.set_option("b16s_max_rows", 0)                 # (its bf16 sibling, csrc/gemm_b16s.hip)
     try:
         yield
     finally:
-        KD._native.set_option("x3s_max_rows", -2 ** 31)       # back to the built-in default
+        KD._native.set_option("x3s_max_rows", -2 ** 31)       # back to the built-in defaults
+        KD._native.set_option("b16s_max_rows", -2 ** 31)
 
 
 def _prof_names(nat):
@@ -958,6 +960,74 @@ def test_split3_few_rows_latency_kernel(KD, ops, monkeypatch, request, H, W, nh,
         a, b = (got[k], old[k]) if k != "packed" else (got["qkv"], old["qkv"])
         assert relerr(a, b) < 1e-4, k
     assert not torch.equal(got["qkv"], old["qkv"])
+
+
+@pytest.mark.few_rows
+@pytest.mark.parametrize("H,W,nh,B,K", [(16, 16, 8, 1, 512), (7, 7, 4, 4, 256), (32, 32, 4, 1, 256), (9, 12, 2, 3, 128), (6, 6, 1, 4, 64), (16, 16, 18, 2, 384)])
+def test_bf16_few_rows_latency_kernel(KD, ops, request, H, W, nh, B, K):
+    """The few-rows form of the bf16 projections (round 4, csrc/gemm_b16s.hip: the bf16 sibling of gemm_x3s.hip) at batch-1 shapes of the
+    headline config, 49 tokens per sample (a 32-row group spans samples), ragged row counts, 18 heads, K = 64: every epilogue against the
+    oracle on bf16-rounded operands at the bf16 kernels' tolerances, against the throughput kernels (same roundings, another summation
+    order: within a bf16 step), and bit-identical from run to run."""
+    from k_diffusion_amd import _native as nat
+    T, d, M = H * W, nh * 64, B * H * W
+    x, scale = rn(B, T, K, seed=8), 1 + 0.2 * rn(B, K, seed=9)
+    xn = hdit.rms_norm(_rt(x), scale[:, None, :])
+    w = rn(3 * d, K, seed=10, scale=K ** -0.5)
+    qs = torch.linspace(5.0, 12.0, nh)
+    pos, freqs = hdit.axial_pos(H, W).reshape(T, 2), hdit.rope_freqs(nh)
+    qk = (g(qs), g(pos.contiguous()), g((freqs / (2 * np.pi)).contiguous()), nh)
+    theta = hdit.rope_theta(hdit.axial_pos(H, W), freqs)
+    wg = rn(2 * 3 * K, K, seed=11, scale=K ** -0.5)
+    ws = rn(256, K, seed=12, scale=K ** -0.5)
+    wd = rn(K, 3 * K, seed=13, scale=(3 * K) ** -0.5)
+    hid, res = rn(B, T, 3 * K, seed=15), rn(B, T, K, seed=14)
+    PB = nat.PREC_BF16
+
+    def run_all():
+        out = {}
+        out["qkv"] = ops.norm_linear(_bf(x), g(scale), g(w), rows_per_sample=T, epi=nat.EPI_QKV, qk=qk)
+        out["geglu"] = ops.norm_linear(_bf(x), g(scale), g(wg), rows_per_sample=T, epi=nat.EPI_GEGLU)
+        out["shared"] = ops.norm_linear(_bf(x), g(scale[0].contiguous()), g(ws), rows_per_sample=T)
+        out["plain"] = ops.gemm(_bf(hid), g(wd), torch.empty(M, K, device=DEV, dtype=BF), M=M, N=K, K=3 * K, precision=PB)
+        out["res"] = ops.gemm(_bf(hid), g(wd), torch.empty(M, K, device=DEV, dtype=BF), M=M, N=K, K=3 * K, epi=nat.EPI_RESIDUAL, residual=_bf(res), precision=PB)
+        inplace = _bf(res).clone()
+        ops.gemm(_bf(hid), g(wd), inplace, M=M, N=K, K=3 * K, epi=nat.EPI_RESIDUAL, residual=inplace, precision=PB)
+        out["inplace"] = inplace
+        return out
+
+    nat.set_option("b16s_max_wgs", 1 << 20)        # (by default the kernel takes grids of one round, two behind a norm at few rows: here every shape)
+    request.addfinalizer(lambda: nat.set_option("b16s_max_wgs", -2 ** 31))
+    nat.lib().kd_prof_reset()
+    nat.lib().kd_prof_enable(1)
+    try:
+        got = run_all()
+        torch.cuda.synchronize()
+        names = _prof_names(nat)
+    finally:
+        nat.lib().kd_prof_enable(0)
+        nat.lib().kd_prof_reset()
+    assert sum(n.startswith("gemm_bf16_few_rows") for n in names) == 6, names
+    qkv = got["qkv"].float().cpu().view(B, H, W, 3, nh, 64)
+    ref = (xn @ _rt(w).T).view(B, H, W, 3, nh, 64)
+    q_ref, k_ref = hdit.cosine_sim_scale(ref[..., 0, :, :], ref[..., 1, :, :], qs)
+    assert relerr(qkv[..., 0, :, :], hdit.apply_rope(q_ref, theta)) < 1.2e-2
+    assert relerr(qkv[..., 1, :, :], hdit.apply_rope(k_ref, theta)) < 1.2e-2
+    assert relerr(qkv[..., 2, :, :], ref[..., 2, :, :]) < 1.2e-2
+    assert relerr(got["geglu"], hdit.linear_geglu(xn, _rt(wg))) < 1.5e-2
+    assert relerr(got["shared"], hdit.rms_norm(_rt(x), scale[0]) @ _rt(ws).T) < 1.2e-2
+    assert relerr(got["plain"], _rt(hid).view(M, -1) @ _rt(wd).T) < 1.2e-2
+    assert relerr(got["res"], _rt(hid).view(M, -1) @ _rt(wd).T + _rt(res).view(M, -1)) < 1.2e-2
+    assert torch.equal(got["inplace"].view(M, K), got["res"])
+    again = run_all()
+    assert all(torch.equal(got[k], again[k]) for k in got)
+    nat.set_option("b16s_max_rows", 0)
+    try:
+        old = run_all()
+    finally:
+        nat.set_option("b16s_max_rows", -2 ** 31)
+    for k in got:
+        assert relerr(got[k], old[k]) < 1e-2, k
 
 
 @pytest.mark.parametrize("B,H,W,C,N", [(2, 32, 32, 128, 256), (3, 16, 24, 256, 512), (1, 48, 40, 64, 128)])
