@@ -53,7 +53,11 @@ const char* kd_last_error(void);
  *   bf16 kernels : "bf16_fast" (1; 0 = generic kernel only) "wstat" (1) "wstat_waves" (0 = per shape) "wstat_max_slices" (24)
  *                  "wstat_prefetch" (0; 1 next-chunk prefetch, 2 software-pipelined tiles) "astat_bf16" (1) "astat_splits" (0 = auto)
  *                  "tiled_bm" (0 = auto, 128, 256) "tiled_lw" (1; 0 = no loader waves in the tiled kernel at one tile per CU) "attn_global_qw" (8) "patch_fast" (1; 0 = patch-in / patch-out through the generic kernel)
- *                  "ffn_fused" (1; 0 = kd_ffn_bf16_supported answers no) "ffn_fused_256" (0)
+ *                  "ffn_fused" (1; 0 = kd_ffn_bf16_supported answers no) "ffn_fused_256" (0) "ffn_bf16_min_rows" (16384: rows from which
+ *                  kd_ffn_bf16_supported advises the fused block)
+ *                  "b16s_max_rows" (4096; 0 = off) the few-rows latency form of the bf16 projections (gemm_b16s.hip, the bf16 sibling of
+ *                  gemm_x3s.hip), taken up to that many rows where its grid is one round of the chip (two behind a norm at <= 512 rows);
+ *                  "b16s_max_wgs" (-1; >= 0: a cap on the grid instead)
  *                  "code_warm" (8: the first wave of that many workgroups of a launch -- one per XCD -- reads the kernel's own code
  *                  range into L2 at entry, so that a kernel that has not run for a while does not walk its code through one
  *                  instruction-cache miss after the other; 0 = off.  Pure prefetch: results do not depend on it) */
