@@ -308,3 +308,7 @@ int gemm_b16s_try(const KdGemm& d, hipStream_t s, int* rc) {
 
 }  // namespace b16
 }  // namespace kd
+
+// Not a code-warm-up user, but its code object ends like those of the kernels that are (kd_common.h): 36 KiB of s_nop behind the last kernel,
+// so that an instruction fetch running ahead of a wave's last instructions stays inside the loaded image whatever the loader put behind it.
+KD_TEXT_PAD(gemm_b16s)

@@ -468,3 +468,7 @@ int gemm_x3s_try(const GemmP& d, hipStream_t s, int* rc) {
 }
 
 }  // namespace kd
+
+// Not a code-warm-up user, but its code object ends like those of the kernels that are (kd_common.h): 36 KiB of s_nop behind the last kernel,
+// so that an instruction fetch running ahead of a wave's last instructions stays inside the loaded image whatever the loader put behind it.
+KD_TEXT_PAD(gemm_x3s)
