@@ -337,9 +337,8 @@ int kd_prof_reset(void);
  * tail and the spread of the workgroups' lifetimes (benchmarks/wg_timeline.py, benchmarks/x3r_bench.py). */
 int kd_prof_clock_buffer(void* dev_ptr);
 
-/* A forward's launch list in ONE host call (round 4).  The Python mirror issues the ~110 launches of a model call one ctypes call at a
- * time (~6.5 us of host time each): at batch 1 - 2 that, not the device, set the pace of the bf16 mode (0.71 ms per forward against 0.55 ms
- * of kernels).  kd_run_list walks an array of calls and invokes the entry point each one names with the arguments it carries, in order, on
+/* A forward's launch list in ONE host call (round 4).  The Python mirror used to issue the 58 - 66 launches of a model call one ctypes call
+ * at a time; kd_run_list walks an array of calls and invokes the entry point each one names with the arguments it carries, in order, on
  * `stream`; it stops at the first failure, returns that entry point's code and stores the index in *failed (if not NULL).  Descriptors are
  * passed by ADDRESS (p[0]) and read at the call, so a caller may keep patching them between runs.  Arguments of the other entry points:
  * their pointer arguments in declaration order in p[], their int arguments in declaration order in i[], their one float (eps) in f.

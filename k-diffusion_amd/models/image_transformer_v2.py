@@ -37,20 +37,32 @@ from .. import ops
 from . import axial_rope
 
 D_HEAD = 64
-# KDIFF_GRAPH: replay the main and the per-step conditioning chain of a forward from captured hipGraphs (one host call per forward)
-# instead of issuing their ~110 launches (see _graph_policy: `auto`, the default, does so for the bf16 mode at batch 1 - 2 only; replay is
-# 2 - 6 % slower wherever the device sets the pace -- profiles/r04_small_batch.log, profiles/r02_small_batch_graph.log).
+# KDIFF_GRAPH=1: replay the main and the per-step conditioning chain of a forward from captured hipGraphs (one host call per forward)
+# instead of issuing their launches.  Off by default: slower at every batch size (see _graph_policy).
 # Largest [steps, B, scale_width] scale table kept per sigma schedule (prefetch_schedule); longer schedules use the per-step chain.
 SCHEDULE_TABLE_MAX_BYTES = 1 << 30
 SCHEDULES_KEPT = 4            # a run of a two-stage solver hints two tables; older records (and their tensors) are dropped
 SCHEDULE_CHAINS_KEPT = 2      # conditioning workspaces kept per plan, by schedule length (least recently used dropped)
 # environment switches read while a plan is built (name, default): part of the plan key
-PLAN_SWITCHES = (("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "auto"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "1"), ("KDIFF_X3_PLANES", "1"),
+PLAN_SWITCHES = (("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "0"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "1"), ("KDIFF_X3_PLANES", "1"),
                  ("KDIFF_X3_DOWN", "0"), ("KDIFF_RUN_LIST", "1"))
 CLASS_IDS_KEPT = 4            # range-checked class_cond tensors remembered per plan (cond / uncond pairs of a guidance wrapper)
 
 
 _untracked = itertools.count(-1, -1)
+
+# bumped whenever ANY module registers a parameter, a buffer or a sub-module (assignment of an nn.Parameter / register_buffer / a new child):
+# the models' cached tensor lists (_weights_fingerprint) are rebuilt after that
+_registration_epoch = [0]
+
+
+def _note_registration(*_args):
+    _registration_epoch[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_note_registration)
+torch.nn.modules.module.register_module_buffer_registration_hook(_note_registration)
+torch.nn.modules.module.register_module_module_registration_hook(_note_registration)
 
 
 def _ver(t):
@@ -59,19 +71,16 @@ def _ver(t):
     return next(_untracked) if t.is_inference() else t._version
 
 
-GRAPH_AUTO_MAX_TOKENS = 8192          # level-0 tokens of a forward (batch x grid) up to which `auto` replays the bf16 mode from graphs
-
-
-def _graph_policy(bf16, tokens):
-    """KDIFF_GRAPH: 0 = issue the launch lists directly, 1 = replay them from captured hipGraphs, auto (default) = replay where it was
-    measured faster: the bf16 mode up to GRAPH_AUTO_MAX_TOKENS level-0 tokens (batch 1 - 2 at 256 x 256).  There the kernels of a forward
-    take ~0.55 ms while the host needs ~0.72 ms to issue their ~110 launches (~6.5 us each, most of it inside hipLaunchKernel: handing the
-    list over in one call, kd_run_list, only saves 2 - 6 %): replay 0.56 against 0.72 ms at batch 1, 0.68 against 0.74 at batch 2, level at
-    batch 4.  The fp32-parity mode is device-bound from batch 1 on (0.72 ms of kernels) and replay costs it 6 % (0.77): direct."""
-    mode = os.environ.get("KDIFF_GRAPH", "auto").lower()
-    if mode not in ("0", "1", "auto"):
-        raise ValueError(f"KDIFF_GRAPH={mode!r}: expected 0, 1 or auto")
-    return mode == "1" or (mode == "auto" and bf16 and tokens <= GRAPH_AUTO_MAX_TOKENS)
+def _graph_policy():
+    """KDIFF_GRAPH: 0 (default) = issue the launch lists directly, 1 = replay them from captured hipGraphs.  Replay is 6 - 16 % slower than
+    direct issue at every batch size and in both modes (round 4, profiles/r04_small_batch.log: 0.59 against 0.51 ms per forward at batch 1
+    in the bf16 mode, 0.76 against 0.70 in the fp32-parity mode): the host needs ~0.2 ms to issue a forward's launches (kd_run_list, 3 us
+    each), well under what the kernels take even at batch 1.  (Earlier in round 4 replay looked 22 % FASTER for the bf16 mode at batch 1: the
+    host was then spending 0.3 - 0.4 ms per model call walking the module tree for its weights fingerprint -- see _weights_fingerprint.)"""
+    mode = os.environ.get("KDIFF_GRAPH", "0").lower()
+    if mode not in ("0", "1"):
+        raise ValueError(f"KDIFF_GRAPH={mode!r}: expected 0 or 1")
+    return mode == "1"
 
 
 # ---------------------------------------------------------------------------------- configuration
@@ -251,7 +260,7 @@ class _Plan:
             grids.append((gh // 2, gw // 2))
         self.B, self.grids = B, grids
         self.out_shape = (B, m.out_channels, H, W)
-        self.use_graph = _graph_policy(bf, B * grids[0][0] * grids[0][1])
+        self.use_graph = _graph_policy()
         self.graphs, self.cond_graphs = {}, {}              # captured main chains / conditioning chains (see replay())
         self.g_x = self.g_out = self.capture_stream = None   # their fixed input / output images
         self.direct_runs = self.direct_cond_runs = 0
@@ -703,6 +712,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         self.out_norm = _rms_scale(levels[0].width)
         self.patch_out = _Holder(proj=_linear_weight(out_channels * ph * pw, levels[0].width, zero=True))
         self._plans, self._fingerprint, self._packed, self._plans_epoch = {}, None, {}, None
+        self._fp_tensors, self._fp_tracked, self._fp_epoch = (), (), -1
 
     # ---- bookkeeping ---------------------------------------------------------------------------
     def _ada_norm_modules(self):
@@ -748,7 +758,14 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         return ent[1]
 
     def _weights_fingerprint(self):
-        return tuple((t.data_ptr(), 0 if t.is_inference() else t._version) for t in list(self.parameters()) + list(self.buffers()))
+        """(address, version) of every parameter and buffer: a changed entry drops the plans and the packed weight images.  Walked on every
+        model call, so the LIST of tensors is kept (torch's module traversal -- parameters() / buffers() over ~90 sub-modules -- took
+        0.3 - 0.4 ms per call, more than the launches of a batch-1 forward) and rebuilt only after a parameter, buffer or sub-module was
+        registered anywhere (_registration_epoch); what is read per call is the two counters of each tensor."""
+        if self._fp_epoch != _registration_epoch[0]:
+            ts = list(self.parameters()) + list(self.buffers())
+            self._fp_tensors, self._fp_tracked, self._fp_epoch = tuple(ts), tuple(not t.is_inference() for t in ts), _registration_epoch[0]
+        return tuple([(t.data_ptr(), t._version if tr else 0) for t, tr in zip(self._fp_tensors, self._fp_tracked)])
 
     def param_groups(self, base_lr=5e-4, mapping_lr_scale=1 / 3):
         raise NotImplementedError("training is outside this package's scope (sampling hot path only)")
