@@ -17,7 +17,6 @@
 // Same arithmetic as the throughput kernels (3 bf16 MFMA terms per product, fp32 accumulate) in another summation order.
 #include "x3_common.h"
 #include <cstdio>
-#include <cstdlib>
 
 namespace kd {
 namespace x3s {
@@ -452,8 +451,7 @@ int gemm_x3s_try(const GemmP& d, hipStream_t s, int* rc) {
   const double bytes = 4.0 * ((double)d.M * d.K + n_eff * d.K + (double)d.M * d.N * (d.epi == KD_EPI_RESIDUAL ? 2 : 1));
   char nm[96] = "gemm_x3s";
   if (prof_on()) snprintf(nm, sizeof(nm), "gemm_x3s<n%d,e%d> M=%d N=%d K=%d", sc, d.epi, d.M, d.N, d.K);
-  static const bool trace = getenv("KDIFF_X3S_TRACE") != nullptr;      // debugging aid: one line per launch, the stream drained in front of it
-  if (trace) {
+  if (option("x3s_trace", 0)) {                 // debugging aid (kd_set_option): one line per launch on stderr, the stream drained in front of it
     fprintf(stderr, "x3s: epi=%d norm=%d M=%d N=%d K=%d rps=%d stride=%d heads=%d packed=%d c_split=%d A=%p Wp=%p C=%p R=%p scale=%p pos=%p freq=%p\n", d.epi, d.norm, d.M, d.N, d.K,
             a.rows_per_sample, a.scale_stride, a.n_heads, a.qkv_packed, a.c_split, (const void*)a.A, (const void*)a.Wp, (void*)a.C, (const void*)a.R, (const void*)a.scale, (const void*)a.pos, (const void*)a.freq);
     (void)hipStreamSynchronize(s);
