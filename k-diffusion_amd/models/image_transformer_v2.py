@@ -747,6 +747,14 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         freq = sa.pos_emb.freqs.detach().to(torch.float32).cpu() / (2.0 * math.pi)
         return pos.reshape(-1, 2).to(torch.float32).contiguous().to(device), freq.contiguous().to(device)
 
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .half(): normally the same Parameter objects with new .data (seen through their addresses), but with
+        # torch.__future__.set_overwrite_module_params_on_conversion(True) NEW Parameters written straight into the dicts, past the
+        # registration hooks: rebuild the kept tensor list after any conversion
+        out = super()._apply(fn, *args, **kwargs)
+        _note_registration()
+        return out
+
     def _packed_image(self, W, N, K, geglu, bf16=False):
         """Packed image of a weight (split-bf16, or plain bf16 for the bf16 mode), shared by all plans of this model.  The
         entry keeps the source tensor alive, so its address cannot be recycled under the cached image; the dict is dropped
