@@ -569,3 +569,43 @@ def test_run_list_entries_are_packed_by_the_rule_the_library_unpacks_by():
     # every name in the table is a declared entry point whose last parameter is the stream
     for name in nat.RUN_LIST_OPS:
         assert nat.SIGNATURES[name][-1] is C.c_void_p
+
+
+def test_weights_fingerprint_keeps_its_tensor_list_and_still_sees_every_change():
+    """The per-call weights check of the model (round 4): the list of parameters / buffers is kept between calls -- walking the module tree
+    cost 0.3 - 0.4 ms per model call -- and rebuilt when torch registers a parameter, buffer or sub-module, or converts the module.  Host
+    logic only (no device): every way a weight can change must move the fingerprint, and an untouched model must not walk the tree again."""
+    import torch
+    import k_diffusion_amd as K
+    from k_diffusion_amd.models import image_transformer_v2 as itv2
+    cfg = K.config.load_config(os.path.join(REPO, "configs", "config_mnist_transformer.json"))
+    m = K.config.make_model(cfg).eval().requires_grad_(False)
+    f0 = m._weights_fingerprint()
+    assert len(f0) == len(list(m.parameters())) + len(list(m.buffers()))
+    walked = []
+    orig = type(m).parameters
+    try:
+        type(m).parameters = lambda self, *a, **k: (walked.append(1), orig(self, *a, **k))[1]
+        assert m._weights_fingerprint() == f0 and not walked                      # unchanged: the kept list, no traversal
+        m.load_state_dict(K.synth.synth_state_dict(m.state_dict(), seed=1))     # in-place copies: versions move
+        f1 = m._weights_fingerprint()
+        assert f1 != f0 and not walked
+        with torch.no_grad():
+            m.out_norm.scale.mul_(2.0)
+        f2 = m._weights_fingerprint()
+        assert f2 != f1 and not walked
+        m.patch_in.proj.weight = torch.nn.Parameter(torch.zeros_like(m.patch_in.proj.weight), requires_grad=False)      # a new tensor object
+        f3 = m._weights_fingerprint()
+        assert f3 != f2 and walked and any(t is m.patch_in.proj.weight for t in m._fp_tensors)
+        del walked[:]
+        p = m.mapping.out_norm.scale
+        p.data = p.data.clone()                                                   # same Parameter, other storage (what Module.to() does)
+        f4 = m._weights_fingerprint()
+        assert f4 != f3 and not walked
+        m.double()                                                                # a conversion: list rebuilt
+        assert m._weights_fingerprint() != f4 and walked
+        epoch = itv2._registration_epoch[0]
+        torch.nn.Linear(2, 2)                                                     # ANY registration anywhere bumps the epoch (cheap, conservative)
+        assert itv2._registration_epoch[0] > epoch
+    finally:
+        type(m).parameters = orig
