@@ -44,7 +44,7 @@ BF16_MFMA_SUSTAINED_TFLOPS = 2000.0  # measured: a pure MFMA kernel on all 256 C
 HBM_PEAK_GBS = 8000.0              # HBM3E spec (6.3 TB/s is the measured streaming ceiling)
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3, help="timed passes (each = one full sampling run of a batch)")
@@ -66,7 +66,13 @@ def parse():
     p.add_argument("--no-power", action="store_true", help="skip the socket power / shader clock samples (a few extra untimed passes with rocm-smi beside them)")
     p.add_argument("--no-small-batch", action="store_true", help="skip the batch-1 / batch-4 latency entries (`small_batch`)")
     p.add_argument("--no-parity", action="store_true", help="skip the golden-vector parity block (5-step batch-32 run per measured mode)")
-    return p.parse_args()
+    p.add_argument("--no-job", action="store_true", help="skip the `job` block (the sample.py CLI job timed end to end: noise draw -> finished images)")
+    p.add_argument("--job-images", type=int, default=512, help="images of the timed CLI job (`job`)")
+    p.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="process-group backend (default: nccl = RCCL on a GPU box; gloo is for the "
+                                                                              "launcher's CPU test together with --stub-workload)")
+    p.add_argument("--stub-workload", action="store_true",
+                   help="launcher / rank-plumbing test: a tiny CPU tensor op per pass instead of the sampler (no GPU, no kernels; the line says so and is no measurement)")
+    return p.parse_args(argv)
 
 
 def build_model(cfg, device, seed):
@@ -279,6 +285,44 @@ def small_batch_latency(cfg, model, dev, args, measured_modes, batches=(1, 4)):
     return {"workload": f"{os.path.basename(args.config)}, {args.sampler} {args.sampler_steps} steps, 3 timed runs per entry", **out}
 
 
+def job_rate(args, modes, dev):
+    """The job the CLI runs ("noise draw -> final image on device" over a full sampling run; /root/reference sample.py:52-66 +
+    k_diffusion/evaluation.py:80-90), timed end to end: ``sample.main([... --random-weights --seed S -n N --batch-size B --steps 50 --sampler dpmpp_2m
+    --no-png])`` builds its own model, draws every batch's noise, runs the sampler over N / B batches and assembles the N finished images on the
+    device; ``seconds`` is sample.py's own "N images in ... s" region (first batch's plan building included) and images / seconds is the job rate.
+    Both noise sources of --seed are timed: `host` (per-image CPU generators, drawn ahead by worker threads -- the recipe of the committed
+    fixtures) and `device` (kd_randn_f32, keyed by (seed, global index)).  `value` above times the sampler on a resident x0; `ratio_to_value`
+    says how much of that the whole job keeps."""
+    import contextlib
+    import sample as cli
+    cfgpath = os.path.join(REPO, args.config) if not os.path.isabs(args.config) else args.config
+    out, saved = {}, os.environ.get("KDIFF_GEMM")
+    base = ["--config", cfgpath, "--random-weights", "--seed", str(args.seed), "--batch-size", str(args.batch), "--steps", str(args.sampler_steps),
+            "--sampler", args.sampler.replace("sample_", ""), "--no-png"]
+    try:
+        for m in modes:
+            os.environ["KDIFF_GEMM"] = m
+            ent = {}
+            for noise in ("host", "device"):
+                with contextlib.redirect_stdout(sys.stderr):                      # the CLI's own prints must not join the JSON line on stdout
+                    cli.main(base + ["-n", str(args.batch), "--noise", noise])     # one batch: what a fresh model pays once (plans, packed weights)
+                    first = dict(cli.LAST_RUN)
+                    t0 = time.perf_counter()
+                    cli.main(base + ["-n", str(args.job_images), "--noise", noise])
+                    wall = time.perf_counter() - t0
+                    st = dict(cli.LAST_RUN)
+                ent[noise] = {"value": round(st["n"] / st["seconds"], 3), "unit": "images/sec", "images": st["n"], "batches": st["rounds"],
+                              "seconds": round(st["seconds"], 4), "main_wall_seconds": round(wall, 3), "one_batch_job_seconds": round(first["seconds"], 4)}
+            out[m] = ent
+    finally:
+        os.environ["KDIFF_GEMM"] = saved if saved is not None else "split3"
+    return {"workload": f"sample.py --config {os.path.basename(args.config)} --random-weights --seed {args.seed} -n {args.job_images} --batch-size {args.batch} "
+                        f"--steps {args.sampler_steps} --sampler {args.sampler.replace('sample_', '')} --no-png [--noise host|device]",
+            "timed_region": "sample.py's own 'N images in ... s': schedule, every batch's noise draw, sampler, assembly of the N finished fp32 images on "
+                            "the device, final synchronize (model construction / weight upload before it are in main_wall_seconds)",
+            "modes": out}
+
+
 CONFIG_OF = {"flowers_na": "configs/config_oxford_flowers.json", "flowers_sw": "configs/config_oxford_flowers_shifted_window.json"}
 
 
@@ -443,12 +487,68 @@ def other_config(name, path, dev, args, sampler_name, mode, fp8=False, brownian=
     return ent
 
 
+def launch_ranks(args):
+    """``python bench.py --gpus N`` typed plainly (no WORLD_SIZE in the environment): replace this process by the launcher the contract
+    names -- ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
+    arguments>`` -- which starts one rank per GPU; rank 0 of that run prints the JSON line.  The port is a free one asked of the kernel."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    os.environ["KDIFF_BENCH_LAUNCHER"] = "self"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def stub_line(args, ctx):
+    """--stub-workload: the rank plumbing of this file (launcher, process group, barrier-bracketed timed region, max over ranks, the
+    all-gather, ONE line from rank 0) around a tiny CPU tensor op -- what the launcher's CPU test drives over gloo.  Not a measurement."""
+    B = 2
+    x0 = torch.full((B, 3, 8, 8), float(ctx.process_index))
+
+    def one_pass():
+        return ctx.gather(x0 * 1.0)
+    for _ in range(args.warmup):
+        one_pass()
+    ctx.wait_for_everyone()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    ctx.wait_for_everyone()
+    dt = time.perf_counter() - t0
+    if ctx.num_processes > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    ranks_seen = sorted({int(v) for v in out[::B, 0, 0, 0].tolist()})
+    if ctx.is_main_process:
+        print(json.dumps({"metric": "STUB (launcher / rank plumbing test, no GPU work)", "value": round(args.gpus * B * args.steps / dt, 3), "unit": "stub items/sec",
+                          "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
+                          "config": {"workload": "stub", "global_batch": B * args.gpus, "nranks": torch.distributed.get_world_size() if args.gpus > 1 else 1,
+                                     "backend": torch.distributed.get_backend() if args.gpus > 1 else None, "ranks_in_gather": ranks_seen,
+                                     "launcher": os.environ.get("KDIFF_BENCH_LAUNCHER", "external")}}), flush=True)
+    ctx.wait_for_everyone()
+    ctx.shutdown()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                         # does not return
     os.environ["KDIFF_GEMM"] = args.mode
-    ctx = K.distributed.RankContext()
+    if args.stub_workload:
+        ctx = K.distributed.RankContext(device="cpu", backend=args.backend or "gloo")
+    else:
+        ctx = K.distributed.RankContext(backend=args.backend)
     if ctx.num_processes != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.num_processes}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.num_processes}: start it plainly (python bench.py --gpus N launches its own ranks) "
+                         f"or under torch.distributed.run with --nproc-per-node {args.gpus}")
+    if args.stub_workload:
+        return stub_line(args, ctx)
     if args.gpus > 1:
         assert torch.distributed.get_world_size() == args.gpus and torch.distributed.get_backend() == "nccl", "one rank per GPU over RCCL"
     if ctx.device.type != "cuda":
@@ -506,6 +606,7 @@ def main():
                                    f"{args.sampler_steps} steps, batch {B}/GPU, all-gather of finished images",
                        "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus} (independent images, one final all-gather)",
                        "rccl_nranks": torch.distributed.get_world_size() if args.gpus > 1 else 1,
+                       "launcher": os.environ.get("KDIFF_BENCH_LAUNCHER", "external") if args.gpus > 1 else None,
                        "gather": {"ms_per_step": round(gather_ms, 3), "bytes_per_rank": int(out[:B].numel() * out.element_size()),
                                   "dtype": str(out.dtype).replace("torch.", ""),
                                   "note": "all_gather_into_tensor of the finished fp32 images, timed by HIP events on the compute stream "
@@ -551,6 +652,16 @@ def main():
                                 "modes": {m: par[m] for m in measured}}
         if args.gpus == 1 and not args.no_small_batch:
             result["small_batch"] = small_batch_latency(cfg, model, dev, args, measured_modes=[args.mode] + [m for m in result.get("modes", {}) if m != args.mode and m != "exact"])
+        if args.gpus == 1 and not args.no_job:
+            measured = [args.mode] + [m for m in result.get("modes", {}) if m not in (args.mode, "exact")]
+            job = job_rate(args, measured, dev)
+            for m, ent in job["modes"].items():
+                ref_value = head["value"] if m == args.mode else result["modes"][m]["value"]
+                for e in ent.values():
+                    e["ratio_to_value"] = round(e["value"] / ref_value, 4)
+            job["value"] = job["modes"][args.mode]["host"]["value"]          # the CLI's default noise source
+            job["ratio_to_value"] = job["modes"][args.mode]["host"]["ratio_to_value"]
+            result["job"] = job
         if "modes" in result:
             # short copy of the per-mode throughputs (the full entries carry their rooflines: a truncated log tail may cut them off)
             result["mode_values"] = {m: e["value"] for m, e in result["modes"].items()}

@@ -316,6 +316,14 @@ int kd_brownian_f32(float* out, const unsigned long long* seeds, int batch, long
 int kd_brownian_cached_f32(float* out, float* w0, float* w1, int have0, int have1, const unsigned long long* seeds, int batch,
                            long long per_sample, double T0, double T1, double t0, double t1, float mult, int depth, void* stream);
 
+/* Index-addressed standard normals: the start noise of a sampling run (/root/reference sample.py:59, `torch.randn([n, C, H, W],
+ * device=device) * sigma_max`) and the randn_like of the ancestral samplers (k_diffusion/sampling.py:61-62), drawn on the device as a
+ * function of (seeds[b], draw, element) only -- so image i of a seeded job is the same for any batch size / GPU count (the reference's
+ * draw comes from rank-local generator state).  out[b, e] = scale * z, z from Philox4x32-10 (key seeds[b], counter (e >> 2, draw | 2^63))
+ * through two Box-Muller pairs per block; `draw` < 2^63 numbers the calls of one run (0 = start noise).  out: 16-byte aligned. */
+int kd_randn_f32(float* out, const unsigned long long* seeds, int batch, long long per_sample, unsigned long long draw, float scale,
+                 void* stream);
+
 /* Final image conversion (k_diffusion/utils.py:27-34 to_pil_image): u8 = trunc((clamp(x,-1,1)+1)/2*255)
  * (torchvision's to_pil_image does mul(255).byte(), i.e. truncation) */
 int kd_to_uint8(const float* x, unsigned char* y, long long n, void* stream);

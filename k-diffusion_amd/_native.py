@@ -109,6 +109,7 @@ SIGNATURES = {
     "kd_dpm_error_f32": [_vp, _vp, _vp, _f, _f, _ll, _vp, _vp],
     "kd_brownian_f32": [_vp, _vp, _i, _ll, _d, _d, _d, _d, _f, _i, _vp],
     "kd_brownian_cached_f32": [_vp, _vp, _vp, _i, _i, _vp, _i, _ll, _d, _d, _d, _d, _f, _i, _vp],
+    "kd_randn_f32": [_vp, _vp, _i, _ll, C.c_ulonglong, _f, _vp],
     "kd_to_uint8": [_vp, _vp, _ll, _vp],
     "kd_norm_split_f32": [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _f, _vp],
     "kd_prof_enable": [_i],

@@ -113,9 +113,54 @@ static int launch_brownian(const char* what, float* out, float* w0, float* w1, i
   return check_launch(what);
 }
 
+// Index-addressed standard normals (initial noise x0 = randn * sigma_max, sample.py:59; randn_like of the ancestral samplers,
+// sampling.py:61-62): out[b, e] = scale * z(seeds[b], draw, e).  One Philox4x32-10 block per FOUR consecutive elements -- key seeds[b],
+// counter (e >> 2, draw | 2^63: the top bit keeps these blocks apart from the tree's (element, node) counters under the same key) --
+// turned into four normals by two Box-Muller pairs (r1 cos a1, r1 sin a1, r2 cos a2, r2 sin a2).  A sample's values depend on
+// (seed, draw, element) only: not on the batch it is drawn in, the launch grid or the rank.  HBM-write bound (16 B per lane).
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, const unsigned long long* __restrict__ seeds, int batch,
+                                                    long per_sample, unsigned long long draw, float scale) {
+  const long quads = (per_sample + 3) >> 2;
+  const long n = (long)batch * quads;
+  const unsigned long long node = draw | 0x8000000000000000ull;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / quads;
+    const long q = i - b * quads;
+    const Philox4 x = philox4x32_10(seeds[b], (unsigned long long)q, node);
+    const float r1 = scale * bm_radius(x.x0), r2 = scale * bm_radius(x.x2);
+    const float a1 = unit24(x.x1), a2 = unit24(x.x3);
+    float4 z;
+    z.x = r1 * __builtin_amdgcn_cosf(a1);
+    z.y = r1 * __builtin_amdgcn_cosf(a1 - 0.25f);       // sin(a) = cos(a - 1/4 turn)
+    z.z = r2 * __builtin_amdgcn_cosf(a2);
+    z.w = r2 * __builtin_amdgcn_cosf(a2 - 0.25f);
+    float* o = out + b * per_sample + 4 * q;
+    if (4 * q + 4 <= per_sample && (per_sample & 3) == 0) {
+      *reinterpret_cast<float4*>(o) = z;
+    } else {
+      const float v[4] = {z.x, z.y, z.z, z.w};
+      for (int k = 0; k < 4 && 4 * q + k < per_sample; ++k) o[k] = v[k];
+    }
+  }
+}
+
 }  // namespace kd
 
 using namespace kd;
+
+extern "C" int kd_randn_f32(float* out, const unsigned long long* seeds, int batch, long long per_sample, unsigned long long draw, float scale,
+                            void* stream) {
+  if (!out || !seeds || batch <= 0 || per_sample <= 0) return fail(KD_EINVAL, "kd_randn_f32: bad arguments");
+  if (draw >> 63) return fail(KD_EINVAL, "kd_randn_f32: draw must be below 2^63");
+  if ((reinterpret_cast<uintptr_t>(out) & 15) != 0) return fail(KD_EINVAL, "kd_randn_f32: out must be 16-byte aligned");
+  const long n = (long)batch * ((per_sample + 3) >> 2);
+  long blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope prof("randn_f32", 0, 4.0 * batch * per_sample, s);
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, seeds, batch, (long)per_sample, draw, scale);
+  return check_launch("kd_randn_f32");
+}
 
 extern "C" int kd_brownian_f32(float* out, const unsigned long long* seeds, int batch, long long per_sample, double T0, double T1,
                                double t0, double t1, float mult, int depth, void* stream) {

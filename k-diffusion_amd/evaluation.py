@@ -25,33 +25,51 @@ def compute_features(accelerator, sample_fn, extractor_fn, n, batch_size):
     return torch.cat(gathered)[:n]
 
 
-def compute_features_indexed(accelerator, sample_fn, n, batch_size, post=None):
+def indexed_rounds(n, world, batch_size):
+    """The gather rounds of ``compute_features_indexed``: a list of ``(width, [(lo_r, count_r) for every rank r])`` -- in a round rank r
+    draws the ``count_r`` images ``lo_r .. lo_r + count_r - 1`` of its contiguous shard (``distributed.shard_range``), padded to the
+    common ``width``.  A pure function of (n, world, batch_size): every rank computes every rank's share on the host, so no index
+    vector has to travel with the images."""
+    from .distributed import shard_range
+    per = math.ceil(n / world)
+    spans = [shard_range(n, world, r) for r in range(world)]
+    rounds = []
+    for start in range(0, per, batch_size):
+        width = min(batch_size, per - start)                       # the same on every rank
+        rounds.append((width, [(lo + start, max(0, min(width, hi - lo - start))) for lo, hi in spans]))
+    return rounds
+
+
+def compute_features_indexed(accelerator, sample_fn, n, batch_size, post=None, on_schedule=None):
     """``n`` samples addressed by GLOBAL index, independent of the process count: rank r owns the contiguous shard
     ``distributed.shard_range(n, world, r)`` and draws it in batches of at most ``batch_size``; ``sample_fn(indices)`` (a 1-D
-    int64 CPU tensor, possibly empty) returns the samples of exactly those indices; every round is all-gathered together
-    with its index vector (RCCL over xGMI) and scattered into the result, so ``out[i]`` IS sample ``i`` whatever the batch size
-    and the number of GPUs.  (``compute_features`` above keeps the reference's schedule, which sizes a rank's batches by the
-    GLOBAL remainder -- evaluation.py:85 -- and returns the ranks' batches interleaved: fine for FID features, wrong for
-    "image i of a seeded run".)  ``post``: applied to a rank's batch before the gather (e.g. ``ops.to_uint8``: 4x fewer bytes
-    over xGMI)."""
-    from .distributed import shard_range
+    int64 CPU tensor, possibly empty) returns the samples of exactly those indices; every round is all-gathered (RCCL over xGMI)
+    and copied into the result at the positions the HOST knows (``indexed_rounds``), so ``out[i]`` IS sample ``i`` whatever the
+    batch size and the number of GPUs -- and no round waits for the device (the reference's loop, evaluation.py:84-88, does not
+    either; a mask-indexed scatter would put a device->host sync behind every batch and leave the GPU idle while the next batch
+    is prepared).  (``compute_features`` above keeps the reference's schedule, which sizes a rank's batches by the GLOBAL
+    remainder -- evaluation.py:85 -- and returns the ranks' batches interleaved: fine for FID features, wrong for "image i of a
+    seeded run".)  ``post``: applied to a rank's batch before the gather (e.g. ``ops.to_uint8``: 4x fewer bytes over xGMI).
+    ``on_schedule``: called once, before the first round, with this rank's list of index tensors (one per round, in order) -- a
+    sample_fn that prepares inputs ahead of time (``synth.NoisePrefetcher``) learns the whole job from it."""
     world, rank = accelerator.num_processes, accelerator.process_index
-    lo, hi = shard_range(n, world, rank)
-    per = math.ceil(n / world)
+    rounds = indexed_rounds(n, world, batch_size)
+    mine = [torch.arange(shares[rank][0], shares[rank][0] + shares[rank][1]) for _, shares in rounds]
+    if on_schedule is not None:
+        on_schedule(mine)
     out = None
-    for start in trange(0, per, batch_size, disable=not accelerator.is_main_process):
-        width = min(batch_size, per - start)                       # the same on every rank
-        idx = torch.arange(lo + start, lo + start + width)
-        real = idx[idx < hi]
-        x = sample_fn(real)
+    for k in trange(len(rounds), disable=not accelerator.is_main_process):
+        width, shares = rounds[k]
+        x = sample_fn(mine[k])
         x = x if post is None else post(x)
-        buf = x.new_zeros((width, *x.shape[1:]))
-        buf[:len(real)] = x
-        tag = torch.full((width,), -1, dtype=torch.int64)
-        tag[:len(real)] = real
-        g_x, g_tag = accelerator.gather(buf), accelerator.gather(tag.to(buf.device))
+        if world > 1 and len(mine[k]) != width:                   # a short or empty shard: pad to the common width for the gather
+            buf = x.new_zeros((width, *x.shape[1:]))
+            buf[:len(mine[k])] = x
+            x = buf
+        g_x = accelerator.gather(x)
         if out is None:
             out = g_x.new_zeros((n, *g_x.shape[1:]))
-        keep = g_tag >= 0
-        out[g_tag[keep]] = g_x[keep]
+        for r, (lo, count) in enumerate(shares):
+            if count:
+                out[lo:lo + count] = g_x[r * width:r * width + count]
     return out

@@ -24,6 +24,8 @@ CPU path: calling ``forward`` without a ROCm device or without the built library
 """
 import ctypes as C
 import itertools
+import operator
+import weakref
 import os
 import math
 from dataclasses import dataclass
@@ -50,20 +52,6 @@ CLASS_IDS_KEPT = 4            # range-checked class_cond tensors remembered per 
 
 
 _untracked = itertools.count(-1, -1)
-
-# bumped whenever ANY module registers a parameter, a buffer or a sub-module (assignment of an nn.Parameter / register_buffer / a new child):
-# the models' cached tensor lists (_weights_fingerprint) are rebuilt after that
-_registration_epoch = [0]
-
-
-def _note_registration(*_args):
-    _registration_epoch[0] += 1
-
-
-torch.nn.modules.module.register_module_parameter_registration_hook(_note_registration)
-torch.nn.modules.module.register_module_buffer_registration_hook(_note_registration)
-torch.nn.modules.module.register_module_module_registration_hook(_note_registration)
-
 
 def _ver(t):
     """Version counter of a tensor, or a value that never repeats for tensors made under torch.inference_mode() (they carry no
@@ -712,7 +700,8 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         self.out_norm = _rms_scale(levels[0].width)
         self.patch_out = _Holder(proj=_linear_weight(out_channels * ph * pw, levels[0].width, zero=True))
         self._plans, self._fingerprint, self._packed, self._plans_epoch = {}, None, {}, None
-        self._fp_tensors, self._fp_tracked, self._fp_epoch = (), (), -1
+        self._fp_dicts, self._fp_names, self._fp_objs, self._fp_tensors, self._fp_tracked, self._fp_epoch = (), (), (), (), (), 0
+        self._fp_hooked = weakref.WeakSet()
 
     # ---- bookkeeping ---------------------------------------------------------------------------
     def _ada_norm_modules(self):
@@ -747,12 +736,21 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         freq = sa.pos_emb.freqs.detach().to(torch.float32).cpu() / (2.0 * math.pi)
         return pos.reshape(-1, 2).to(torch.float32).contiguous().to(device), freq.contiguous().to(device)
 
+    def _note_weights_rewritten(self, *_args):
+        self._fp_epoch += 1
+
+    def invalidate(self):
+        """Drop the plans and packed weight images at the next call.  Needed only after an IN-PLACE edit of weights that were created
+        under torch.inference_mode() outside load_state_dict / .to(): such tensors carry no version counter, so the edit leaves no trace
+        (_weights_fingerprint sees everything else by itself)."""
+        self._fp_epoch += 1
+
     def _apply(self, fn, *args, **kwargs):
-        # .to() / .cuda() / .half(): normally the same Parameter objects with new .data (seen through their addresses), but with
-        # torch.__future__.set_overwrite_module_params_on_conversion(True) NEW Parameters written straight into the dicts, past the
-        # registration hooks: rebuild the kept tensor list after any conversion
+        # .to() / .cuda() / .half(): the same Parameter objects with new .data (seen through their addresses) or, with
+        # torch.__future__.set_overwrite_module_params_on_conversion(True), new Parameters in the dicts (seen through the slot check);
+        # the epoch covers inference-mode tensors converted in place
         out = super()._apply(fn, *args, **kwargs)
-        _note_registration()
+        self._fp_epoch += 1
         return out
 
     def _packed_image(self, W, N, K, geglu, bf16=False):
@@ -766,14 +764,35 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         return ent[1]
 
     def _weights_fingerprint(self):
-        """(address, version) of every parameter and buffer: a changed entry drops the plans and the packed weight images.  Walked on every
-        model call, so the LIST of tensors is kept (torch's module traversal -- parameters() / buffers() over ~90 sub-modules -- took
-        0.3 - 0.4 ms per call, more than the launches of a batch-1 forward) and rebuilt only after a parameter, buffer or sub-module was
-        registered anywhere (_registration_epoch); what is read per call is the two counters of each tensor."""
-        if self._fp_epoch != _registration_epoch[0]:
-            ts = list(self.parameters()) + list(self.buffers())
-            self._fp_tensors, self._fp_tracked, self._fp_epoch = tuple(ts), tuple(not t.is_inference() for t in ts), _registration_epoch[0]
-        return tuple([(t.data_ptr(), t._version if tr else 0) for t, tr in zip(self._fp_tensors, self._fp_tracked)])
+        """(address, version) of every parameter and buffer (behind a per-model epoch): a changed entry drops the plans and the packed
+        weight images.  Read on every model call, so the LIST of tensors is kept -- torch's module traversal (parameters() / buffers() over
+        ~90 sub-modules) took 0.3 - 0.4 ms per call, more than the launches of a batch-1 forward.  What makes the kept list safe is a
+        per-call identity check of every SLOT the tree has -- each (module._parameters | _buffers | _modules dict, name) still holds the
+        object it held when the list was built -- which is ~200 dict reads in C (a few microseconds), needs no traversal and sees every
+        way a tensor can be swapped: attribute assignment, register_*, del + re-register, a replaced sub-module, and direct writes into
+        ``module._parameters[name]`` (torch.func.functional_call / stateless._reparametrize_module swap parameters that way, past every
+        registration hook).  In-place edits move the tensors' version counters; .to() moves their addresses; load_state_dict / _apply /
+        invalidate() bump the epoch (which also covers inference-mode tensors, whose edits leave no version trace).  No process-wide
+        hooks: only this model's own tree is looked at."""
+        if not (self._fp_objs and all(map(operator.is_, map(dict.get, self._fp_dicts, self._fp_names), self._fp_objs))):
+            dicts, names, objs, ts = [], [], [], []
+            for mod in self.modules():
+                if mod not in self._fp_hooked:       # a (sub-)module's load_state_dict rewrites weights in place: bump the epoch (inference-mode tensors)
+                    self._fp_hooked.add(mod)
+                    mod.register_load_state_dict_post_hook(self._note_weights_rewritten)
+                for d, is_tensor in ((mod._parameters, True), (mod._buffers, True), (mod._modules, False)):
+                    for name, obj in d.items():
+                        dicts.append(d), names.append(name), objs.append(obj)
+                        if is_tensor and obj is not None:
+                            ts.append(obj)
+            seen, uniq = set(), []
+            for t in ts:                     # tied tensors once, like parameters() / buffers()
+                if id(t) not in seen:
+                    seen.add(id(t))
+                    uniq.append(t)
+            self._fp_dicts, self._fp_names, self._fp_objs = tuple(dicts), tuple(names), tuple(objs)
+            self._fp_tensors, self._fp_tracked = tuple(uniq), tuple(not t.is_inference() for t in uniq)
+        return (self._fp_epoch, *[(t.data_ptr(), t._version if tr else 0) for t, tr in zip(self._fp_tensors, self._fp_tracked)])
 
     def param_groups(self, base_lr=5e-4, mapping_lr_scale=1 / 3):
         raise NotImplementedError("training is outside this package's scope (sampling hot path only)")

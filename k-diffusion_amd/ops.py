@@ -489,6 +489,18 @@ def brownian_cached(out, w0, have0, w1, have1, seeds, T0, T1, t0, t1, mult, dept
     return out
 
 
+def randn_indexed(out, seeds, draw=0, scale=1.0):
+    """out[b, ...] = scale * standard normals that are a function of (seeds[b], draw, element index) only (seeds: int64 [B] on the
+    device, ``draw`` numbers the calls of one run): the device-side form of ``torch.randn(...) * sigma_max`` (sample.py:59) /
+    ``randn_like`` (sampling.py:61-62) for jobs whose image i must not depend on the batch or rank it is drawn in."""
+    B = out.shape[0]
+    _chk(seeds, "seeds", torch.int64)
+    if seeds.numel() != B:
+        raise ValueError(f"one seed per batch item: {seeds.numel()} seeds for batch {B}")
+    nat.check(nat.lib().kd_randn_f32(_p(_chk(out, "out")), _p(seeds), B, out.numel() // B, int(draw), float(scale), _stream()), "kd_randn_f32")
+    return out
+
+
 def to_uint8(x, out=None):
     out = torch.empty(x.shape, device=x.device, dtype=torch.uint8) if out is None else out
     if x.numel() == 0:       # an empty shard (more ranks than images in a round): nothing to launch, and the other ranks still gather

@@ -37,26 +37,52 @@ def append_zero(x):
     return torch.cat([x, x.new_zeros([1])])
 
 
+def _to_device_with_host_copy(sig, device):
+    """``sig.to(device)`` that remembers the CPU tensor it came from (``_kd_host``: the copy and the device tensor's version at
+    that moment): a sampler loop needs the schedule's VALUES on the host, and reading them back from the device is a blocking
+    device->host transfer -- in a multi-batch job it would hold the host until the previous batch's GPU pass has drained."""
+    dev = sig.to(device)
+    if dev is not sig:
+        try:
+            dev._kd_host = (sig, dev._version)
+        except Exception:                 # inference-mode tensors carry no version counter: no shortcut for them
+            pass
+    return dev
+
+
+def _host_values(sigmas):
+    """fp32 CPU copy of a schedule: the remembered one when the tensor still is what ``get_sigmas_*`` returned (same version: no
+    in-place edit since), else one device->host transfer."""
+    kept = getattr(sigmas, '_kd_host', None)
+    if kept is not None:
+        try:
+            if kept[1] == sigmas._version and kept[0].shape == sigmas.shape and kept[0].dtype == torch.float32:
+                return kept[0]
+        except Exception:
+            pass
+    return sigmas.detach().to('cpu', torch.float32)
+
+
 def get_sigmas_karras(n, sigma_min, sigma_max, rho=7., device='cpu'):
     """Karras et al. (2022) schedule.  Evaluated on the CPU (fp32 ramp, double scalars) exactly as the
     reference does (sampling.py:17-23) and then moved, so the schedule is bit-identical everywhere."""
     ramp = torch.linspace(0, 1, n)
     lo, hi = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
-    return append_zero((hi + ramp * (lo - hi)) ** rho).to(device)
+    return _to_device_with_host_copy(append_zero((hi + ramp * (lo - hi)) ** rho), device)
 
 
 def get_sigmas_exponential(n, sigma_min, sigma_max, device='cpu'):
-    return append_zero(torch.linspace(math.log(sigma_max), math.log(sigma_min), n).exp()).to(device)
+    return _to_device_with_host_copy(append_zero(torch.linspace(math.log(sigma_max), math.log(sigma_min), n).exp()), device)
 
 
 def get_sigmas_polyexponential(n, sigma_min, sigma_max, rho=1., device='cpu'):
     ramp = torch.linspace(1, 0, n) ** rho
-    return append_zero(torch.exp(ramp * (math.log(sigma_max) - math.log(sigma_min)) + math.log(sigma_min))).to(device)
+    return _to_device_with_host_copy(append_zero(torch.exp(ramp * (math.log(sigma_max) - math.log(sigma_min)) + math.log(sigma_min))), device)
 
 
 def get_sigmas_vp(n, beta_d=19.9, beta_min=0.1, eps_s=1e-3, device='cpu'):
     t = torch.linspace(1, eps_s, n)
-    return append_zero(torch.sqrt(torch.exp(beta_d * t ** 2 / 2 + beta_min * t) - 1)).to(device)
+    return _to_device_with_host_copy(append_zero(torch.sqrt(torch.exp(beta_d * t ** 2 / 2 + beta_min * t) - 1)), device)
 
 
 # --------------------------------------------------------------------------------- helpers
@@ -183,7 +209,7 @@ class _Loop:
             raise TypeError(f'fp32 latents only (got {x.dtype})')
         self.model, self.extra, self.callback = model, ({} if extra_args is None else extra_args), callback
         self.sigmas = sigmas
-        self.sig = sigmas.detach().to('cpu', torch.float32)      # the ONE device->host transfer
+        self.sig = _host_values(sigmas)      # the ONE device->host transfer -- none when get_sigmas_* kept the host copy
         self.x = x.contiguous()
         self.B = x.shape[0]
         self._owned = False
@@ -196,7 +222,8 @@ class _Loop:
         model call of the run.  The model is told so (``prefetch_schedule``): the conditioning chain is a function of
         sigma / class / ... only, so a model that takes the hint runs it once for the whole table instead of once per call."""
         v = torch.stack([torch.as_tensor(s, dtype=torch.float32).reshape(()) for s in values])
-        table = v.to(self.x.device)[:, None].expand(len(values), self.B).contiguous()
+        v = v.pin_memory() if self.x.is_cuda and len(values) else v      # (a pageable .to(device) ends with a stream synchronisation)
+        table = v.to(self.x.device, non_blocking=True)[:, None].expand(len(values), self.B).contiguous()
         if _COND_PREFETCH and _COND_SCHEDULE and len(values):
             hint = getattr(self.model, 'prefetch_schedule', None)
             if hint is not None:

@@ -105,6 +105,27 @@ def brownian_increment(seeds, per_sample, T0, T1, t0, t1, mult=1.0, depth=36):
     return out
 
 
+def randn_indexed(seeds, per_sample, draw=0, scale=1.0):
+    """[len(seeds), per_sample] float32: the index-addressed normals of ``kd_randn_f32`` (k-diffusion_amd/csrc/brownian.hip).  One
+    Philox block (key seeds[b], counter (e >> 2, draw | 2^63)) per four consecutive elements, two Box-Muller pairs per block:
+    r(x0) cos(x1), r(x0) sin(x1), r(x2) cos(x3), r(x2) sin(x3) with sin(a) evaluated as cos(a - 1/4 turn), each radius scaled first.
+    Stands where the reference draws ``torch.randn(...) * sigma_max`` from rank-local generator state (sample.py:59): there is no
+    reference stream to match, so -- like the tree above -- what is checked is this restatement, the N(0, 1) statistics and the
+    independence of batch / rank."""
+    quads = (per_sample + 3) // 4
+    q = np.arange(quads, dtype=np.uint64)
+    node = int(draw) | (1 << 63)
+    out = np.empty((len(seeds), quads * 4), dtype=np.float32)
+    s = np.float32(scale)
+    for b, key in enumerate(seeds):
+        x0, x1, x2, x3 = _philox(int(key) & 0xFFFFFFFFFFFFFFFF, q, node)
+        r1, r2 = s * _radius(x0), s * _radius(x2)
+        a1, a2 = _unit24(x1), _unit24(x3)
+        z = np.stack([r1 * _cos_rev(a1), r1 * _cos_rev(a1 - np.float32(0.25)), r2 * _cos_rev(a2), r2 * _cos_rev(a2 - np.float32(0.25))], axis=1)
+        out[b] = z.reshape(-1).astype(np.float32)
+    return out[:, :per_sample]
+
+
 class OracleBrownianTree:
     """Stands in for ``torchsde.BrownianTree(t0, w0, t1, entropy=seed)`` (the constructor and call surface
     k_diffusion/sampling.py:80,88 uses) with THIS package's stream: ``tree(ta, tb)`` -> W(tb) - W(ta) shaped like ``w0``,

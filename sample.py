@@ -14,6 +14,11 @@ sample.py:59-60, and therefore cannot run its own class-conditional configs):
   --class-cond C       class id for every image (-1: image index mod num_classes) for class-conditional configs
   --random-weights     no checkpoint: synthetic weights (K.synth), for smoke runs and benchmarking
   --no-png             skip PNG encoding (timing runs)
+  --noise host|device  where --seed's per-image noise is drawn.  host (default): one CPU torch.Generator per global image index
+                       (K.synth.synth_noise: the recipe of the committed fixtures), drawn by worker threads AHEAD of the sampler and
+                       handed over as an asynchronous pinned copy, so the draw runs beside the previous batch's GPU pass;
+                       device: the keyed Philox generator of the HIP library (kd_randn_f32; seed, global index, draw number ->
+                       values), no host work at all -- also for the ancestral samplers' per-step noise
   --gather-uint8       8-bit conversion on the GPU before the all-gather of finished images (same PNG bytes, 4x less xGMI traffic).
                        The DEFAULT whenever there is a gather (more than one process) and PNG files are written -- the writer needs
                        nothing else; --gather-fp32 keeps the reference's fp32 gather (main() then returns fp32 images)
@@ -31,6 +36,9 @@ from tqdm import tqdm
 import k_diffusion_amd as K
 
 
+LAST_RUN = {}        # statistics of the most recent main() (see run())
+
+
 def parse(argv=None):
     p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     p.add_argument('--batch-size', type=int, default=64, help='the batch size')
@@ -44,6 +52,8 @@ def parse(argv=None):
     p.add_argument('--class-cond', type=int, default=None, help='class id for all images; -1 = index mod num_classes')
     p.add_argument('--random-weights', action='store_true', help='synthetic weights instead of a checkpoint')
     p.add_argument('--no-png', action='store_true', help='do not write PNG files')
+    p.add_argument('--noise', choices=['host', 'device'], default='host',
+                   help="where --seed's per-image noise is drawn: CPU generators ahead of the sampler (default) or the library's keyed device generator")
     p.add_argument('--gather-uint8', action='store_true',
                    help='convert finished images to uint8 on the GPU before the all-gather (what the PNG writer needs; 4x less xGMI traffic)')
     p.add_argument('--gather-fp32', action='store_true', help='all-gather the finished images as fp32 even when only PNG files are wanted')
@@ -74,7 +84,7 @@ def class_ids(args, num_classes, indices, device):
     if args.class_cond >= num_classes:
         raise SystemExit(f'--class-cond {args.class_cond} is out of range: this config has {num_classes} classes (0..{num_classes - 1})')
     if args.class_cond < 0:
-        return (indices % num_classes).to(device)
+        return to_device_async(indices % num_classes, device)
     return torch.full([len(indices)], args.class_cond, dtype=torch.int64, device=device)
 
 
@@ -84,26 +94,55 @@ def brownian_seeds(seed, indices):
     return [((int(seed) * 0x9E3779B97F4A7C15) ^ (int(g) * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D)) & 0x7FFFFFFFFFFFFFFF for g in indices]
 
 
-def indexed_noise_sampler(seed, indices, shape, device):
+def noise_seeds(seed, indices):
+    """One key of the device generator (kd_randn_f32) per GLOBAL image index; a different mix from ``brownian_seeds``, so an SDE run's
+    start noise and its Brownian trees are unrelated streams."""
+    return [((int(seed) * 0xD6E8FEB86659FD93) ^ (int(g) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019)) & 0x7FFFFFFFFFFFFFFF for g in indices]
+
+
+def to_device_async(t, device):
+    """A small host tensor (class ids, seeds) onto the device without the stream synchronisation a pageable ``.to(device)`` ends with --
+    that wait would hold the host until the previous batch's GPU pass has drained."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
+def device_noise(seed, indices, shape, device, draw=0, scale=1.0):
+    """[len(indices), *shape] normals * scale drawn on the device: a function of (seed, global index, draw number) only."""
+    keys = to_device_async(torch.tensor(noise_seeds(seed, indices), dtype=torch.int64), device)
+    return K.ops.randn_indexed(torch.empty((len(indices), *shape), device=device, dtype=torch.float32), keys, draw=draw, scale=scale)
+
+
+def indexed_noise_sampler(seed, indices, shape, device, where='host'):
     """noise_sampler(sigma, sigma_next) for the ancestral samplers (default: randn_like on the global stream, sampling.py:73-75)
-    whose draw for image i is a function of (seed, i, call number) only."""
+    whose draw for image i is a function of (seed, i, call number) only.  ``where``: 'host' = one CPU generator per (image, call)
+    (the recipe of the round-1 fixtures; slow -- every call draws on the host), 'device' = kd_randn_f32 with the call number as
+    its draw counter (draw 0 is the start noise)."""
     calls = [0]
+    keys = None
 
     def noise_sampler(sigma, sigma_next):
+        nonlocal keys
         k = calls[0]
         calls[0] += 1
+        if where == 'device':
+            if keys is None:
+                keys = to_device_async(torch.tensor(noise_seeds(seed, indices), dtype=torch.int64), device)
+            return K.ops.randn_indexed(torch.empty((len(indices), *shape), device=device, dtype=torch.float32), keys, draw=k + 1)
         return torch.stack([K.synth.synth_noise(shape, int(seed) + 7919 * (k + 1), int(g), 1.0) for g in indices]).to(device)
     return noise_sampler
 
 
-def seeded_noise_args(sampler, seed, indices, x, sigma_min, sigma_max):
+def seeded_noise_args(sampler, seed, indices, x, sigma_min, sigma_max, where='host'):
     """extra keyword arguments that make a stochastic sampler's noise index-addressed when --seed is given."""
     import inspect
     if seed is None or 'noise_sampler' not in inspect.signature(sampler).parameters:
         return {}
     if sampler.__name__ in ('sample_dpmpp_sde', 'sample_dpmpp_2m_sde', 'sample_dpmpp_3m_sde'):      # default: Brownian tree (sampling.py:548,615,661)
         return {'noise_sampler': K.sampling.BrownianTreeNoiseSampler(x, sigma_min, sigma_max, seed=brownian_seeds(seed, indices))}
-    return {'noise_sampler': indexed_noise_sampler(seed, indices, tuple(x.shape[1:]), x.device)}
+    return {'noise_sampler': indexed_noise_sampler(seed, indices, tuple(x.shape[1:]), x.device, where)}
 
 
 def main(argv=None):
@@ -140,16 +179,23 @@ def main(argv=None):
         if accelerator.is_local_main_process:
             tqdm.write('Sampling...')
         sigmas = K.sampling.get_sigmas_karras(args.steps, sigma_min, sigma_max, rho=7., device=device)
+        host_noise = K.synth.NoisePrefetcher(shape, args.seed, sigma_max, device, width=min(args.batch_size, args.n)) if (args.seed is not None and args.noise == 'host') else None
+        rounds_done, batch_marks = [0], []
 
         def sample_fn(indices):
             """Images of the given GLOBAL indices (this rank's share of one round; may be empty)."""
             n = len(indices)
+            k = rounds_done[0]
+            rounds_done[0] += 1
+            batch_marks.append(time.perf_counter())
+            if host_noise is not None:
+                x = host_noise.take(k)                            # drawn ahead by worker threads, asynchronous pinned copy
             if n == 0:
                 return torch.empty([0, *shape], device=device)
             if args.seed is None:
                 x = torch.randn([n, *shape], device=device) * sigma_max
-            else:
-                x = torch.stack([K.synth.synth_noise(shape, args.seed, int(g), sigma_max) for g in indices]).to(device)
+            elif host_noise is None:
+                x = device_noise(args.seed, indices, shape, device, draw=0, scale=sigma_max)
             extra = {}
             cc = class_ids(args, num_classes, indices, device)
             if cc is not None:
@@ -159,7 +205,7 @@ def main(argv=None):
                 return sampler(model, x, sigma_min, sigma_max, args.steps, extra_args=extra, disable=quiet)
             if sampler is K.sampling.sample_dpm_adaptive:
                 return sampler(model, x, sigma_min, sigma_max, extra_args=extra, disable=quiet)
-            noise = seeded_noise_args(sampler, args.seed, indices, x, sigma_min, sigma_max)
+            noise = seeded_noise_args(sampler, args.seed, indices, x, sigma_min, sigma_max, args.noise)
             return sampler(model, x, sigmas, extra_args=extra, disable=quiet, **noise)
 
         t0 = time.perf_counter()
@@ -168,9 +214,20 @@ def main(argv=None):
         # [-1, 1] fp32 -> uint8 on the device before the gather: 4x fewer bytes over xGMI, the same PNG bytes
         as_u8 = args.gather_uint8 or (accelerator.num_processes > 1 and not args.no_png and not args.gather_fp32)
         post = K.ops.to_uint8 if as_u8 else None
-        x_0 = K.evaluation.compute_features_indexed(accelerator, sample_fn, args.n, args.batch_size, post=post)
-        torch.cuda.synchronize()
-        accelerator.print(f'{args.n} images in {time.perf_counter() - t0:.2f} s')
+        try:
+            x_0 = K.evaluation.compute_features_indexed(accelerator, sample_fn, args.n, args.batch_size, post=post,
+                                                        on_schedule=host_noise.schedule if host_noise is not None else None)
+            torch.cuda.synchronize()
+        finally:
+            if host_noise is not None:
+                host_noise.close()
+        seconds = time.perf_counter() - t0
+        accelerator.print(f'{args.n} images in {seconds:.2f} s')
+        # what a caller that times the job (bench.py's `job` block) reads: the sampling region above -- noise draw -> finished
+        # (gathered) images on the device, PNG encoding excluded -- and when each round was handed to the sampler
+        LAST_RUN.clear()
+        LAST_RUN.update({'n': args.n, 'seconds': seconds, 'rounds': len(batch_marks), 'round_starts': [m - t0 for m in batch_marks],
+                         'world': accelerator.num_processes, 'noise': args.noise if args.seed is not None else 'device (unseeded torch.randn)'})
         if accelerator.is_main_process and not args.no_png:
             for i, out in enumerate(x_0):
                 K.utils.to_pil_image(out).save(f'{args.prefix}_{i:05}.png')

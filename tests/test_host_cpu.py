@@ -572,22 +572,24 @@ def test_run_list_entries_are_packed_by_the_rule_the_library_unpacks_by():
 
 
 def test_weights_fingerprint_keeps_its_tensor_list_and_still_sees_every_change():
-    """The per-call weights check of the model (round 4): the list of parameters / buffers is kept between calls -- walking the module tree
-    cost 0.3 - 0.4 ms per model call -- and rebuilt when torch registers a parameter, buffer or sub-module, or converts the module.  Host
-    logic only (no device): every way a weight can change must move the fingerprint, and an untouched model must not walk the tree again."""
+    """The per-call weights check of the model: the list of parameters / buffers is kept between calls -- walking the module tree cost
+    0.3 - 0.4 ms per model call -- and what keeps it honest is a per-call identity check of every (module dict, name) slot of the model's
+    OWN tree (no process-wide hooks).  Host logic only (no device): every way a weight can change must move the fingerprint -- including
+    direct writes into ``module._parameters`` (torch.func.functional_call swaps parameters that way, past all registration hooks) -- and
+    an untouched model must not walk the tree again."""
     import torch
     import k_diffusion_amd as K
     from k_diffusion_amd.models import image_transformer_v2 as itv2
     cfg = K.config.load_config(os.path.join(REPO, "configs", "config_mnist_transformer.json"))
     m = K.config.make_model(cfg).eval().requires_grad_(False)
     f0 = m._weights_fingerprint()
-    assert len(f0) == len(list(m.parameters())) + len(list(m.buffers()))
+    assert len(f0) == 1 + len(list(m.parameters())) + len(list(m.buffers()))      # the epoch, then one entry per tensor
     walked = []
-    orig = type(m).parameters
+    orig = type(m).modules
     try:
-        type(m).parameters = lambda self, *a, **k: (walked.append(1), orig(self, *a, **k))[1]
+        type(m).modules = lambda self, *a, **k: (walked.append(1), orig(self, *a, **k))[1]
         assert m._weights_fingerprint() == f0 and not walked                      # unchanged: the kept list, no traversal
-        m.load_state_dict(K.synth.synth_state_dict(m.state_dict(), seed=1))     # in-place copies: versions move
+        m.load_state_dict(K.synth.synth_state_dict(m.state_dict(), seed=1))     # in-place copies: versions move (and the epoch)
         f1 = m._weights_fingerprint()
         assert f1 != f0 and not walked
         with torch.no_grad():
@@ -602,10 +604,139 @@ def test_weights_fingerprint_keeps_its_tensor_list_and_still_sees_every_change()
         p.data = p.data.clone()                                                   # same Parameter, other storage (what Module.to() does)
         f4 = m._weights_fingerprint()
         assert f4 != f3 and not walked
-        m.double()                                                                # a conversion: list rebuilt
-        assert m._weights_fingerprint() != f4 and walked
-        epoch = itv2._registration_epoch[0]
-        torch.nn.Linear(2, 2)                                                     # ANY registration anywhere bumps the epoch (cheap, conservative)
-        assert itv2._registration_epoch[0] > epoch
+        # a write straight into the dict, past __setattr__ and every registration hook
+        old = m.patch_out.proj._parameters["weight"]
+        m.patch_out.proj._parameters["weight"] = torch.nn.Parameter(old.detach().clone() + 1.0, requires_grad=False)
+        f5 = m._weights_fingerprint()
+        assert f5 != f4 and walked and any(t is m.patch_out.proj._parameters["weight"] for t in m._fp_tensors)
+        del walked[:]
+        # torch.func.functional_call swaps parameters through the dicts for the duration of the call: the model must see the swapped
+        # tensors INSIDE the call (plans / packed images built from the real weights must not serve it) and the real ones after it
+        inside = []
+        real_forward = type(m).forward
+        type(m).forward = lambda self, *a, **k: inside.append(self._weights_fingerprint())
+        try:
+            before = m._weights_fingerprint()
+            swapped = {k: v.detach().clone() + 0.5 for k, v in m.named_parameters()}
+            torch.func.functional_call(m, swapped, ())
+            assert inside and inside[0] != before
+            addrs = {t.data_ptr() for t in swapped.values()}
+            assert {a for a, _ in inside[0][1:]} >= addrs                          # the fingerprint read inside the call is of the SWAPPED tensors
+            after = m._weights_fingerprint()
+            assert after == before                                                # restored: same objects, addresses and versions as before the call
+        finally:
+            type(m).forward = real_forward
+        del walked[:]
+        # a replaced sub-module (same name, other object)
+        m.out_norm = type(m.out_norm)(scale=torch.nn.Parameter(torch.ones_like(m.out_norm.scale)))
+        f6 = m._weights_fingerprint()
+        assert f6 != after and walked
+        del walked[:]
+        m.double()                                                                # a conversion: epoch bumped, addresses move
+        f7 = m._weights_fingerprint()
+        assert f7 != f6
+        # weights made under inference_mode carry no version counter: load_state_dict (post-hook) and invalidate() still move the fingerprint
+        with torch.inference_mode():
+            mi = K.config.make_model(cfg).eval()
+        g0 = mi._weights_fingerprint()
+        with torch.inference_mode():                                              # (in-place edits of inference tensors are only legal here)
+            mi.load_state_dict({k: v + 1 for k, v in mi.state_dict().items()})
+        g1 = mi._weights_fingerprint()
+        assert g1 != g0
+        mi.invalidate()
+        assert mi._weights_fingerprint() != g1
+        # no import side effect on unrelated modules: the package installs no process-wide registration hooks
+        from torch.nn.modules import module as tmod
+        for table in (tmod._global_parameter_registration_hooks, tmod._global_buffer_registration_hooks, tmod._global_module_registration_hooks):
+            assert not any(getattr(h, "__module__", "").startswith("k-diffusion_amd") or getattr(h, "__module__", "").startswith("k_diffusion_amd") for h in table.values())
+        assert not hasattr(itv2, "_registration_epoch")
     finally:
-        type(m).parameters = orig
+        type(m).modules = orig
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` typed plainly (no WORLD_SIZE): bench.py re-executes itself under torch.distributed.run with one rank per
+    device, rank 0 prints ONE JSON line.  Driven here over gloo with the stub workload (no GPU in this container); the rank plumbing --
+    launcher, process group, barrier-bracketed timed region, max over ranks, the all-gather -- is the code the GPU run goes through."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--stub-workload"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["data"] == "stub"
+    assert line["config"]["nranks"] == 2 and line["config"]["backend"] == "gloo" and line["config"]["ranks_in_gather"] == [0, 1]
+    assert line["config"]["launcher"] == "self"
+    # started under the launcher by somebody else (what the driver's multi-GPU command does): no second launch, launcher reported as external
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29655",
+                        os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--backend", "gloo", "--stub-workload"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["config"]["launcher"] == "external" and line["config"]["nranks"] == 2
+    # a world size that contradicts --gpus is refused with the way out spelled out
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--stub-workload"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode != 0 and "launches its own ranks" in r.stderr
+
+
+def test_noise_prefetcher_draws_the_fixture_recipe_ahead(KD):
+    """synth.NoisePrefetcher (sample.py --seed, --noise host): the batches of a job's schedule drawn by worker threads ahead of the sampler
+    are value for value ``synth_noise(shape, seed, g, sigma_max)`` -- ragged and empty batches, slots reused, any thread count."""
+    shape, seed, smax = (3, 8, 8), 11, 160.0
+    plan = [torch.arange(0, 4), torch.arange(4, 8), torch.arange(8, 11), torch.arange(11, 11), torch.arange(11, 12)]
+    for threads, depth in ((1, 1), (3, 2), (8, 4)):
+        pf = KD.synth.NoisePrefetcher(shape, seed, smax, "cpu", depth=depth, threads=threads)
+        pf.schedule(plan)
+        try:
+            for k, idx in enumerate(plan):
+                x = pf.take(k)
+                assert x.shape == (len(idx), *shape)
+                for row, g in enumerate(idx):
+                    assert torch.equal(x[row], KD.synth.synth_noise(shape, seed, int(g), smax)), (threads, k, row)
+            with pytest.raises(KeyError):
+                pf.take(len(plan))
+        finally:
+            pf.close()
+    assert torch.equal(KD.synth.synth_noise_batch(shape, seed, 4, 3, smax), torch.stack([KD.synth.synth_noise(shape, seed, g, smax) for g in (4, 5, 6)]))
+
+
+def test_indexed_rounds_and_the_schedule_callback(KD):
+    """evaluation.indexed_rounds is a pure host function every rank evaluates for every rank (no index vector travels with the images), and
+    compute_features_indexed tells the sample_fn its whole schedule before the first round."""
+    ev = KD.evaluation
+    for n, world, bs in ((21, 8, 2), (7, 2, 4), (5, 8, 3), (64, 1, 32), (1, 1, 64)):
+        rounds = ev.indexed_rounds(n, world, bs)
+        covered = sorted(g for width, shares in rounds for lo, cnt in shares for g in range(lo, lo + cnt))
+        assert covered == list(range(n))
+        assert all(cnt <= width <= bs for width, shares in rounds for _, cnt in shares)
+
+    class One:
+        num_processes, process_index, is_main_process = 1, 0, False
+        gather = staticmethod(lambda t: t)
+    seen, calls = [], []
+    out = ev.compute_features_indexed(One(), lambda idx: (calls.append(idx.tolist()), idx.float()[:, None] * torch.ones(1, 2))[1], 7, 3, on_schedule=seen.append)
+    assert [p.tolist() for p in seen[0]] == [[0, 1, 2], [3, 4, 5], [6]] == calls
+    assert torch.equal(out, torch.arange(7.)[:, None] * torch.ones(1, 2))
+
+
+def test_oracle_index_addressed_normals():
+    """oracle.brownian.randn_indexed (the restatement of kd_randn_f32, the device noise source of a seeded job): N(0, 1) moments, a
+    sample's values are a function of (seed, draw, element) only, draws and seeds give unrelated streams."""
+    import numpy as np
+    from oracle import brownian as ob
+    z = ob.randn_indexed([5, 6], 200_000)
+    assert z.shape == (2, 200_000) and z.dtype == np.float32
+    for row in z:
+        assert abs(row.mean()) < 8e-3 and abs(row.var() - 1) < 1.5e-2
+        assert abs((row ** 4).mean() - 3) < 0.1 and abs((row ** 3).mean()) < 0.05
+        assert abs(np.corrcoef(row[:-1], row[1:])[0, 1]) < 8e-3                  # neighbours (the cos / sin pair of a block) are uncorrelated
+    assert abs(np.corrcoef(z[0], z[1])[0, 1]) < 8e-3
+    assert np.array_equal(ob.randn_indexed([6], 1001)[0], z[1][:1001])           # ragged length: a prefix of the same stream
+    assert np.array_equal(ob.randn_indexed([9, 5], 64)[1], z[0][:64])            # position in the batch does not matter
+    d1 = ob.randn_indexed([5], 200_000, draw=1)[0]
+    assert abs(np.corrcoef(d1, z[0])[0, 1]) < 8e-3 and not np.array_equal(d1, z[0])
+    assert np.allclose(ob.randn_indexed([5], 64, scale=160.0)[0], 160.0 * z[0][:64], rtol=1e-6)

@@ -695,6 +695,33 @@ def test_brownian_vs_oracle(ops):
     assert abs(torch.corrcoef(big[:2])[0, 1].item()) < 0.02
 
 
+def test_index_addressed_normals_vs_oracle(ops):
+    """kd_randn_f32 (the device noise source of a seeded job: sample.py --noise device) against oracle.brownian.randn_indexed: integer
+    Philox bit-exact, Box-Muller on the hardware log2 / sqrt / cos (1e-5 absolute per unit of scale); a sample's values do not depend
+    on the batch it is drawn in or on the launch size; ragged lengths; moments of a 25 MB draw (the job's batch)."""
+    seeds = [12345, 2 ** 63 - 7, 0]
+    for per, shape in ((3 * 6 * 8, (3, 3, 6, 8)), (3 * 5 * 7, (3, 3, 5, 7)), (1, (3, 1))):       # a multiple of 4, a ragged tail, one element
+        for draw, scale in ((0, 1.0), (3, 160.0)):
+            out = torch.full(shape, float("nan"), device=DEV)
+            ops.randn_indexed(out, g(torch.tensor(seeds, dtype=torch.int64)), draw=draw, scale=scale)
+            ref = obrown.randn_indexed(seeds, per, draw=draw, scale=scale)
+            assert np.abs(out.cpu().numpy().reshape(3, per) - ref).max() < 1e-5 * scale, (per, draw)
+    big = torch.empty(32, 3, 256, 256, device=DEV)
+    keys = torch.arange(32, dtype=torch.int64) * 977 + 5
+    ops.randn_indexed(big, g(keys), draw=0, scale=1.0)
+    assert abs(big.mean().item()) < 2e-3 and abs(big.var().item() - 1) < 2e-3 and abs((big ** 4).mean().item() - 3) < 2e-2
+    assert abs(torch.corrcoef(big[:2].reshape(2, -1))[0, 1].item()) < 1e-2
+    sub = torch.empty(2, 3, 256, 256, device=DEV)                      # images 7 and 30 drawn alone: the same values
+    ops.randn_indexed(sub, g(keys[[7, 30]]), draw=0, scale=1.0)
+    assert torch.equal(sub[0], big[7]) and torch.equal(sub[1], big[30])
+    ref = obrown.randn_indexed([int(keys[7])], 4096)
+    assert np.abs(big[7].reshape(-1)[:4096].cpu().numpy() - ref[0]).max() < 1e-5
+    with pytest.raises(ValueError):
+        ops.randn_indexed(big, g(keys[:3]))
+    with pytest.raises(RuntimeError):
+        ops.randn_indexed(torch.empty(1, 4), keys[:1])               # host tensors: no CPU fallback
+
+
 def test_brownian_cached_endpoints(ops):
     """kd_brownian_cached_f32: stored end points reproduce the uncached increments bit for bit."""
     seeds = g(torch.tensor([7, 8], dtype=torch.int64))
