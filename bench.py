@@ -212,32 +212,34 @@ def _cpu_baseline(hdit, solvers, cfg, seed, sampler_steps, target_seconds):
 PARITY_CASE = "smp32_flowers_na_2m5"     # tests/golden/cases.SAMPLE_B32_CASES[0]: this workload's config at this batch, 5 DPM++2M steps
 
 
-def parity_vs_reference_golden(dev, modes):
-    """Distance of this build, on this box, to the REFERENCE's own images: the committed golden ``tests/golden/samples_r3.safetensors``
-    (recorded from the imported reference by oracle/make_golden_r3.py; the oracle is not involved) holds the reference's fp32 output of a
-    5-step DPM++2M run of config_oxford_flowers.json at batch 32 for images cases.B32_KEEP.  The same run (same weights seed, noise, sigmas)
-    goes through the HIP path in every mode; rel_err = max|got - ref| / max|ref|, north_star's measure.  The bf16 mode is also compared with
-    the reference's own torch.autocast(bfloat16) run of those images (samples_r4.safetensors, oracle/make_golden_r4.py)."""
+def golden_parity(dev, modes, golden_file, case, cfgname, sampler, steps, batch, keep, autocast_file=None):
+    """Distance of this build, on this box, to the REFERENCE's own images of one committed golden case (tests/golden/*.safetensors, recorded from
+    the imported reference by oracle/make_golden*.py; the oracle is not involved): the same run (weights seed, noise, class ids, sigmas) goes
+    through the HIP path in every mode; rel_err = max|got - ref| / max|ref|, north_star's measure.  The bf16 mode is also compared with the
+    reference's own torch.autocast(bfloat16) run where one was recorded."""
     from safetensors.torch import load_file
     from tests.golden import cases
-    case, cfgname, sampler, steps, batch = next(c for c in cases.SAMPLE_B32_CASES if c[0] == PARITY_CASE)
-    ref = load_file(os.path.join(cases.GOLDEN_DIR, "samples_r3.safetensors"))[case]
-    r4 = os.path.join(cases.GOLDEN_DIR, "samples_r4.safetensors")
-    ref16 = load_file(r4).get(case + "_bf16") if os.path.exists(r4) else None
+    ref = load_file(os.path.join(cases.GOLDEN_DIR, golden_file))[case]
+    ref16 = None
+    if autocast_file and os.path.exists(os.path.join(cases.GOLDEN_DIR, autocast_file)):
+        t16 = load_file(os.path.join(cases.GOLDEN_DIR, autocast_file))       # (round-1 autocast file: same case names; later ones: case + "_bf16")
+        ref16 = t16.get(case + "_bf16", t16.get(case) if autocast_file != golden_file else None)
     cfg = K.config.load_config(cases.raw_config(cfgname))
     mc = cfg["model"]
     model = K.config.make_model(cfg).eval().requires_grad_(False)
     model.load_state_dict(K.synth.synth_state_dict(model.state_dict(), seed=cases.WEIGHT_SEED))
     den = K.Denoiser(model.to(dev), sigma_data=mc["sigma_data"])
-    x, _ = cases.sample_inputs(cfg, batch)
+    x, cls = cases.sample_inputs(cfg, batch)
     x = x.to(dev)
+    extra = {"class_cond": cls.to(dev)} if cls is not None else {}
     sigmas = K.sampling.get_sigmas_karras(steps, mc["sigma_min"], mc["sigma_max"], rho=7., device=dev)
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
     out, saved = {}, os.environ.get("KDIFF_GEMM")
     try:
         for m in modes:
             os.environ["KDIFF_GEMM"] = m
-            y = getattr(K.sampling, sampler)(den, x, sigmas, disable=True)[cases.B32_KEEP].float().cpu()
+            y = getattr(K.sampling, sampler)(den, x, sigmas, extra_args=extra, disable=True)
+            y = (y if keep is None else y[keep]).float().cpu()
             gate = 1e-3 if m != "bf16" else None         # north_star's tolerance applies to the fp32-parity modes
             ent = {"rel_err_vs_reference_golden": round(rel(y, ref), 7), "gate": gate}
             if gate is not None:
@@ -248,9 +250,18 @@ def parity_vs_reference_golden(dev, modes):
             out[m] = ent
     finally:
         os.environ["KDIFF_GEMM"] = saved if saved is not None else "split3"
-    return {"case": f"{case}: {os.path.basename(CONFIG_OF[cfgname])} 256x256, {sampler} {steps} steps, batch {batch}, images {cases.B32_KEEP} "
-                    "against the reference's fp32 run (tests/golden/samples_r3.safetensors)",
+    what = CONFIG_OF.get(cfgname, cfgname)
+    return {"case": f"{case}: {os.path.basename(what)}, {sampler} {steps} steps, batch {batch}, images {keep if keep is not None else 'all'} "
+                    f"against the reference's fp32 run (tests/golden/{golden_file})",
             "measure": "max|got - ref| / max|ref|", **out}
+
+
+def parity_vs_reference_golden(dev, modes):
+    """The headline workload's parity case: the reference's fp32 output of a 5-step DPM++2M run of config_oxford_flowers.json at batch 32
+    (samples_r3.safetensors, images cases.B32_KEEP; the bf16 mode also against the reference's autocast run, samples_r4.safetensors)."""
+    from tests.golden import cases
+    case, cfgname, sampler, steps, batch = next(c for c in cases.SAMPLE_B32_CASES if c[0] == PARITY_CASE)
+    return golden_parity(dev, modes, "samples_r3.safetensors", case, cfgname, sampler, steps, batch, cases.B32_KEEP, "samples_r4.safetensors")
 
 
 def small_batch_latency(cfg, model, dev, args, measured_modes, batches=(1, 4)):
@@ -323,23 +334,41 @@ def job_rate(args, modes, dev):
             "modes": out}
 
 
-CONFIG_OF = {"flowers_na": "configs/config_oxford_flowers.json", "flowers_sw": "configs/config_oxford_flowers_shifted_window.json"}
+CONFIG_OF = {"flowers_na": "configs/config_oxford_flowers.json", "flowers_sw": "configs/config_oxford_flowers_shifted_window.json",
+             "mnist": "configs/config_mnist_transformer.json", "cifar": "configs/config_cifar10_transformer.json"}
+
+
+def _smi(*args):
+    import subprocess
+    try:
+        return subprocess.run(["rocm-smi", *args], capture_output=True, text=True, timeout=10).stdout
+    except Exception:
+        return ""
+
+
+def power_limits():
+    """What the board says about its own limits, read once (idle): the power cap the firmware enforces (rocm-smi --showmaxpower), the
+    performance level policy and the clock range of the shader domain.  None-valued keys = the tool did not print that field here."""
+    import re
+    cap = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", _smi("--showmaxpower"))
+    perf = re.search(r"Performance Level: (\S+)", _smi("--showperflevel"))
+    levels = [int(m) for m in re.findall(r"\b\d+: (\d+)Mhz", _smi("--showclkfrq").split("sclk")[-1].split("Supported")[0])] if "sclk" in _smi("--showclkfrq") else []
+    return {"cap_w": float(cap.group(1)) if cap else None, "perf_level": perf.group(1) if perf else None,
+            "sclk_levels_mhz": levels or None}
 
 
 def power_and_clock(one_pass, passes=16):
     """Socket power and shader clock while the path runs: `passes` more untimed passes with rocm-smi sampled from a side thread (the timed
-    region is not touched).  On MI355X the fp32-parity path runs INTO the chip's power limit (~1.2 kW average, every fused projection / FF kernel
-    1.3 - 1.4 kW) and is clocked down to ~2.0 of 2.4 GHz: DESIGN.md section 5 A, profiles/r04_power_clock.log.  None if rocm-smi is unavailable."""
+    region is not touched), next to the board's power cap.  None if rocm-smi is unavailable."""
     import re
-    import subprocess
     import threading
+    limits = power_limits()
     stop, out = threading.Event(), []
 
     def sample():
         while not stop.is_set():
-            try:
-                txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
-            except Exception:
+            txt = _smi("--showpower", "--showclocks")
+            if not txt:
                 return
             p = re.search(r"Socket Graphics Package Power \(W\): ([0-9.]+)", txt)
             c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
@@ -356,10 +385,25 @@ def power_and_clock(one_pass, passes=16):
     body = out[len(out) // 3:-1] if len(out) > 5 else out          # (the first second still rides the boost after an idle gap: the steady state follows)
     if not body:
         return None
-    return {"socket_power_w": round(sum(p for p, _ in body) / len(body), 1), "shader_clock_mhz": round(sum(c for _, c in body) / len(body)),
-            "max_shader_clock_mhz": 2400, "samples": len(body),
-            "note": "rocm-smi sampled every ~0.15 s during extra untimed passes of this mode right after its timed region; a clock below the part's "
-                    "2400 MHz at ~1.2 kW means the power limit, not a pipe, sets the pace"}
+    pw, ck = [p for p, _ in body], [c for _, c in body]
+    mean_w = sum(pw) / len(pw)
+    cap = limits["cap_w"]
+    head = None if cap is None else round(cap - mean_w, 1)
+    if head is None:
+        verdict = "no power cap reported by rocm-smi on this box: the clock figure stands alone"
+    elif head <= 100:
+        verdict = (f"average draw within {head:.0f} W of the {cap:.0f} W cap (peaks at or above it) with the shader clock below its top level: "
+                   "the firmware's power management sets the pace of this path on this box")
+    else:
+        verdict = (f"average draw {head:.0f} W under the {cap:.0f} W cap: on THIS box the power cap is not what holds the clock at "
+                   f"{round(sum(ck) / len(ck))} MHz -- see DESIGN.md (power section) for what the samples do and do not show")
+    return {"socket_power_w": round(mean_w, 1), "socket_power_w_min": min(pw), "socket_power_w_max": max(pw),
+            "shader_clock_mhz": round(sum(ck) / len(ck)), "shader_clock_mhz_min": min(ck), "shader_clock_mhz_max": max(ck),
+            "max_shader_clock_mhz": max(limits["sclk_levels_mhz"]) if limits["sclk_levels_mhz"] else 2400, "samples": len(body),
+            "cap_w": cap, "headroom_w": head, "perf_level": limits["perf_level"], "sclk_levels_mhz": limits["sclk_levels_mhz"],
+            "reading": verdict,
+            "note": "rocm-smi sampled every ~0.15 s (a ~1 ms-averaged register, not an energy counter) during extra untimed passes of this mode right "
+                    "after its timed region; cap from rocm-smi --showmaxpower"}
 
 
 MODE_DTYPE = {
@@ -447,8 +491,9 @@ def mode_entry(mode, dt, steps, warmup, n_img, groups, n_gpus):
     return ent, fam
 
 
-def other_config(name, path, dev, args, sampler_name, mode, fp8=False, brownian=False):
-    """A secondary BASELINE configuration on the same box: 1 warm-up + --other-passes timed passes + one event pass."""
+def other_config(name, path, dev, args, sampler_name, mode, fp8=False, brownian=False, batch=None, steps=None, passes=None):
+    """A secondary BASELINE configuration on the same box: 1 warm-up + --other-passes timed passes + one event pass.  Class-conditional
+    configs get class id = image index mod num_classes."""
     os.environ["KDIFF_GEMM"] = mode
     cfg = K.config.load_config(os.path.join(REPO, path))
     mc = cfg["model"]
@@ -460,24 +505,28 @@ def other_config(name, path, dev, args, sampler_name, mode, fp8=False, brownian=
     model = model.to(dev)
     den = K.Denoiser(model, sigma_data=mc["sigma_data"])
     shape = (mc["input_channels"], *mc["input_size"])
-    B = args.batch
+    B = batch or args.batch
+    n_steps = steps or args.sampler_steps
+    n_passes = passes or args.other_passes
     x0 = K.synth.synth_noise_batch(shape, args.seed, 0, B, mc["sigma_max"]).to(dev)
-    sigmas = K.sampling.get_sigmas_karras(args.sampler_steps, mc["sigma_min"], mc["sigma_max"], rho=7., device=dev)
+    sigmas = K.sampling.get_sigmas_karras(n_steps, mc["sigma_min"], mc["sigma_max"], rho=7., device=dev)
     sampler = getattr(K.sampling, sampler_name)
+    nc = cfg["dataset"]["num_classes"]
+    extra = {"class_cond": (torch.arange(B) % nc).to(dev)} if nc else {}
     import sample as cli      # the CLI's per-image Brownian seeds: image i's noise path is a function of (seed, global index i)
 
     def one_pass():
-        kw = {}
+        kw = {"extra_args": extra} if extra else {}
         if brownian:
             kw["noise_sampler"] = K.sampling.BrownianTreeNoiseSampler(x0, mc["sigma_min"], mc["sigma_max"], seed=cli.brownian_seeds(args.seed, range(B)))
         return sampler(den, x0, sigmas, disable=True, **kw)
     ctx1 = K.distributed.RankContext.__new__(K.distributed.RankContext)
     ctx1.num_processes, ctx1.process_index, ctx1.local_process_index, ctx1.device, ctx1._owns_group = 1, 0, 0, dev, False
-    dt, out, groups = Timed(ctx1, args.other_passes, 1, not args.no_kernel_events).run(one_pass)
-    nfe = {"sample_dpmpp_2m": args.sampler_steps, "sample_dpmpp_sde": 2 * args.sampler_steps - 1, "sample_heun": 2 * args.sampler_steps - 1}.get(sampler_name)
-    ent = {"value": round(args.other_passes * B / dt, 3), "unit": "images/sec", "steps": args.other_passes, "warmup": 1, "batch": B, "mode": mode,
-           "ms_per_step": round(dt / args.other_passes * 1e3, 2), "model_calls_per_pass": nfe,
-           "workload": f"{os.path.basename(path)} {mc['input_size'][0]}x{mc['input_size'][1]}, {sampler_name} {args.sampler_steps} steps"
+    dt, out, groups = Timed(ctx1, n_passes, 1, not args.no_kernel_events).run(one_pass)
+    nfe = {"sample_dpmpp_2m": n_steps, "sample_euler": n_steps, "sample_dpmpp_sde": 2 * n_steps - 1, "sample_heun": 2 * n_steps - 1}.get(sampler_name)
+    ent = {"value": round(n_passes * B / dt, 3), "unit": "images/sec", "steps": n_passes, "warmup": 1, "batch": B, "mode": mode,
+           "ms_per_step": round(dt / n_passes * 1e3, 2), "model_calls_per_pass": nfe, "ms_per_model_call": round(dt / n_passes * 1e3 / nfe, 4) if nfe else None,
+           "workload": f"{os.path.basename(path)} {mc['input_size'][0]}x{mc['input_size'][1]}, {sampler_name} {n_steps} steps"
                        + (", BrownianTreeNoiseSampler (one tree per image)" if brownian else "") + (", fp8-stored weights (e4m3, exact in bf16)" if fp8 else "")}
     if groups:
         tot = sum(g["ms"] for n, g in groups.items() if not n.startswith(SIDE_STREAM))
@@ -630,9 +679,25 @@ def main():
             os.environ["KDIFF_GEMM"] = args.mode
         if args.gpus == 1 and not args.no_other_configs and os.path.basename(args.config) == "config_oxford_flowers.json":
             sw, na = "configs/config_oxford_flowers_shifted_window.json", "configs/config_oxford_flowers.json"
+            from tests.golden import cases
+            c64 = cases.SAMPLE_B64_CASE
             result["other_configs"] = {
+                # BASELINE configs[0]: the reference's CPU-runnable plumbing case, here on the GPU (batch 4: the latency regime)
+                "configs[0] mnist, euler x 10, batch 4": {
+                    **{m: other_config("mnist", CONFIG_OF["mnist"], dev, args, "sample_euler", m, batch=4, steps=10, passes=20) for m in ("split3", "bf16")},
+                    "parity": golden_parity(dev, ("split3", "bf16"), "samples.safetensors", "smp_mnist_euler10", "mnist", "sample_euler", 10, 4, None,
+                                            "samples_bf16.safetensors")},
+                # BASELINE configs[1]: global attention only, sample_heun x 50 (99 model calls) at its stated batch 64
+                "configs[1] cifar, heun x 50, batch 64": {
+                    **{m: other_config("cifar", CONFIG_OF["cifar"], dev, args, "sample_heun", m, batch=64) for m in ("bf16", "split3")},
+                    "parity": golden_parity(dev, ("split3", "bf16"), "samples_r5.safetensors", *c64, cases.B64_KEEP, "samples_r5.safetensors")},
                 # BASELINE configs[2]: the single-GPU 256x256 DPM++2M case with shifted-window attention
-                "configs[2] shifted-window, dpmpp_2m": {m: other_config("sw", sw, dev, args, "sample_dpmpp_2m", m) for m in ("split3", "bf16")},
+                "configs[2] shifted-window, dpmpp_2m": {
+                    **{m: other_config("sw", sw, dev, args, "sample_dpmpp_2m", m) for m in ("split3", "bf16")},
+                    "parity": golden_parity(dev, ("split3", "bf16"), "samples_r3.safetensors", "smp32_flowers_sw_2m5", "flowers_sw", "sample_dpmpp_2m", 5, 32,
+                                            cases.B32_KEEP, "samples_r4.safetensors")},
+                # BASELINE configs[3] is the headline workload of this line (`value`, `modes`, `parity`, `job`): its per-GPU share of the 8-GPU batch
+                "configs[3] neighbourhood, dpmpp_2m": "the headline workload: see value / modes / parity / job of this line (32 images per GPU of the 8 x 32 batch)",
                 # BASELINE configs[4]: neighbourhood attention, sample_dpmpp_sde x 50 (99 model calls, 98 Brownian queries of one tree per
                 # image), fp8-stored weights where the arithmetic can hold them exactly (bf16 mode); the fp32-parity mode runs fp32 weights
                 "configs[4] neighbourhood, dpmpp_sde + Brownian tree": {

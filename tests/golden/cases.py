@@ -102,6 +102,13 @@ SAMPLE_B32_CASES = [
 ]
 
 
+# round 5 ------------------------------------------------------------------------------------------------
+# BASELINE configs[1] at its stated batch: CIFAR-10 config, sample_heun x 50, batch 64 (fp32 and the reference under autocast(bfloat16)).
+# Recorded by oracle/make_golden_r5.py; the golden file keeps images B64_KEEP.
+SAMPLE_B64_CASE = ("smp64_cifar_heun50", "cifar", "sample_heun", 50, 64)
+B64_KEEP = [0, 13, 37, 63]
+
+
 def sde_brownian_seeds(batch, seed=SDE_SEED):
     """One Brownian-tree seed per global image index: the rule of sample.py --seed (sample.brownian_seeds), restated here so that
     the golden script and the tests do not import the CLI."""
