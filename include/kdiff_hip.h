@@ -255,6 +255,16 @@ int kd_attn_global_bf16(const void* qkv, void* out, int batch, int T, int nh, vo
 int kd_attn_window_bf16(const void* qkv, void* out, int batch, int H, int W, int nh, int ws, int shift, void* stream);
 int kd_attn_na2d_bf16(const void* qkv, void* out, int batch, int H, int W, int nh, int ks, void* stream);
 
+/* The global-attention block in front of its out projection as ONE launch (round 5; k_diffusion/models/image_transformer_v2.py:370-392:
+ * norm -> qkv_proj -> scale_for_cosine_sim_qkv -> apply_rotary_emb_ -> scaled_dot_product_attention / flash_attn_qkvpacked_func).  `d` is the
+ * descriptor of the block's qkv projection exactly as kd_gemm_bf16 takes it (A = residual stream, Wp = packed qkv weight, scale /
+ * scale_stride / rows_per_sample = the AdaRMSNorm scales, qk_scale, rope_pos, rope_freq, n_heads; epi = KD_EPI_QKV, norm = 1, precision =
+ * KD_PREC_BF16), except that C receives the ATTENTION OUTPUT [M, n_heads * 64] bf16: q, k, v never reach HBM.  One workgroup per (sample,
+ * head).  Shapes: 256 tokens per sample, K = 64 * n_heads in {256, 512}, N = 3 K, M % 256 == 0 (kd_attn_block_bf16_supported tells);
+ * anything else returns KD_EINVAL and the caller issues kd_gemm_bf16 + kd_attn_global_bf16, whose results this entry reproduces bit for bit. */
+int kd_attn_block_bf16_supported(int tokens_per_sample, int width, int n_heads);
+int kd_attn_block_bf16(const KdGemm* d, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Solver step arithmetic (k_diffusion/sampling.py), one fused elementwise launch per step with
  * host-precomputed fp32 coefficients.  Operation order follows the reference expression trees
@@ -354,10 +364,12 @@ int kd_prof_clock_buffer(void* dev_ptr);
  *   KD_OP_ATTN_GLOBAL_F32 : p = qkv, out, scale_h, cos_t, sin_t; i = batch, T, nh, prep, precision; f = eps
  *   KD_OP_ATTN_WINDOW_F32 : p as above; i = batch, H, W, nh, ws, shift, prep, precision        KD_OP_ATTN_NA2D_F32 : i = batch, H, W, nh, ks, prep, precision
  *   KD_OP_ATTN_GLOBAL_BF16 : p = qkv, out; i = batch, T, nh      KD_OP_ATTN_WINDOW_BF16 : i = batch, H, W, nh, ws, shift      KD_OP_ATTN_NA2D_BF16 : i = batch, H, W, nh, ks
- *   KD_OP_NORM_SPLIT_F32 : p = x, scale, hi, lo; i = scale_stride, rows_per_sample, M, K; f = eps */
+ *   KD_OP_NORM_SPLIT_F32 : p = x, scale, hi, lo; i = scale_stride, rows_per_sample, M, K; f = eps
+ *   KD_OP_ATTN_BLOCK_BF16 : p[0] = const KdGemm* */
 enum { KD_OP_GEMM_F32 = 0, KD_OP_GEMM_BF16 = 1, KD_OP_FFN_F32 = 2, KD_OP_FFN_BF16 = 3,
        KD_OP_ATTN_GLOBAL_F32 = 4, KD_OP_ATTN_WINDOW_F32 = 5, KD_OP_ATTN_NA2D_F32 = 6,
-       KD_OP_ATTN_GLOBAL_BF16 = 7, KD_OP_ATTN_WINDOW_BF16 = 8, KD_OP_ATTN_NA2D_BF16 = 9, KD_OP_NORM_SPLIT_F32 = 10 };
+       KD_OP_ATTN_GLOBAL_BF16 = 7, KD_OP_ATTN_WINDOW_BF16 = 8, KD_OP_ATTN_NA2D_BF16 = 9, KD_OP_NORM_SPLIT_F32 = 10,
+       KD_OP_ATTN_BLOCK_BF16 = 11 };
 typedef struct {
   int op;             /* KD_OP_* */
   float f;

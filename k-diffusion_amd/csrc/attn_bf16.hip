@@ -227,6 +227,267 @@ __global__ __launch_bounds__(QW * 64, (QW <= 4 && MODE != MODE_WINDOW16) ? 2 : 1
   store_o(a.out + ((size_t)b * a.T + q_tok) * (a.nh * DH) + head * DH, O, 1.0f / l, h2, q_ok);
 }
 
+// ---- global-attention block in ONE launch: AdaRMSNorm -> qkv projection of one head -> cosine-sim + RoPE -> dense attention ----------
+// (image_transformer_v2.py:370-396: norm, qkv_proj, scale_for_cosine_sim_qkv, apply_rotary_emb_, attention -- everything in front of
+// out_proj.)  At the level-2 shape (8192 rows, K = 512) the two-launch form spent 29.5 us in the projection (a 4 us K loop per wave
+// between a row prologue repeated per n-split and the q / k epilogues) and 13.5 us in a core that has 1.7 us of work, with a 25 MB
+// qkv round trip through HBM between them.  Here a workgroup owns ONE (sample, head) problem with T = 256 tokens:
+//   * its 8 waves take 32 rows each: the sample's rows come in by LDS-DMA once per workgroup, are normalised and scaled into
+//     MFMA B-operand fragments held in registers (the A-stationary form of csrc/gemm_bf16.hip, same arithmetic, same order);
+//   * the head's 64 rows of W_k, W_v, W_q stream past them (three passes over K, 8 KiB half blocks of the packed image, 4-slot ring of
+//     two k-steps each, one barrier per 16 MFMAs per wave); k and v leave their epilogues as bf16 rows of the K / V images in LDS
+//     (the dense core's swizzle), q -- the last pass -- stays in registers as the B fragments of S^T = K Q^T;
+//   * then the dense core above, unchanged: scores, softmax, O^T = V^T P^T, 16-byte stores of the attention output.
+// Neither q, k nor v ever reaches HBM.  The arithmetic is that of the two-launch form operation for operation (the results are
+// bit-identical: tests/test_ops_gpu.py::test_attn_block_bf16_matches_two_launches).  144 KiB of LDS, one workgroup per CU.
+struct BArgs {
+  const u16* x; const char* Wp; u16* out;
+  const float* scale; int scale_stride; float eps;
+  int batch, nh;                      // 256 tokens per sample
+  const float* qk_scale; const float* pos; const float* freq;
+  int warm;
+};
+
+__device__ __forceinline__ void wait_vm_n(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+  }
+}
+
+// one 64-dim row held as two C-layout blocks -> its 128-byte row of a [token][64] bf16 image in LDS (chunk c at c ^ asw(row))
+__device__ __forceinline__ void row_to_image(char* img, int rowi, const f32x16& b0, const f32x16& b1, float mul, int lh) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    unsigned pk[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x16& v = e ? b1 : b0;
+      pk[g][0] = pack_bf16(v[4 * g] * mul, v[4 * g + 1] * mul);
+      pk[g][1] = pack_bf16(v[4 * g + 2] * mul, v[4 * g + 3] * mul);
+    }
+#pragma unroll
+    for (int gp = 0; gp < 4; gp += 2) {
+      half_swap(pk[gp][0], pk[gp + 1][0]);
+      half_swap(pk[gp][1], pk[gp + 1][1]);
+      const int c = 4 * e + gp + lh;                       // dims 8 c .. 8 c + 7 of the row
+      *reinterpret_cast<u32x4*>(img + rowi * 128 + ((c ^ asw(rowi)) << 4)) = u32x4{pk[gp][0], pk[gp][1], pk[gp + 1][0], pk[gp + 1][1]};
+    }
+  }
+}
+
+template <int NC /* K / 16 */>
+__global__ __launch_bounds__(512, 1) void attn_block_bf16_kernel(const BArgs p) {
+  constexpr int K = NC * 16, NK = NC / 4, SPP = NK / 2, NSTAGE = 3 * SPP, NSLOT = 4, PDIST = 3, T = 256, NT = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kimg = smem + NSLOT * WBLK;
+  char* Vimg = Kimg + T * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
+  const auto warm = code_warm_begin<24 * 1024>((int)blockIdx.x < p.warm && tid < 64);
+  // workgroup -> (sample, head): ids go to the 8 XCDs round-robin, so the heads of one sample get ids 8 apart -- one XCD's L2 fetches the
+  // sample's rows from HBM once for all of them
+  int b, head;
+  if ((p.batch & 7) == 0) {
+    const int j = blockIdx.x >> 3;
+    b = (j / p.nh) * 8 + (blockIdx.x & 7);
+    head = j % p.nh;
+  } else {
+    b = blockIdx.x / p.nh;
+    head = blockIdx.x % p.nh;
+  }
+  const int tok = wid * 32 + l31;                         // this lane's token of the sample: its row, later its query
+  const size_t row = (size_t)b * T + tok;
+
+  // ---- the wave's 32 rows -> normalised, scaled B fragments (gemm_astat_kernel's prologue) ------------------------------------------
+  bf16x8 a[NC];
+  float rs;
+  {
+    constexpr int RPR = WBLK / (2 * K);                // rows per staging round (one 16 KiB slot): 16 at K = 512, 32 at K = 256
+    constexpr int NR = 32 / RPR, CPR = K / 8;          // rounds; 16-byte chunks per row
+    static_assert(RPR >= 16 && NR * RPR == 32, "staging geometry");
+    u32x4 raw[NC];
+    char* stage = smem + wid * WBLK;
+    char* scl = smem + 8 * WBLK + wid * (K * 4);
+    const char* ssrc = reinterpret_cast<const char*>(p.scale + (size_t)b * p.scale_stride) + lane * 16;
+#pragma unroll
+    for (int i = 0; i < K * 4 / 1024; ++i) glds16(ssrc + i * 1024, scl + i * 1024);
+    float ssq = 0.f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rr = (i * 64 + lane) / CPR, qs = (i * 64 + lane) % CPR;        // LDS row of this lane's piece, its slot in the row
+        const size_t grow = (size_t)b * T + wid * 32 + r * RPR + rr;
+        glds16(reinterpret_cast<const char*>(p.x + grow * K) + ((qs ^ (rr & 15)) << 4), stage + i * 1024);
+      }
+      KD_WAIT_VM(0);                                   // wave-private slot: no barrier
+      if (NR == 1 || (l31 / RPR) == r) {
+        const int rr = l31 % RPR;
+        const char* rowp = stage + rr * (2 * K);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) raw[c] = *reinterpret_cast<const u32x4*>(rowp + (((2 * c + lh) ^ (rr & 15)) << 4));
+      }
+      if (NR > 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is overwritten by the next round
+    }
+    f32x4 s0[2][4], s1[2][4];
+    const float* spl = reinterpret_cast<const float*>(scl) + 8 * lh;
+    auto load_scales = [&](int c0, int g) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s0[g][u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
+        s1[g][u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
+      }
+    };
+    load_scales(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c0 = 0; c0 < NC; c0 += 4) {
+      const int g = (c0 >> 2) & 1;
+      if (c0 + 4 < NC) load_scales(c0 + 4, g ^ 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[2 * e] = bf_lo(raw[c0 + u][e]); x[2 * e + 1] = bf_hi(raw[c0 + u][e]); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ssq = fmaf(x[e], x[e], ssq);
+        u32x4 o = {pack_bf16(x[0] * s0[g][u][0], x[1] * s0[g][u][1]), pack_bf16(x[2] * s0[g][u][2], x[3] * s0[g][u][3]),
+                   pack_bf16(x[4] * s1[g][u][0], x[5] * s1[g][u][1]), pack_bf16(x[6] * s1[g][u][2], x[7] * s1[g][u][3])};
+        asm volatile("" : "+v"(o));
+        a[c0 + u] = __builtin_bit_cast(bf16x8, o);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ssq += __shfl_xor(ssq, 32, 64);
+    rs = rsqrtf(ssq / (float)K + p.eps);
+  }
+  float py = p.pos[2 * tok], px = p.pos[2 * tok + 1];
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(py), "+v"(px) : : "memory");
+  code_warm_end(warm);
+  KD_BARRIER();                                        // every wave has taken its rows out of the slot it borrowed
+
+  // ---- the head's W_k, W_v, W_q rows past the fragments -------------------------------------------------------------------------------
+  // stage s = pass s / SPP (k, v, q), k-steps 2 kk and 2 kk + 1 of that pass: two 8 KiB half blocks (rows 64 (head & 1) .. + 63 of the
+  // block (n-tile of the head's rows, k-step)); wave w brings piece w of each
+  const char* wbase = p.Wp + (head & 1) * 8192 + wid * 1024 + lane * 16;
+  auto issue = [&](int s) {
+    const int pass = s / SPP, kk = s % SPP;
+    const int which = pass == 0 ? 1 : (pass == 1 ? 2 : 0);
+    const int nt = (which * K + head * 64) >> 7;
+    char* dst = smem + (s % NSLOT) * WBLK + wid * 1024;
+    glds16(wbase + ((size_t)nt * NK + 2 * kk) * WBLK, dst);
+    glds16(wbase + ((size_t)nt * NK + 2 * kk + 1) * WBLK, dst + 8192);
+  };
+#pragma unroll
+  for (int s = 0; s < PDIST; ++s) issue(s);
+
+  int off4[4];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) off4[cc] = swz128(l31, 2 * cc + lh);
+  // the head's constants through the scalar cache (see gemm_astat_kernel)
+  typedef float f32x8s __attribute__((ext_vector_type(8)));
+  f32x8s fq;
+  float qsc;
+  asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+               : "=s"(fq), "=s"(qsc) : "s"(p.freq + head * 8), "s"(p.qk_scale + head) : "memory");
+  float fr[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) fr[u] = pick_half(fq[u], fq[4 + u], 0u - (unsigned)lh);
+  const float sqs = sqrtf(qsc);
+
+  bf16x8 qf[4];
+  f32x16 acc[2];
+#pragma unroll
+  for (int s = 0; s < NSTAGE; ++s) {
+    const int pass = s / SPP, kk = s % SPP;
+    if (kk == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    }
+    wait_vm_n(2 * min(PDIST - 1, NSTAGE - 1 - s));
+    KD_BARRIER();                        // every wave's pieces of stage s are in; everyone is done reading slot (s - 1) % NSLOT
+    if (s + PDIST < NSTAGE) issue(s + PDIST);
+    const char* st = smem + (s % NSLOT) * WBLK;
+    bf16x8 wf[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wf[0][j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 128 + off4[0]);
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {     // 8 chunks of 16 k: half block h = c8 / 4, chunk cc = c8 % 4
+      if (c8 + 1 < 8) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          wf[(c8 + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(st + ((c8 + 1) >> 2) * 8192 + j * 32 * 128 + off4[(c8 + 1) & 3]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c8 & 1][j], a[4 * (2 * kk + (c8 >> 2)) + (c8 & 3)], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kk == SPP - 1) {
+      if (pass == 0) {                   // k: cosine-sim scale + RoPE, then its row of the K image
+        qk_prep_blocks(acc[0], acc[1], rs, sqs, p.eps, py, px, fr);
+        row_to_image(Kimg, tok, acc[0], acc[1], 1.0f, lh);
+      } else if (pass == 1) {            // v
+        row_to_image(Vimg, tok, acc[0], acc[1], rs, lh);
+      } else {                           // q: stays in registers as the B fragments of the score products (dims 16 st + 8 lh .. + 7)
+        qk_prep_blocks(acc[0], acc[1], rs, sqs, p.eps, py, px, fr);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          unsigned pk[4][2];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            pk[g][0] = pack_bf16(acc[e][4 * g], acc[e][4 * g + 1]);
+            pk[g][1] = pack_bf16(acc[e][4 * g + 2], acc[e][4 * g + 3]);
+          }
+#pragma unroll
+          for (int gp = 0; gp < 4; gp += 2) {
+            half_swap(pk[gp][0], pk[gp + 1][0]);
+            half_swap(pk[gp][1], pk[gp + 1][1]);
+            qf[2 * e + gp / 2] = __builtin_bit_cast(bf16x8, u32x4{pk[gp][0], pk[gp][1], pk[gp + 1][0], pk[gp + 1][1]});
+          }
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  KD_BARRIER();                                        // all 256 rows of the K and V images are written
+
+  // ---- S^T = K Q^T, softmax, O^T = V^T P^T: the dense core ------------------------------------------------------------------------------
+  f32x16 S[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
+  const int ka = l31 * 128 + ((lh ^ asw(l31)) << 4);
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kimg + (ka ^ (32 * st)) + 4096 * t);
+      S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], S[t], 0, 0, 0);
+    }
+  }
+  const float m = score_max<NT>(S);
+  float l = score_exp<NT>(S, m);
+  l += __shfl_xor(l, 32, 64);
+  f32x16 O[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) O[e][i] = 0.f;
+  const int va = vt_addr(4 * lh + vt_lane_row(lane), lane);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) pv_step(O, Vimg + (32 * t + 16 * u) * 128, va, p_frag(S[t], u));
+  store_o(p.out + row * (size_t)(p.nh * DH) + head * DH, O, 1.0f / l, lh, true);
+}
+
 // ---- global core for T > 256: 128-key blocks double-buffered through LDS, online softmax ---------------------------------------
 constexpr int GL_QW = 8, GL_KB = 128, GL_NTK = GL_KB / 32;
 constexpr int GL_IMG = GL_KB * 128, GL_BUF = 2 * GL_IMG, GL_LDS = 2 * GL_BUF;
@@ -644,6 +905,44 @@ extern "C" int kd_attn_global_bf16(const void* qkv, void* out, int batch, int T,
   if (qw >= 8) return launch_dense<MODE_GLOBAL, 8, 8>(a, nb, "attn_global_bf16", s);
   if (qw == 2) return launch_dense<MODE_GLOBAL, 8, 2>(a, nb, "attn_global_bf16", s);
   return launch_dense<MODE_GLOBAL, 8, 4>(a, nb, "attn_global_bf16", s);
+}
+
+// The global-attention block in front of its out projection as ONE launch (attn_block_bf16_kernel above).  `d` is the descriptor of the
+// block's qkv projection exactly as kd_gemm_bf16 takes it (A = the residual stream, Wp = the packed qkv weight, scale / scale_stride /
+// rows_per_sample = the AdaRMSNorm scale table, qk_scale / rope_pos / rope_freq / n_heads) -- except that C receives the ATTENTION OUTPUT
+// [M, n_heads * 64] bf16 instead of qkv.  Shapes: 256 tokens per sample, K = n_heads * 64 in {256, 512}, N = 3 K.
+extern "C" int kd_attn_block_bf16_supported(int tokens_per_sample, int width, int n_heads) {
+  return tokens_per_sample == 256 && (width == 256 || width == 512) && n_heads * 64 == width && option("attn_block_bf16", 1) ? 1 : 0;
+}
+
+extern "C" int kd_attn_block_bf16(const KdGemm* dp, void* stream) {
+  if (!dp) return fail(KD_EINVAL, "kd_attn_block_bf16: null descriptor");
+  const KdGemm& d = *dp;
+  if (!d.A || !d.Wp || !d.C || !d.scale || !d.qk_scale || !d.rope_pos || !d.rope_freq) return fail(KD_EINVAL, "kd_attn_block_bf16: null operand");
+  if (d.epi != KD_EPI_QKV || !d.norm || d.a_mode != KD_A_PLAIN || d.precision != KD_PREC_BF16)
+    return fail(KD_EINVAL, "kd_attn_block_bf16: the descriptor must be a bf16 norm -> qkv projection");
+  if (!kd_attn_block_bf16_supported(d.rows_per_sample, d.K, d.n_heads) || d.N != 3 * d.K || d.M <= 0 || d.M % 256)
+    return fail(KD_EINVAL, "kd_attn_block_bf16: shape M=%d N=%d K=%d, %d tokens per sample, %d heads is not taken (256 tokens per sample, "
+                "K = 64 heads in {256, 512})", d.M, d.N, d.K, d.rows_per_sample, d.n_heads);
+  BArgs a{reinterpret_cast<const u16*>(d.A), reinterpret_cast<const char*>(d.Wp), reinterpret_cast<u16*>(d.C), d.scale, d.scale_stride, d.eps,
+          d.M / 256, d.n_heads, d.qk_scale, d.rope_pos, d.rope_freq, option("code_warm", KD_CODE_WARM_DEFAULT)};
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int LDS = 8 * WBLK + 8 * 512 * 4;          // prologue: 8 wave-private staging slots + 8 scale vectors; later ring + K / V images
+  const double flops = 2.0 * d.M * 3.0 * d.K * d.K + 4.0 * (double)a.batch * a.nh * 256.0 * 256.0 * DH;
+  const double bytes = 2.0 * ((double)d.M * d.K * 2.0 + 3.0 * d.K * d.K);
+  char nm[96] = "attn_block_bf16";
+  if (prof_on()) snprintf(nm, sizeof(nm), "attn_block_bf16 M=%d K=%d nh=%d", d.M, d.K, d.n_heads);
+  LaunchScope prof(nm, flops, bytes, s);
+  if (d.K == 512) {
+    static LdsAttr set;
+    set.ensure(reinterpret_cast<const void*>(attn_block_bf16_kernel<32>), LDS);
+    hipLaunchKernelGGL(attn_block_bf16_kernel<32>, dim3((unsigned)(a.batch * a.nh)), dim3(512), LDS, s, a);
+  } else {
+    static LdsAttr set;
+    set.ensure(reinterpret_cast<const void*>(attn_block_bf16_kernel<16>), LDS);
+    hipLaunchKernelGGL(attn_block_bf16_kernel<16>, dim3((unsigned)(a.batch * a.nh)), dim3(512), LDS, s, a);
+  }
+  return check_launch("kd_attn_block_bf16");
 }
 
 extern "C" int kd_attn_window_bf16(const void* qkv, void* out, int batch, int H, int W, int nh, int ws, int shift, void* stream) {

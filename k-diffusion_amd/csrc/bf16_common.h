@@ -121,18 +121,23 @@ __device__ __forceinline__ float pick_half(float f_lo, float f_hi, unsigned hi_m
 // dims d < 8 turn with y, 8 <= d < 16 with x (axial_rope.py / image_transformer_v2.py:234-248).
 __device__ __forceinline__ void qk_prep_blocks(f32x16& a0, f32x16& a1, float rs, float sqrt_scale, float eps, float py, float px,
                                                const float (&fr)[4]) {
+  // Every product / sum below is written as the instruction it must become (contraction off, explicit fmaf): this function is inlined
+  // into several kernels -- the qkv projections and the fused attention block (attn_bf16.hip), whose results are tested BIT-IDENTICAL
+  // against each other -- and left to itself the compiler fuses `x1 * c - x2 * s` one way in one kernel and the other way in the next.
+#pragma clang fp contract(off)
   float ss = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) ss = fmaf(a0[r], a0[r], fmaf(a1[r], a1[r], ss));
   ss += __shfl_xor(ss, 32, 64);
-  const float g = rs * sqrt_scale * rsqrtf(rs * rs * ss + eps);
+  const float g = rs * sqrt_scale * rsqrtf(fmaf(rs * rs, ss, eps));
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const float rev = ((r >> 2) ? px : py) * fr[r & 3];
     const float c = __builtin_amdgcn_cosf(rev), s = __builtin_amdgcn_sinf(rev);
     const float x1 = a0[r] * g, x2 = a0[r + 8] * g;
-    a0[r] = x1 * c - x2 * s;
-    a0[r + 8] = x2 * c + x1 * s;
+    const float t1 = x2 * s, t2 = x1 * s;
+    a0[r] = fmaf(x1, c, -t1);
+    a0[r + 8] = fmaf(x2, c, t2);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) a1[r] *= g;

@@ -46,7 +46,7 @@ SCHEDULE_TABLE_MAX_BYTES = 1 << 30
 SCHEDULES_KEPT = 4            # a run of a two-stage solver hints two tables; older records (and their tensors) are dropped
 SCHEDULE_CHAINS_KEPT = 2      # conditioning workspaces kept per plan, by schedule length (least recently used dropped)
 # environment switches read while a plan is built (name, default): part of the plan key
-PLAN_SWITCHES = (("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "0"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "1"), ("KDIFF_X3_PLANES", "1"),
+PLAN_SWITCHES = (("KDIFF_ATTN_BLOCK", "1"), ("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "0"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "1"), ("KDIFF_X3_PLANES", "1"),
                  ("KDIFF_X3_DOWN", "0"), ("KDIFF_RUN_LIST", "1"))
 CLASS_IDS_KEPT = 4            # range-checked class_cond tensors remembered per plan (cond / uncond pairs of a guidance wrapper)
 
@@ -459,7 +459,16 @@ class _Plan:
                 # their operands as stored instead of converting every halo / window / key-block element again
                 # (the tiled qkv epilogue keeps its per-head constants in a 16-head LDS table, csrc/gemm_x3t.hip: wider levels -- 1152 =
                 # 18 heads and up -- take the fp32-A norm -> projection kernels of round 1 like every shape the fused kernels refuse)
-                if xn is not None and prepass(d) and nh <= 16:
+                # bf16 mode, global attention at 256 tokens per sample: norm -> qkv projection of a head -> cosine-sim + RoPE -> attention in
+                # ONE launch per layer (csrc/attn_bf16.hip: attn_block_bf16_kernel; q, k, v never reach HBM).  The descriptor is the qkv
+                # projection's, its C the attention output
+                fused_block = bf and isinstance(spec, GlobalAttentionSpec) and target is self.launches and T % 256 == 0 \
+                    and os.environ.get("KDIFF_ATTN_BLOCK", "1") != "0" and bool(lib.kd_attn_block_bf16_supported(rps, d, nh))
+                if fused_block:
+                    dq = gemm(prefix + "attn_block", x, sa.qkv_proj.weight, att, T, 3 * d, d, epi=nat.EPI_QKV,
+                              scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps, qk=qk)
+                    target[-1] = _Launch(lib.kd_attn_block_bf16, (C.byref(dq),), prefix + "attn_block", enc=("kd_attn_block_bf16", (dq,)))
+                elif xn is not None and prepass(d) and nh <= 16:
                     # AdaRMSNorm -> planes once, then a GEMM whose two operands both move by LDS-DMA
                     xn_planes = norm_split(prefix + "self_attn.norm", x, scale_ptr(prefix + "self_attn.norm")[1], T, d, rps)
                     dq = gemm(prefix + "qkv_proj", None, sa.qkv_proj.weight, qkv, T, 3 * d, d, epi=nat.EPI_QKV, rows_per_sample=rps, qk=qk,
@@ -472,7 +481,9 @@ class _Plan:
                 shift = 0
                 if isinstance(spec, ShiftedWindowAttentionSpec):
                     shift = spec.window_size // 2 if index % 2 == 1 else 0          # :523
-                if bf and isinstance(spec, GlobalAttentionSpec):
+                if fused_block:
+                    pass
+                elif bf and isinstance(spec, GlobalAttentionSpec):
                     call(prefix + "attn_global", lib.kd_attn_global_bf16, _ptr(qkv), _ptr(att), B, gh * gw, nh)
                 elif bf and isinstance(spec, NeighborhoodAttentionSpec):
                     call(prefix + "attn_na2d", lib.kd_attn_na2d_bf16, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.kernel_size)

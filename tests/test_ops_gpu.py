@@ -831,6 +831,42 @@ def test_bf16_qkv_epilogue(ops, H, W, nh, B, K):
     assert relerr(qkv[..., 2, :, :], ref[..., 2, :, :]) < 1.2e-2
 
 
+@pytest.mark.parametrize("nh,B,K", [(8, 32, 512), (8, 3, 512), (4, 16, 256), (4, 5, 256)])
+def test_attn_block_bf16_matches_two_launches(KD, ops, nh, B, K):
+    """kd_attn_block_bf16 (round 5: AdaRMSNorm -> qkv projection of a head -> cosine-sim + RoPE -> dense attention in one launch per
+    (sample, head); q, k, v never reach HBM) against the two launches it replaces (kd_gemm_bf16 EPI_QKV + kd_attn_global_bf16): the same
+    arithmetic operation for operation, so BIT-IDENTICAL; and against the oracle's separate steps at the bf16 mode's tolerance.  Batches
+    that are and are not multiples of 8 (the XCD-aware and the plain workgroup order)."""
+    from k_diffusion_amd import _native as nat
+    H = W = 16
+    T, d = H * W, nh * 64
+    assert d == K and nat.lib().kd_attn_block_bf16_supported(T, K, nh) == 1
+    x, scale = rn(B, T, K, seed=8) * (1 + rn(B, T, 1, seed=3).abs()), 1 + 0.2 * rn(B, K, seed=9)
+    w = rn(3 * d, K, seed=10, scale=K ** -0.5)
+    qs = torch.linspace(5.0, 12.0, nh)
+    pos, freqs = hdit.axial_pos(H, W).reshape(T, 2), hdit.rope_freqs(nh)
+    qk = (g(qs), g(pos.contiguous()), g((freqs / (2 * np.pi)).contiguous()), nh)
+    xb, sc, wd = _bf(x), g(scale), g(w)
+    qkv = ops.norm_linear(xb, sc, wd, rows_per_sample=T, epi=nat.EPI_QKV, qk=qk)
+    two = ops.attn_global(qkv, nh)
+    one = ops.attn_block(xb, sc, wd, rows_per_sample=T, qk=qk)
+    assert one.dtype == BF and one.shape == (B, T, K)
+    ndiff = int((one != two).sum())
+    print(f"attn_block B={B} K={K}: {ndiff} of {one.numel()} outputs differ, max |diff| {float((one.float() - two.float()).abs().max()):.3e}")
+    assert torch.equal(one, two)
+    # the oracle: norm -> projection -> cosine-sim + RoPE -> softmax attention, fp32 on the bf16-rounded operands
+    ref = (hdit.rms_norm(_rt(x), scale[:, None, :]) @ _rt(w).T).view(B, H, W, 3, nh, 64)
+    theta = hdit.rope_theta(hdit.axial_pos(H, W), freqs)
+    q_ref, k_ref = hdit.cosine_sim_scale(ref[..., 0, :, :], ref[..., 1, :, :], qs)
+    q_ref, k_ref, v_ref = hdit.apply_rope(q_ref, theta), hdit.apply_rope(k_ref, theta), ref[..., 2, :, :]
+    tohead = lambda t: t.reshape(B, T, nh, 64).transpose(1, 2)
+    att = torch.softmax(tohead(q_ref) @ tohead(k_ref).transpose(-1, -2), dim=-1) @ tohead(v_ref)
+    assert relerr(one.float().cpu(), att.transpose(1, 2).reshape(B, T, K)) < 2e-2
+    # shapes it does not take are refused, not approximated
+    with pytest.raises(RuntimeError):
+        ops.attn_block(_bf(rn(2, 64, K, seed=1)), g(scale[:2]), wd, rows_per_sample=64, qk=qk)
+
+
 @pytest.mark.parametrize("H,W,nh,B,K", [(64, 64, 2, 2, 128), (32, 32, 4, 2, 256), (32, 16, 4, 3, 256), (24, 24, 2, 1, 128), (20, 20, 2, 2, 128), (16, 16, 8, 4, 512),
                                         (20, 20, 4, 3, 256), (12, 20, 8, 3, 512)])
 def test_split3_projections_round3(KD, ops, monkeypatch, H, W, nh, B, K):
