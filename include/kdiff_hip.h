@@ -261,9 +261,14 @@ int kd_attn_na2d_bf16(const void* qkv, void* out, int batch, int H, int W, int n
  * scale_stride / rows_per_sample = the AdaRMSNorm scales, qk_scale, rope_pos, rope_freq, n_heads; epi = KD_EPI_QKV, norm = 1, precision =
  * KD_PREC_BF16), except that C receives the ATTENTION OUTPUT [M, n_heads * 64] bf16: q, k, v never reach HBM.  One workgroup per (sample,
  * head).  Shapes: 256 tokens per sample, K = 64 * n_heads in {256, 512}, N = 3 K, M % 256 == 0 (kd_attn_block_bf16_supported tells);
- * anything else returns KD_EINVAL and the caller issues kd_gemm_bf16 + kd_attn_global_bf16, whose results this entry reproduces bit for bit. */
+ * anything else returns KD_EINVAL and the caller issues kd_gemm_bf16 + kd_attn_global_bf16, whose results this entry reproduces bit for bit.
+ * `out_proj` (may be NULL): the descriptor of the block's out projection + residual (:393-396; epi = KD_EPI_RESIDUAL, A = the attention
+ * output = d->C, C = R = the residual stream = d->A, N = K = d->K) -- then that projection runs in the same launch: the n_heads workgroups of a
+ * sample meet once their attention columns are stored, and workgroup (sample, h) computes the output columns 64 h .. of x += att W_out^T in
+ * place (bit-identical to kd_gemm_bf16 on that descriptor).  `sync`: 2 * batch + 1 ints of device memory owned by the caller, zeroed once
+ * (the kernel leaves the counters zero; entry [2 * batch] is set if a rendezvous timed out -- it never should). */
 int kd_attn_block_bf16_supported(int tokens_per_sample, int width, int n_heads);
-int kd_attn_block_bf16(const KdGemm* d, void* stream);
+int kd_attn_block_bf16(const KdGemm* d, const KdGemm* out_proj, int* sync, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Solver step arithmetic (k_diffusion/sampling.py), one fused elementwise launch per step with
@@ -365,7 +370,7 @@ int kd_prof_clock_buffer(void* dev_ptr);
  *   KD_OP_ATTN_WINDOW_F32 : p as above; i = batch, H, W, nh, ws, shift, prep, precision        KD_OP_ATTN_NA2D_F32 : i = batch, H, W, nh, ks, prep, precision
  *   KD_OP_ATTN_GLOBAL_BF16 : p = qkv, out; i = batch, T, nh      KD_OP_ATTN_WINDOW_BF16 : i = batch, H, W, nh, ws, shift      KD_OP_ATTN_NA2D_BF16 : i = batch, H, W, nh, ks
  *   KD_OP_NORM_SPLIT_F32 : p = x, scale, hi, lo; i = scale_stride, rows_per_sample, M, K; f = eps
- *   KD_OP_ATTN_BLOCK_BF16 : p[0] = const KdGemm* */
+ *   KD_OP_ATTN_BLOCK_BF16 : p = const KdGemm* (qkv), const KdGemm* (out projection or NULL), sync */
 enum { KD_OP_GEMM_F32 = 0, KD_OP_GEMM_BF16 = 1, KD_OP_FFN_F32 = 2, KD_OP_FFN_BF16 = 3,
        KD_OP_ATTN_GLOBAL_F32 = 4, KD_OP_ATTN_WINDOW_F32 = 5, KD_OP_ATTN_NA2D_F32 = 6,
        KD_OP_ATTN_GLOBAL_BF16 = 7, KD_OP_ATTN_WINDOW_BF16 = 8, KD_OP_ATTN_NA2D_BF16 = 9, KD_OP_NORM_SPLIT_F32 = 10,

@@ -88,7 +88,7 @@ SIGNATURES = {
     "kd_attn_window_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "kd_attn_na2d_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "kd_attn_block_bf16_supported": [_i, _i, _i],
-    "kd_attn_block_bf16": [C.POINTER(KdGemm), _vp],
+    "kd_attn_block_bf16": [C.POINTER(KdGemm), C.POINTER(KdGemm), _vp, _vp],
     "kd_packed_weight_bytes": [_i, _i, _i],
     "kd_pack_weight_bf16x3": [_vp, _vp, _i, _i, _i, _vp],
     "kd_rmsnorm_f32": [_vp, _vp, _vp, _i, _i, _f, _vp],

@@ -150,7 +150,9 @@ extern "C" int kd_run_list(const KdCall* calls, int n, void* stream, int* failed
         rc = kd_norm_split_f32(static_cast<const float*>(c.p[0]), static_cast<const float*>(c.p[1]), i[0], i[1], const_cast<void*>(c.p[2]), const_cast<void*>(c.p[3]), i[2], i[3],
                                c.f, stream);
         break;
-      case KD_OP_ATTN_BLOCK_BF16: rc = kd_attn_block_bf16(static_cast<const KdGemm*>(c.p[0]), stream); break;
+      case KD_OP_ATTN_BLOCK_BF16:
+        rc = kd_attn_block_bf16(static_cast<const KdGemm*>(c.p[0]), static_cast<const KdGemm*>(c.p[1]), static_cast<int*>(const_cast<void*>(c.p[2])), stream);
+        break;
       default: rc = kd::fail(KD_EINVAL, "kd_run_list: entry %d names no entry point (op %d)", k, c.op);
     }
     if (rc != KD_OK) {

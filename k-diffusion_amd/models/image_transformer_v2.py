@@ -46,7 +46,7 @@ SCHEDULE_TABLE_MAX_BYTES = 1 << 30
 SCHEDULES_KEPT = 4            # a run of a two-stage solver hints two tables; older records (and their tensors) are dropped
 SCHEDULE_CHAINS_KEPT = 2      # conditioning workspaces kept per plan, by schedule length (least recently used dropped)
 # environment switches read while a plan is built (name, default): part of the plan key
-PLAN_SWITCHES = (("KDIFF_ATTN_BLOCK", "1"), ("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "0"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "1"), ("KDIFF_X3_PLANES", "1"),
+PLAN_SWITCHES = (("KDIFF_ATTN_BLOCK", "2"), ("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "0"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "1"), ("KDIFF_X3_PLANES", "1"),
                  ("KDIFF_X3_DOWN", "0"), ("KDIFF_RUN_LIST", "1"))
 CLASS_IDS_KEPT = 4            # range-checked class_cond tensors remembered per plan (cond / uncond pairs of a guidance wrapper)
 
@@ -288,6 +288,7 @@ class _Plan:
         self.main_entry = torch.cuda.Event()
         self.schedules, self.schedule_chains = [], {}       # conditioning of whole sigma schedules (prefetch_schedule); chains by length
         self.keep += [xs, qkv, att, hid, wcat]
+        self.block_sync = None                              # counters of kd_attn_block_bf16's fused out projection (zeroed once; the kernel leaves them zero)
         self.xs = xs
 
         def gemm(what, A, Wt, Cc, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, scale_ptr=None, scale_stride=0,
@@ -463,11 +464,25 @@ class _Plan:
                 # ONE launch per layer (csrc/attn_bf16.hip: attn_block_bf16_kernel; q, k, v never reach HBM).  The descriptor is the qkv
                 # projection's, its C the attention output
                 fused_block = bf and isinstance(spec, GlobalAttentionSpec) and target is self.launches and T % 256 == 0 \
-                    and os.environ.get("KDIFF_ATTN_BLOCK", "1") != "0" and bool(lib.kd_attn_block_bf16_supported(rps, d, nh))
+                    and os.environ.get("KDIFF_ATTN_BLOCK", "2") != "0" and bool(lib.kd_attn_block_bf16_supported(rps, d, nh))
+                fused_out_proj = False
                 if fused_block:
                     dq = gemm(prefix + "attn_block", x, sa.qkv_proj.weight, att, T, 3 * d, d, epi=nat.EPI_QKV,
                               scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps, qk=qk)
-                    target[-1] = _Launch(lib.kd_attn_block_bf16, (C.byref(dq),), prefix + "attn_block", enc=("kd_attn_block_bf16", (dq,)))
+                    target.pop()
+                    do = None
+                    if not fuse_out and os.environ.get("KDIFF_ATTN_BLOCK", "2") == "2":
+                        # ... and the block's out projection + residual in the same launch (the sample's workgroups meet once its
+                        # attention columns are stored; KDIFF_ATTN_BLOCK=1: two launches)
+                        do = gemm(prefix + "out_proj", att, sa.out_proj.weight, x, T, d, d, epi=nat.EPI_RESIDUAL, R=x)
+                        target.pop()
+                        if self.block_sync is None:
+                            self.block_sync = torch.zeros(2 * B + 1, device=device, dtype=torch.int32)
+                    sync_p = C.c_void_p(self.block_sync.data_ptr()) if do is not None else None
+                    target.append(_Launch(lib.kd_attn_block_bf16, (C.byref(dq), C.byref(do) if do is not None else None, sync_p),
+                                          prefix + ("attn_block+out" if do is not None else "attn_block"),
+                                          enc=("kd_attn_block_bf16", (dq, do, sync_p))))
+                    fused_out_proj = do is not None
                 elif xn is not None and prepass(d) and nh <= 16:
                     # AdaRMSNorm -> planes once, then a GEMM whose two operands both move by LDS-DMA
                     xn_planes = norm_split(prefix + "self_attn.norm", x, scale_ptr(prefix + "self_attn.norm")[1], T, d, rps)
@@ -495,7 +510,7 @@ class _Plan:
                     call(prefix + "attn_na2d", lib.kd_attn_na2d_f32, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.kernel_size, *prep)
                 else:
                     call(prefix + "attn_window", lib.kd_attn_window_f32, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.window_size, shift, *prep)
-                if not fuse_out:
+                if not fuse_out and not fused_out_proj:
                     gemm(prefix + "out_proj", att, sa.out_proj.weight, x, T, d, d, epi=nat.EPI_RESIDUAL, R=x)
             if ffn_x3:
                 # fp32-parity mode: the whole FeedForwardBlock in one kernel (csrc/ffn_x3.hip), hidden activation on the chip; at widths 128 / 256

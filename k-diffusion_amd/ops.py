@@ -78,16 +78,15 @@ def pack_weight(W, N, K, geglu, cache=True, bf16=False):
 def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scale=None, scale_stride=0,
          rows_per_sample=0, residual=None, grid=(0, 0), patch=(0, 0, 0), eps=1e-6, out_add=0.0,
          sigma=None, sigma_data=1.0, fac=None, scale_ptr=None, precision=None, qk=None, qkv_packed=False, per_row=False,
-         a_planes=None, c_planes=None, attn_block=False):
+         a_planes=None, c_planes=None, launch=True):
     """Fused GEMM (see KdGemm in include/kdiff_hip.h).  ``norm_scale`` may be a tensor or, with
     ``scale_ptr``, a raw device address inside a larger scale table.  ``precision``: nat.PREC_EXACT /
     nat.PREC_SPLIT3 / nat.PREC_BF16 (default: KDIFF_GEMM env, split3).  In bf16 mode A, out and residual are bf16 tensors
     (except the fp32 image side of the patch modes) and ``qk`` = (scale_h, rope_pos [T, 2], rope_freq [nh, 8], nh).
     ``per_row`` (fp32 modes): the per-row FMA kernel of the conditioning chain whatever M (KdGemm.per_row).
     ``a_planes`` / ``c_planes`` (split3): (hi, lo) bf16 tensors instead of the fp32 ``A`` / ``out`` (KdGemm.a_split / c_split; ``A`` / ``out``
-    are then ignored and may be None).
-    ``attn_block`` (bf16 mode, EPI_QKV): the descriptor goes to kd_attn_block_bf16 -- norm -> qkv projection -> cosine-sim + RoPE -> global
-    attention in one launch -- and ``out`` [M, n_heads * 64] receives the ATTENTION OUTPUT instead of qkv."""
+    are then ignored and may be None).  ``launch=False``: only build and return the descriptor (for entry points that take one, e.g.
+    kd_attn_block_bf16)."""
     d = nat.KdGemm()
     d.per_row = 1 if per_row else 0
     d.precision = nat.default_precision() if precision is None else precision
@@ -129,11 +128,9 @@ def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scal
         if len(qk) >= 6:        # + (rope_pos [T, 2], rope_freq [nh, 8] in revolutions): the round-3 split3 kernel evaluates the angles itself
             d.rope_pos, d.rope_freq = _chk(qk[4], "rope_pos").data_ptr(), _chk(qk[5], "rope_freq").data_ptr()
         d.qkv_packed = 1 if qkv_packed else 0      # q, k, v stored as split-bf16 chunks for the attention cores (prep="packed")
-    if attn_block:
-        if not bf:
-            raise ValueError("attn_block: bf16 mode only")
-        nat.check(nat.lib().kd_attn_block_bf16(C.byref(d), _stream()), "kd_attn_block_bf16")
-    elif bf:
+    if not launch:
+        return d
+    if bf:
         nat.check(nat.lib().kd_gemm_bf16(C.byref(d), _stream()), "kd_gemm_bf16")
     else:
         nat.check(nat.lib().kd_gemm_f32(C.byref(d), _stream()), "kd_gemm_f32")
@@ -201,15 +198,30 @@ def norm_linear(x, scale, weight, *, rows_per_sample, epi=nat.EPI_STORE, out=Non
                 rows_per_sample=rows_per_sample, eps=eps, qk=qk, qkv_packed=qkv_packed, precision=_prec_of(x))
 
 
-def attn_block(x, scale, weight, *, rows_per_sample, qk, out=None, eps=1e-6):
-    """The global-attention block in front of its out projection as one launch (kd_attn_block_bf16; image_transformer_v2.py:370-392):
-    x [B, T, K] bf16, ``scale`` [B, K] AdaRMSNorm scales, ``weight`` the qkv projection [3 K, K], ``qk`` = (scale_h [nh], rope_pos [T, 2],
-    rope_freq [nh, 8] in revolutions, nh) -> attention output [B, T, K] bf16.  256 tokens per sample, K = 64 nh in {256, 512}."""
+_attn_block_sync = {}
+
+
+def attn_block(x, scale, weight, *, rows_per_sample, qk, out=None, eps=1e-6, w_out=None):
+    """The global-attention block as one launch (kd_attn_block_bf16; image_transformer_v2.py:370-396): x [B, T, K] bf16, ``scale`` [B, K]
+    AdaRMSNorm scales, ``weight`` the qkv projection [3 K, K], ``qk`` = (scale_h [nh], rope_pos [T, 2], rope_freq [nh, 8] in revolutions, nh)
+    -> attention output [B, T, K] bf16 (``out``).  With ``w_out`` [K, K] the out projection + residual runs in the same launch and ``x`` is
+    updated IN PLACE (x += att w_out^T); returns (attention output, x).  256 tokens per sample, K = 64 nh in {256, 512}."""
     K = x.shape[-1]
     M = x.numel() // K
     out = torch.empty_like(x) if out is None else out
-    return gemm(x, weight, out, M=M, N=3 * K, K=K, epi=nat.EPI_QKV, norm_scale=scale, scale_stride=K, rows_per_sample=rows_per_sample, eps=eps,
-                qk=qk, precision=nat.PREC_BF16, attn_block=True)
+    d = gemm(x, weight, out, M=M, N=3 * K, K=K, epi=nat.EPI_QKV, norm_scale=scale, scale_stride=K, rows_per_sample=rows_per_sample, eps=eps,
+             qk=qk, precision=nat.PREC_BF16, launch=False)
+    if w_out is None:
+        nat.check(nat.lib().kd_attn_block_bf16(C.byref(d), None, None, _stream()), "kd_attn_block_bf16")
+        return out
+    do = gemm(out, w_out, x, M=M, N=K, K=K, epi=nat.EPI_RESIDUAL, residual=x, precision=nat.PREC_BF16, launch=False)
+    B = M // max(rows_per_sample, 1)
+    key = (x.device, B)
+    sync = _attn_block_sync.get(key)
+    if sync is None:
+        sync = _attn_block_sync[key] = torch.zeros(2 * B + 1, device=x.device, dtype=torch.int32)
+    nat.check(nat.lib().kd_attn_block_bf16(C.byref(d), C.byref(do), _p(sync), _stream()), "kd_attn_block_bf16")
+    return out, x, sync
 
 
 def token_merge(x, weight, out=None):

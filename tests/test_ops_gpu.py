@@ -862,6 +862,18 @@ def test_attn_block_bf16_matches_two_launches(KD, ops, nh, B, K):
     tohead = lambda t: t.reshape(B, T, nh, 64).transpose(1, 2)
     att = torch.softmax(tohead(q_ref) @ tohead(k_ref).transpose(-1, -2), dim=-1) @ tohead(v_ref)
     assert relerr(one.float().cpu(), att.transpose(1, 2).reshape(B, T, K)) < 2e-2
+    # ... and with the block's out projection + residual in the same launch: x += att W_out^T in place, bit-identical to the tiled projection
+    # (several launches back to back: the per-sample counters must come back to zero each time)
+    wo = g(rn(K, K, seed=12, scale=0.5 * K ** -0.5))
+    x_two = xb.clone()
+    ops.gemm(two, wo, x_two, M=B * T, N=K, K=K, epi=nat.EPI_RESIDUAL, residual=x_two, precision=nat.PREC_BF16)
+    for rep in range(3):
+        x_one = xb.clone()
+        att1, x_new, sync = ops.attn_block(x_one, sc, wd, rows_per_sample=T, qk=qk, w_out=wo)
+        assert x_new is x_one and torch.equal(att1, two)
+        assert torch.equal(x_one, x_two), (rep, int((x_one != x_two).sum()))
+        assert not sync.any()                                     # counters cleared, no rendezvous timed out
+    assert relerr(x_two.float().cpu(), x.float().bfloat16().float() + att.transpose(1, 2).reshape(B, T, K) @ _rt(wo.cpu()).T) < 2e-2
     # shapes it does not take are refused, not approximated
     with pytest.raises(RuntimeError):
         ops.attn_block(_bf(rn(2, 64, K, seed=1)), g(scale[:2]), wd, rows_per_sample=64, qk=qk)
