@@ -280,17 +280,27 @@ __device__ __forceinline__ void row_to_image(char* img, int rowi, const f32x16& 
   }
 }
 
-// Rendezvous of the n workgroups that share a sample (OUTP): one thread per workgroup arrives (release: this workgroup's stores are visible
-// device-wide) and waits until all n have (acquire).  They are resident together -- ids 8 apart inside one group of 8 n consecutive ids, one
-// workgroup per CU, dispatched in id order -- so nobody waits for a workgroup that cannot start; a bounded wait (~1 s) guards the assumption:
-// on expiry the flag behind the counters is set and the workgroup goes on (wrong numbers, reported by the host wrapper's check, no hang).
-__device__ __forceinline__ void sample_rendezvous(int* arrive, int target, int* flag) {
-  __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+// Rendezvous of the n workgroups that share a sample (OUTP): one thread per workgroup arrives and waits until all n have.  They are resident
+// together -- ids 8 apart inside one group of 8 n consecutive ids, one workgroup per CU, dispatched in id order -- so nobody waits for a
+// workgroup that cannot start; a bounded wait (~1 s) guards the assumption: on expiry the flag behind the counters is set and the workgroup goes
+// on (wrong numbers, reported by the host wrapper's check, no hang).
+// Memory order.  With the XCD-aware placement (batch % 8 == 0) the n workgroups sit on ONE XCD and exchange through its L2: a store is
+// acknowledged by the L2 (vmcnt), atomics execute there, and the readers fetch the attention rows with sc1 loads that do not stop in their
+// CU's vector cache -- no cache maintenance at all (`same_l2`).  An agent-scope release / acquire pair instead writes back and invalidates the
+// WHOLE L2 (buffer_wbl2 / buffer_inv sc1): measured 15 k clocks per rendezvous and an out-projection pass that then missed on every line; it is
+// kept for the plain placement only, where the workgroups of a sample are spread over the XCDs.
+__device__ __forceinline__ void sample_rendezvous(int* arrive, int target, int* flag, bool same_l2) {
+  if (!same_l2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int spins = 0;
-  while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    __builtin_amdgcn_s_sleep(8);
-    if (++spins > (1 << 21)) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+  while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > (1 << 23)) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
   }
+  if (!same_l2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void glds16_sc1(const void* src, void* dst) {       // sc1: served by the L2, not by this CU's vector cache
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 16);
 }
 
 // TS: in-kernel time line of workgroup 0 (kd_prof_clock_buffer; a template flag so that the measured kernel's loops stay what they are):
@@ -530,7 +540,7 @@ __global__ __launch_bounds__(512, 1) void attn_block_bf16_kernel(const BArgs p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's attention rows are out (and the residual pieces in)
     KD_BARRIER();
     if (tid == 0) {
-      sample_rendezvous(p.sync + 2 * b, p.nh, p.sync + 2 * p.batch);
+      sample_rendezvous(p.sync + 2 * b, p.nh, p.sync + 2 * p.batch, (p.batch & 7) == 0);
       // everybody of this sample is past its wait once all have departed: the last one clears the counters for the next launch
       if (__hip_atomic_fetch_add(p.sync + 2 * b + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.nh - 1) {
         __hip_atomic_store(p.sync + 2 * b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(512, 1) void attn_block_bf16_kernel(const BArgs p) 
         for (int i = 0; i < 16; ++i) {
           const int rr = (i * 64 + lane_o) / CPR, qs = (i * 64 + lane_o) % CPR;
           const size_t grow = (size_t)b * T + wid * 32 + r * RPR + rr;
-          glds16(reinterpret_cast<const char*>(p.out + grow * K) + ((qs ^ (rr & 15)) << 4), stage + i * 1024);
+          glds16_sc1(reinterpret_cast<const char*>(p.out + grow * K) + ((qs ^ (rr & 15)) << 4), stage + i * 1024);
         }
         KD_WAIT_VM(0);
         if (NR == 1 || (l31_o / RPR) == r) {

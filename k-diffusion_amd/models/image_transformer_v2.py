@@ -46,7 +46,7 @@ SCHEDULE_TABLE_MAX_BYTES = 1 << 30
 SCHEDULES_KEPT = 4            # a run of a two-stage solver hints two tables; older records (and their tensors) are dropped
 SCHEDULE_CHAINS_KEPT = 2      # conditioning workspaces kept per plan, by schedule length (least recently used dropped)
 # environment switches read while a plan is built (name, default): part of the plan key
-PLAN_SWITCHES = (("KDIFF_ATTN_BLOCK", "2"), ("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "0"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "1"), ("KDIFF_X3_PLANES", "1"),
+PLAN_SWITCHES = (("KDIFF_ATTN_BLOCK", "1"), ("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "0"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "1"), ("KDIFF_X3_PLANES", "1"),
                  ("KDIFF_X3_DOWN", "0"), ("KDIFF_RUN_LIST", "1"))
 CLASS_IDS_KEPT = 4            # range-checked class_cond tensors remembered per plan (cond / uncond pairs of a guidance wrapper)
 
@@ -464,16 +464,18 @@ class _Plan:
                 # ONE launch per layer (csrc/attn_bf16.hip: attn_block_bf16_kernel; q, k, v never reach HBM).  The descriptor is the qkv
                 # projection's, its C the attention output
                 fused_block = bf and isinstance(spec, GlobalAttentionSpec) and target is self.launches and T % 256 == 0 \
-                    and os.environ.get("KDIFF_ATTN_BLOCK", "2") != "0" and bool(lib.kd_attn_block_bf16_supported(rps, d, nh))
+                    and os.environ.get("KDIFF_ATTN_BLOCK", "1") != "0" and bool(lib.kd_attn_block_bf16_supported(rps, d, nh))
                 fused_out_proj = False
                 if fused_block:
                     dq = gemm(prefix + "attn_block", x, sa.qkv_proj.weight, att, T, 3 * d, d, epi=nat.EPI_QKV,
                               scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps, qk=qk)
                     target.pop()
                     do = None
-                    if not fuse_out and os.environ.get("KDIFF_ATTN_BLOCK", "2") == "2":
-                        # ... and the block's out projection + residual in the same launch (the sample's workgroups meet once its
-                        # attention columns are stored; KDIFF_ATTN_BLOCK=1: two launches)
+                    if not fuse_out and os.environ.get("KDIFF_ATTN_BLOCK", "1") == "2":
+                        # KDIFF_ATTN_BLOCK=2 (on request): the block's out projection + residual in the same launch too -- the sample's
+                        # workgroups meet once its attention columns are stored.  Bit-identical, but measured LEVEL with the separate launch
+                        # (37.1 us against 25.8 + 14.6 at the level-2 shape; 440 against 442 images/s): the wait for the slowest sibling
+                        # (~5 us) and re-staging the 256 attention rows (~3.7 us) cost what the saved launch gave.  Default 1.
                         do = gemm(prefix + "out_proj", att, sa.out_proj.weight, x, T, d, d, epi=nat.EPI_RESIDUAL, R=x)
                         target.pop()
                         if self.block_sync is None:
