@@ -87,3 +87,25 @@ for B, nh in ((32, 8), (64, 4)):
     print(f"   workgroup 0 (clocks, {mhz:.0f} MHz): rows normalised {rel(4)}, k pass {rel(5) - rel(4)}, v pass {rel(6) - rel(5)}, q pass {rel(8) - rel(6)}, "
           f"scores + softmax {rel(9) - rel(8)}, PV + store {rel(10) - rel(9)}, rendezvous {rel(11) - rel(10)}, out projection {rel(2) - rel(11)}, "
           f"total {rel(2)} = {rel(2) / mhz:.1f} us", flush=True)
+
+# ---- where does the one-launch form pay?  Batch sweep at the level-2 shape with the library's defaults (few-rows kernels on) ----------------
+print("batch sweep, K = 512, nh = 8 (two launches: the kernels the planner would pick at that row count)")
+for B in (1, 2, 4, 8, 16, 32, 64):
+    nh, Kw, T = 8, 512, 256
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, T, Kw, generator=g).to(dev).to(torch.bfloat16)
+    scale = (1 + 0.2 * torch.randn(B, Kw, generator=g)).to(dev)
+    w = (torch.randn(3 * Kw, Kw, generator=g) * Kw ** -0.5).to(dev)
+    qk = (torch.linspace(5., 12., nh).to(dev), hdit.axial_pos(16, 16).reshape(T, 2).contiguous().to(dev),
+          (hdit.rope_freqs(nh) / (2 * np.pi)).contiguous().to(dev), nh)
+    qkv = torch.empty(B, T, 3 * Kw, device=dev, dtype=torch.bfloat16)
+    att2, att1 = torch.empty_like(x), torch.empty_like(x)
+
+    def two():
+        ops.norm_linear(x, scale, w, rows_per_sample=T, epi=nat.EPI_QKV, qk=qk, out=qkv)
+        ops.attn_global(qkv, nh, out=att2)
+
+    def one():
+        ops.attn_block(x, scale, w, rows_per_sample=T, qk=qk, out=att1)
+    t2, t1 = timed(two), timed(one)
+    print(f"   B={B:3d}: two launches {t2:6.1f} us, one launch {t1:6.1f} us, max |diff| {float((att1.float() - att2.float()).abs().max()):.2e}", flush=True)

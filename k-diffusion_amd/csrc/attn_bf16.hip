@@ -338,67 +338,70 @@ __global__ __launch_bounds__(512, 1) void attn_block_bf16_kernel(const BArgs p) 
   const int tok = wid * 32 + l31;                         // this lane's token of the sample: its row, later its query
   const size_t row = (size_t)b * T + tok;
 
-  // ---- the wave's 32 rows -> normalised, scaled B fragments (gemm_astat_kernel's prologue) ------------------------------------------
+  // ---- the wave's 32 rows -> normalised, scaled B fragments ---------------------------------------------------------------------------
+  // gemm_astat_kernel's arithmetic (same products, same order of the sum of squares), another staging schedule: the rows come in by
+  // K-HALVES of 256 elements -- all 32 rows x 512 bytes per round into the wave's 16 KiB slot, every lane reads its own row's 16 chunks (at
+  // K = 512 the row-halves schedule of the projection kernel leaves half the lanes idle in each round) -- and the second half is in flight
+  // while the first is converted.
   bf16x8 a[NC];
   float rs;
   {
-    constexpr int RPR = WBLK / (2 * K);                // rows per staging round (one 16 KiB slot): 16 at K = 512, 32 at K = 256
-    constexpr int NR = 32 / RPR, CPR = K / 8;          // rounds; 16-byte chunks per row
-    static_assert(RPR >= 16 && NR * RPR == 32, "staging geometry");
-    u32x4 raw[NC];
+    constexpr int NH = K / 256;                        // rounds
     char* stage = smem + wid * WBLK;
     char* scl = smem + 8 * WBLK + wid * (K * 4);
     const char* ssrc = reinterpret_cast<const char*>(p.scale + (size_t)b * p.scale_stride) + lane * 16;
 #pragma unroll
     for (int i = 0; i < K * 4 / 1024; ++i) glds16(ssrc + i * 1024, scl + i * 1024);
-    float ssq = 0.f;
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
+    auto request = [&](int h) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int rr = (i * 64 + lane) / CPR, qs = (i * 64 + lane) % CPR;        // LDS row of this lane's piece, its slot in the row
-        const size_t grow = (size_t)b * T + wid * 32 + r * RPR + rr;
-        glds16(reinterpret_cast<const char*>(p.x + grow * K) + ((qs ^ (rr & 15)) << 4), stage + i * 1024);
-      }
-      KD_WAIT_VM(0);                                   // wave-private slot: no barrier
-      if (NR == 1 || (l31 / RPR) == r) {
-        const int rr = l31 % RPR;
-        const char* rowp = stage + rr * (2 * K);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) raw[c] = *reinterpret_cast<const u32x4*>(rowp + (((2 * c + lh) ^ (rr & 15)) << 4));
-      }
-      if (NR > 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is overwritten by the next round
-    }
-    // scales two chunks at a time, one pair ahead (gemm_astat_kernel keeps two groups of four: 64 registers; this kernel carries 2 waves per
-    // SIMD and, with the out projection, a few more live values -- 32 registers of scales keep it clear of scratch)
-    f32x4 s0[2][2], s1[2][2];
-    const float* spl = reinterpret_cast<const float*>(scl) + 8 * lh;
-    auto load_scales = [&](int c0, int g) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        s0[g][u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u));
-        s1[g][u] = *reinterpret_cast<const f32x4*>(spl + 16 * (c0 + u) + 4);
+        const int rr = (i * 64 + lane) >> 5, qs = (i * 64 + lane) & 31;          // LDS row of this lane's piece, its slot in the half row
+        const size_t grow = (size_t)b * T + wid * 32 + rr;
+        glds16(reinterpret_cast<const char*>(p.x + grow * K) + h * 512 + ((qs ^ (rr & 15)) << 4), stage + i * 1024);
       }
     };
-    load_scales(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+    float ssq = 0.f;
+    const float* spl = reinterpret_cast<const float*>(scl) + 8 * lh;
+    const char* rowp = stage + l31 * 512;
+    request(0);
 #pragma unroll
-    for (int c0 = 0; c0 < NC; c0 += 2) {
-      const int g = (c0 >> 1) & 1;
-      if (c0 + 2 < NC) load_scales(c0 + 2, g ^ 1);
+    for (int h = 0; h < NH; ++h) {
+      u32x4 raw[16];
+      KD_WAIT_VM(0);                                   // wave-private slot: no barrier
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { x[2 * e] = bf_lo(raw[c0 + u][e]); x[2 * e + 1] = bf_hi(raw[c0 + u][e]); }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ssq = fmaf(x[e], x[e], ssq);
-        u32x4 o = {pack_bf16(x[0] * s0[g][u][0], x[1] * s0[g][u][1]), pack_bf16(x[2] * s0[g][u][2], x[3] * s0[g][u][3]),
-                   pack_bf16(x[4] * s1[g][u][0], x[5] * s1[g][u][1]), pack_bf16(x[6] * s1[g][u][2], x[7] * s1[g][u][3])};
-        asm volatile("" : "+v"(o));
-        a[c0 + u] = __builtin_bit_cast(bf16x8, o);
+      for (int c = 0; c < 16; ++c) raw[c] = *reinterpret_cast<const u32x4*>(rowp + (((2 * c + lh) ^ (l31 & 15)) << 4));
+      if (h + 1 < NH) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is overwritten by the next round
+        request(h + 1);
       }
+      f32x4 s0[2][2], s1[2][2];
+      auto load_scales = [&](int c0, int g) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          s0[g][u] = *reinterpret_cast<const f32x4*>(spl + 16 * (16 * h + c0 + u));
+          s1[g][u] = *reinterpret_cast<const f32x4*>(spl + 16 * (16 * h + c0 + u) + 4);
+        }
+      };
+      load_scales(0, 0);
       __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c0 = 0; c0 < 16; c0 += 2) {
+        const int g = (c0 >> 1) & 1;
+        if (c0 + 2 < 16) load_scales(c0 + 2, g ^ 1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { x[2 * e] = bf_lo(raw[c0 + u][e]); x[2 * e + 1] = bf_hi(raw[c0 + u][e]); }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ssq = fmaf(x[e], x[e], ssq);
+          u32x4 o = {pack_bf16(x[0] * s0[g][u][0], x[1] * s0[g][u][1]), pack_bf16(x[2] * s0[g][u][2], x[3] * s0[g][u][3]),
+                     pack_bf16(x[4] * s1[g][u][0], x[5] * s1[g][u][1]), pack_bf16(x[6] * s1[g][u][2], x[7] * s1[g][u][3])};
+          asm volatile("" : "+v"(o));
+          a[16 * h + c0 + u] = __builtin_bit_cast(bf16x8, o);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     ssq += __shfl_xor(ssq, 32, 64);
     rs = rsqrtf(ssq / (float)K + p.eps);

@@ -463,8 +463,11 @@ class _Plan:
                 # bf16 mode, global attention at 256 tokens per sample: norm -> qkv projection of a head -> cosine-sim + RoPE -> attention in
                 # ONE launch per layer (csrc/attn_bf16.hip: attn_block_bf16_kernel; q, k, v never reach HBM).  The descriptor is the qkv
                 # projection's, its C the attention output
+                # From 32 (sample, head) workgroups on: below that (batch 1 - 2 at level 2) the few-rows projection + the dense core are faster
+                # (0.514 against 0.543 ms per forward at batch 1; from batch 4 on the one-launch form wins: profiles/r05_attn_block.md)
                 fused_block = bf and isinstance(spec, GlobalAttentionSpec) and target is self.launches and T % 256 == 0 \
-                    and os.environ.get("KDIFF_ATTN_BLOCK", "1") != "0" and bool(lib.kd_attn_block_bf16_supported(rps, d, nh))
+                    and os.environ.get("KDIFF_ATTN_BLOCK", "1") != "0" and bool(lib.kd_attn_block_bf16_supported(rps, d, nh)) \
+                    and (B * nh >= 32 or os.environ.get("KDIFF_ATTN_BLOCK", "1") == "force")
                 fused_out_proj = False
                 if fused_block:
                     dq = gemm(prefix + "attn_block", x, sa.qkv_proj.weight, att, T, 3 * d, d, epi=nat.EPI_QKV,
