@@ -417,6 +417,38 @@ MODE_DTYPE = {
 }
 
 
+def global_attention_block(groups, mode, cfg, batch, model_calls):
+    """north_star's one named efficiency figure: the GLOBAL-ATTENTION level of the network (the last level of the hourglass: norm -> qkv ->
+    attention -> out projection -> norm -> GEGLU up -> down, image_transformer_v2.py:370-396,487-493) as a fraction of the dense bf16 MFMA
+    peak, from this pass's per-launch HIP events: every launch whose row count is that level's (batch x its tokens) except the token merge
+    into it and the split out of it, plus the attention cores of that level.  flops = 2 M N K of the products + 4 T^2 d of the cores (the
+    split-bf16x3 kernels EXECUTE three times that)."""
+    mc = cfg["model"]
+    n_lv = len(mc["depths"])
+    if mc["self_attns"][n_lv - 1]["type"] != "global":
+        return None
+    ph, pw = mc["patch_size"]
+    tokens = (mc["input_size"][0] // ph >> (n_lv - 1)) * (mc["input_size"][1] // pw >> (n_lv - 1))
+    tag = f" M={batch * tokens} "
+    picked = {}
+    for name, g in groups.items():
+        level_gemm = tag in name + " " and "<a1," not in name and ",e3>" not in name and "e3," not in name
+        if level_gemm or name.startswith(("attn_global", "attn_block")):
+            picked[name] = g
+    if not picked:
+        return None
+    layers = mc["depths"][n_lv - 1] * model_calls
+    ms = sum(g["ms"] for g in picked.values())
+    fl = sum(g["flops"] for g in picked.values())
+    tf = fl / (ms * 1e-3) / 1e12
+    return {"level_width": mc["widths"][n_lv - 1], "tokens_per_sample": tokens, "layers_timed": layers,
+            "launches_per_layer": round(sum(g["launches"] for g in picked.values()) / layers, 2),
+            "us_per_layer": round(ms * 1e3 / layers, 2), "gflop_per_layer": round(fl / layers / 1e9, 2), "algorithmic_tflops": round(tf, 1),
+            "frac_of_bf16_mfma_peak": round(tf / BF16_MFMA_PEAK_TFLOPS, 4),
+            "executed_frac_of_bf16_mfma_peak": round(tf * (3.0 if mode == "split3" else 1.0) / BF16_MFMA_PEAK_TFLOPS, 4) if mode != "exact" else None,
+            "kernels_us": {n: round(g["ms"] * 1e3 / max(g["launches"], 1), 2) for n, g in sorted(picked.items(), key=lambda kv: -kv[1]["ms"])}}
+
+
 def roofline_of(groups, mode, pass_seconds):
     """`roofline` object of one arithmetic mode from its own HIP-event pass (kernel_table())."""
     fam = {}
@@ -639,6 +671,10 @@ def main():
     if ctx.is_main_process:
         n_img = args.gpus * B * args.steps
         head, fam = mode_entry(args.mode, dt, args.steps, args.warmup, n_img, groups, args.gpus)
+        nfe_of = {"sample_dpmpp_2m": args.sampler_steps, "sample_euler": args.sampler_steps, "sample_lms": args.sampler_steps,
+                  "sample_heun": 2 * args.sampler_steps - 1, "sample_dpmpp_sde": 2 * args.sampler_steps - 1}.get(args.sampler)
+        if groups and nfe_of and "roofline" in head:
+            head["roofline"]["global_attention_block"] = global_attention_block(groups, args.mode, cfg, B, nfe_of)
         if args.kernel_table and groups:
             with open(args.kernel_table, "w") as f:
                 json.dump({"mode": args.mode, "families": fam, "kernels": groups, "timed_seconds": dt}, f, indent=1)
@@ -671,6 +707,8 @@ def main():
                 os.environ["KDIFF_GEMM"] = m
                 dt_m, out_m, groups_m = Timed(ctx, args.steps, args.warmup, not args.no_kernel_events).run(compute_only)
                 ent, fam_m = mode_entry(m, dt_m, args.steps, args.warmup, B * args.steps, groups_m, 1)
+                if groups_m and nfe_of and "roofline" in ent:
+                    ent["roofline"]["global_attention_block"] = global_attention_block(groups_m, m, cfg, B, nfe_of)
                 ent["max_rel_diff_vs_" + args.mode] = round(float((out_m - out[:B]).abs().max() / out[:B].abs().max()), 6)
                 result["modes"][m] = ent
                 if args.kernel_table and groups_m:
