@@ -156,7 +156,7 @@ def pmc_traffic(kernel_family):
     passes, gfx950 FETCH x2 correction: profiles/summarize_pmc.py); None when the summary has no matching entry."""
     if not kernel_family:
         return None
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):        # newest committed summary that knows the kernel
+    for name in ("r05_pmc_traffic.json", "r05_pmc_traffic_bf16.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):        # newest committed summary that knows the kernel
         path = os.path.join(REPO, "profiles", name)
         try:
             table = json.load(open(path))
@@ -357,12 +357,42 @@ def power_limits():
             "sclk_levels_mhz": levels or None}
 
 
+def throttle_accumulators():
+    """The firmware's own throttle accounting (amd-smi metric --violation, MI300 and newer): a free-running accumulation counter and, per
+    limiter, how many of its ticks were spent limited -- package power tracking (PPT), PROCHOT, socket / VR / HBM thermal.  None where the
+    tool or a field is missing."""
+    import subprocess
+    try:
+        txt = subprocess.run(["amd-smi", "metric", "--violation", "--json"], capture_output=True, text=True, timeout=15).stdout
+        data = json.loads(txt)
+    except Exception:
+        return None
+    found = {}
+
+    def walk(node):
+        if isinstance(node, dict):
+            for k, v in node.items():
+                kl = str(k).lower()
+                if kl in ("accumulation_counter", "ppt_accumulated", "prochot_accumulated", "socket_thermal_accumulated", "vr_thermal_accumulated",
+                          "hbm_thermal_accumulated") and kl not in found:
+                    val = v.get("value") if isinstance(v, dict) else v
+                    if isinstance(val, (int, float)):
+                        found[kl] = int(val)
+                walk(v)
+        elif isinstance(node, list):
+            for v in node:
+                walk(v)
+    walk(data)
+    return found if "accumulation_counter" in found else None
+
+
 def power_and_clock(one_pass, passes=16):
     """Socket power and shader clock while the path runs: `passes` more untimed passes with rocm-smi sampled from a side thread (the timed
     region is not touched), next to the board's power cap.  None if rocm-smi is unavailable."""
     import re
     import threading
     limits = power_limits()
+    acc0 = throttle_accumulators()
     stop, out = threading.Event(), []
 
     def sample():
@@ -382,6 +412,14 @@ def power_and_clock(one_pass, passes=16):
     torch.cuda.synchronize()
     stop.set()
     th.join(timeout=10)
+    acc1 = throttle_accumulators()
+    throttle = None
+    if acc0 and acc1 and acc1["accumulation_counter"] > acc0["accumulation_counter"]:
+        ticks = acc1["accumulation_counter"] - acc0["accumulation_counter"]
+        throttle = {"ticks": ticks, "source": "amd-smi metric --violation, accumulator deltas over the sampled passes (share = ticks spent limited / ticks)"}
+        for k in ("ppt", "prochot", "socket_thermal", "vr_thermal", "hbm_thermal"):
+            if k + "_accumulated" in acc0 and k + "_accumulated" in acc1:
+                throttle[k + "_share"] = round((acc1[k + "_accumulated"] - acc0[k + "_accumulated"]) / ticks, 4)
     body = out[len(out) // 3:-1] if len(out) > 5 else out          # (the first second still rides the boost after an idle gap: the steady state follows)
     if not body:
         return None
@@ -389,7 +427,16 @@ def power_and_clock(one_pass, passes=16):
     mean_w = sum(pw) / len(pw)
     cap = limits["cap_w"]
     head = None if cap is None else round(cap - mean_w, 1)
-    if head is None:
+    if throttle and throttle.get("ppt_share") is not None and throttle["ppt_share"] >= 0.2:
+        verdict = (f"the firmware's own accounting (amd-smi throttle accumulators): the package-power limiter (PPT) was throttling on {100 * throttle['ppt_share']:.0f} % of "
+                   f"the ticks of the sampled passes, the thermal and PROCHOT limiters on {100 * max(throttle.get(k + '_share') or 0 for k in ('prochot', 'socket_thermal', 'vr_thermal', 'hbm_thermal')):.0f} %, "
+                   f"while rocm-smi's averaged socket power read {mean_w:.0f} W of a {cap if cap is not None else float('nan'):.0f} W cap and the shader clock sat at "
+                   f"{round(sum(ck) / len(ck))} of 2400 MHz: power management is the one active limiter of this path on this box -- it acts on a faster power estimate than "
+                   "the averaged reading, and a controller that holds the part at its limit reports a violation only on the ticks where the estimate exceeds it")
+    elif throttle and throttle.get("ppt_share") is not None:
+        verdict = (f"the firmware's own accounting shows the power limiter active for only {100 * throttle['ppt_share']:.0f} % of the sampled passes: on THIS box power "
+                   "management does not explain the shader clock; see DESIGN.md (power section)")
+    elif head is None:
         verdict = "no power cap reported by rocm-smi on this box: the clock figure stands alone"
     elif head <= 100:
         verdict = (f"average draw within {head:.0f} W of the {cap:.0f} W cap (peaks at or above it) with the shader clock below its top level: "
@@ -401,7 +448,7 @@ def power_and_clock(one_pass, passes=16):
             "shader_clock_mhz": round(sum(ck) / len(ck)), "shader_clock_mhz_min": min(ck), "shader_clock_mhz_max": max(ck),
             "max_shader_clock_mhz": max(limits["sclk_levels_mhz"]) if limits["sclk_levels_mhz"] else 2400, "samples": len(body),
             "cap_w": cap, "headroom_w": head, "perf_level": limits["perf_level"], "sclk_levels_mhz": limits["sclk_levels_mhz"],
-            "reading": verdict,
+            "throttle": throttle, "reading": verdict,
             "note": "rocm-smi sampled every ~0.15 s (a ~1 ms-averaged register, not an energy counter) during extra untimed passes of this mode right "
                     "after its timed region; cap from rocm-smi --showmaxpower"}
 

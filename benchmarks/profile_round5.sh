@@ -21,13 +21,13 @@ for MODE in split3 bf16; do
 done
 python $R/benchmarks/attn_block_bench.py > $OUT/attn_block_bench.log 2>&1
 # power management while the headline pass runs: a background loop of passes, the tools beside it
-( python $R/bench.py --mode split3 --steps 60 --warmup 2 --no-cpu-baseline --no-kernel-events --no-other-configs --no-other-modes --no-power --no-parity --no-small-batch --no-job > /dev/null 2>&1 ) &
+( python $R/bench.py --mode split3 --steps 400 --warmup 2 --no-cpu-baseline --no-kernel-events --no-other-configs --no-other-modes --no-power --no-parity --no-small-batch --no-job > /dev/null 2>&1 ) &
 LOAD=$!
 sleep 25
 { echo "== rocm-smi under load"; rocm-smi --showpower --showclocks --showmaxpower --showperflevel --showtemp 2>&1 | grep -v "^$";
   echo "== amd-smi metric under load"; amd-smi metric --power --clock --temperature 2>&1 | head -80;
   echo "== amd-smi metric --help (which throttle / violation fields exist)"; amd-smi metric --help 2>&1 | head -60;
-  for f in --throttle --violation -v; do echo "== amd-smi metric $f"; amd-smi metric $f 2>&1 | head -40; done; } > $OUT/power_tools.log 2>&1
-wait $LOAD
+  echo "== amd-smi metric --violation (twice, 10 s apart: accumulator deltas under load)"; amd-smi metric --violation 2>&1 | head -8; sleep 10; amd-smi metric --violation 2>&1 | head -8; } > $OUT/power_tools.log 2>&1
+kill $LOAD 2>/dev/null; wait $LOAD
 find $OUT -name "*kernel_trace.csv" -path "*stats_*" -size +20M -delete
 du -sh $OUT; find $OUT -name "*.csv" | xargs ls -la | head -30
