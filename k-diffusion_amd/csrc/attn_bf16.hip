@@ -305,6 +305,78 @@ __device__ __forceinline__ void glds16_sc1(const void* src, void* dst) {       /
 
 // TS: in-kernel time line of workgroup 0 (kd_prof_clock_buffer; a template flag so that the measured kernel's loops stay what they are):
 // [0] entry, [4] rows normalised, [5] / [6] / [8] end of the k / v / q pass, [9] scores + softmax done, [2] exit, [1] / [3] s_memrealtime.
+// The 32 rows of one wave (rows 32 wid .. of sample b) -> normalised, scaled MFMA B fragments `a[NC]` held in registers, and the rows' RMS
+// factor `rs`.  gemm_astat_kernel's arithmetic (same products, same order of the sum of squares), another staging schedule: the rows come in by
+// K-HALVES of 256 elements -- all 32 rows x 512 bytes per round into the wave's 16 KiB slot, every lane reads its own row's 16 chunks (at
+// K = 512 the row-halves schedule of the projection kernel leaves half the lanes idle in each round) -- and the second half is in flight while
+// the first is converted; scales two chunks at a time, one pair ahead (32 registers of scales: the block kernels carry 2 waves per SIMD).
+// A MACRO, not a function: as a forceinline function taking / returning the fragments the same code compiled to 40 more registers and, at
+// K = 512, 600 bytes of scratch per lane.  Uses the enclosing kernel's smem, wid, lane, l31, lh, b and the constants NC, K, T; declares a, rs.
+#define KD_ROWS_TO_FRAGMENTS(XPTR, SVEC, EPS) \
+  bf16x8 a[NC]; \
+  float rs; \
+  { \
+    constexpr int NH = K / 256; \
+    char* stage = smem + wid * WBLK; \
+    char* scl = smem + 8 * WBLK + wid * (K * 4); \
+    const char* ssrc = reinterpret_cast<const char*>((SVEC)) + lane * 16; \
+_Pragma("unroll") \
+    for (int i = 0; i < K * 4 / 1024; ++i) glds16(ssrc + i * 1024, scl + i * 1024); \
+    auto request = [&](int h) { \
+_Pragma("unroll") \
+      for (int i = 0; i < 16; ++i) { \
+        const int rr = (i * 64 + lane) >> 5, qs = (i * 64 + lane) & 31; \
+        const size_t grow = (size_t)b * T + wid * 32 + rr; \
+        glds16(reinterpret_cast<const char*>((XPTR) + grow * K) + h * 512 + ((qs ^ (rr & 15)) << 4), stage + i * 1024); \
+      } \
+    }; \
+    float ssq = 0.f; \
+    const float* spl = reinterpret_cast<const float*>(scl) + 8 * lh; \
+    const char* rowp = stage + l31 * 512; \
+    request(0); \
+_Pragma("unroll") \
+    for (int h = 0; h < NH; ++h) { \
+      u32x4 raw[16]; \
+      KD_WAIT_VM(0); \
+_Pragma("unroll") \
+      for (int c = 0; c < 16; ++c) raw[c] = *reinterpret_cast<const u32x4*>(rowp + (((2 * c + lh) ^ (l31 & 15)) << 4)); \
+      if (h + 1 < NH) { \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        request(h + 1); \
+      } \
+      f32x4 s0[2][2], s1[2][2]; \
+      auto load_scales = [&](int c0, int g) { \
+_Pragma("unroll") \
+        for (int u = 0; u < 2; ++u) { \
+          s0[g][u] = *reinterpret_cast<const f32x4*>(spl + 16 * (16 * h + c0 + u)); \
+          s1[g][u] = *reinterpret_cast<const f32x4*>(spl + 16 * (16 * h + c0 + u) + 4); \
+        } \
+      }; \
+      load_scales(0, 0); \
+      __builtin_amdgcn_sched_barrier(0); \
+_Pragma("unroll") \
+      for (int c0 = 0; c0 < 16; c0 += 2) { \
+        const int g = (c0 >> 1) & 1; \
+        if (c0 + 2 < 16) load_scales(c0 + 2, g ^ 1); \
+_Pragma("unroll") \
+        for (int u = 0; u < 2; ++u) { \
+          float x[8]; \
+_Pragma("unroll") \
+          for (int e = 0; e < 4; ++e) { x[2 * e] = bf_lo(raw[c0 + u][e]); x[2 * e + 1] = bf_hi(raw[c0 + u][e]); } \
+_Pragma("unroll") \
+          for (int e = 0; e < 8; ++e) ssq = fmaf(x[e], x[e], ssq); \
+          u32x4 o = {pack_bf16(x[0] * s0[g][u][0], x[1] * s0[g][u][1]), pack_bf16(x[2] * s0[g][u][2], x[3] * s0[g][u][3]), \
+                     pack_bf16(x[4] * s1[g][u][0], x[5] * s1[g][u][1]), pack_bf16(x[6] * s1[g][u][2], x[7] * s1[g][u][3])}; \
+          asm volatile("" : "+v"(o)); \
+          a[16 * h + c0 + u] = __builtin_bit_cast(bf16x8, o); \
+        } \
+        __builtin_amdgcn_sched_barrier(0); \
+      } \
+    } \
+    ssq += __shfl_xor(ssq, 32, 64); \
+    rs = rsqrtf(ssq / (float)K + (EPS)); \
+  }
+
 // OUTP: the block's out projection + residual in the same launch (image_transformer_v2.py:393-396).  The attention output of a sample is
 // complete when its n_heads workgroups have stored their 64 columns; after a rendezvous of those workgroups (same XCD: the exchange stays in
 // one L2) workgroup (sample, h) takes the sample's 256 attention rows as B fragments (LDS-DMA, no arithmetic) and runs ONE more pass: the 64
@@ -339,73 +411,7 @@ __global__ __launch_bounds__(512, 1) void attn_block_bf16_kernel(const BArgs p) 
   const size_t row = (size_t)b * T + tok;
 
   // ---- the wave's 32 rows -> normalised, scaled B fragments ---------------------------------------------------------------------------
-  // gemm_astat_kernel's arithmetic (same products, same order of the sum of squares), another staging schedule: the rows come in by
-  // K-HALVES of 256 elements -- all 32 rows x 512 bytes per round into the wave's 16 KiB slot, every lane reads its own row's 16 chunks (at
-  // K = 512 the row-halves schedule of the projection kernel leaves half the lanes idle in each round) -- and the second half is in flight
-  // while the first is converted.
-  bf16x8 a[NC];
-  float rs;
-  {
-    constexpr int NH = K / 256;                        // rounds
-    char* stage = smem + wid * WBLK;
-    char* scl = smem + 8 * WBLK + wid * (K * 4);
-    const char* ssrc = reinterpret_cast<const char*>(p.scale + (size_t)b * p.scale_stride) + lane * 16;
-#pragma unroll
-    for (int i = 0; i < K * 4 / 1024; ++i) glds16(ssrc + i * 1024, scl + i * 1024);
-    auto request = [&](int h) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int rr = (i * 64 + lane) >> 5, qs = (i * 64 + lane) & 31;          // LDS row of this lane's piece, its slot in the half row
-        const size_t grow = (size_t)b * T + wid * 32 + rr;
-        glds16(reinterpret_cast<const char*>(p.x + grow * K) + h * 512 + ((qs ^ (rr & 15)) << 4), stage + i * 1024);
-      }
-    };
-    float ssq = 0.f;
-    const float* spl = reinterpret_cast<const float*>(scl) + 8 * lh;
-    const char* rowp = stage + l31 * 512;
-    request(0);
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      u32x4 raw[16];
-      KD_WAIT_VM(0);                                   // wave-private slot: no barrier
-#pragma unroll
-      for (int c = 0; c < 16; ++c) raw[c] = *reinterpret_cast<const u32x4*>(rowp + (((2 * c + lh) ^ (l31 & 15)) << 4));
-      if (h + 1 < NH) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is overwritten by the next round
-        request(h + 1);
-      }
-      f32x4 s0[2][2], s1[2][2];
-      auto load_scales = [&](int c0, int g) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          s0[g][u] = *reinterpret_cast<const f32x4*>(spl + 16 * (16 * h + c0 + u));
-          s1[g][u] = *reinterpret_cast<const f32x4*>(spl + 16 * (16 * h + c0 + u) + 4);
-        }
-      };
-      load_scales(0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int c0 = 0; c0 < 16; c0 += 2) {
-        const int g = (c0 >> 1) & 1;
-        if (c0 + 2 < 16) load_scales(c0 + 2, g ^ 1);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          float x[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { x[2 * e] = bf_lo(raw[c0 + u][e]); x[2 * e + 1] = bf_hi(raw[c0 + u][e]); }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ssq = fmaf(x[e], x[e], ssq);
-          u32x4 o = {pack_bf16(x[0] * s0[g][u][0], x[1] * s0[g][u][1]), pack_bf16(x[2] * s0[g][u][2], x[3] * s0[g][u][3]),
-                     pack_bf16(x[4] * s1[g][u][0], x[5] * s1[g][u][1]), pack_bf16(x[6] * s1[g][u][2], x[7] * s1[g][u][3])};
-          asm volatile("" : "+v"(o));
-          a[16 * h + c0 + u] = __builtin_bit_cast(bf16x8, o);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    ssq += __shfl_xor(ssq, 32, 64);
-    rs = rsqrtf(ssq / (float)K + p.eps);
-  }
+  KD_ROWS_TO_FRAGMENTS(p.x, p.scale + (size_t)b * p.scale_stride, p.eps)
   float py = p.pos[2 * tok], px = p.pos[2 * tok + 1];
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(py), "+v"(px) : : "memory");
   code_warm_end(warm);
@@ -628,6 +634,118 @@ __global__ __launch_bounds__(512, 1) void attn_block_bf16_kernel(const BArgs p) 
   }
   if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
   if (TS && wg_slot) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); wg_slot[1] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+// ---- AdaRMSNorm -> up projection + GEGLU of a 256-token level in the attention block's form --------------------------------------------------
+// (image_transformer_v2.py:487-491: norm, up_proj / linear_geglu.)  The A-stationary projection kernel (gemm_bf16.hip: gemm_astat_kernel) runs
+// this shape -- 8 192 rows, K = 512, 3 072 W rows -- as 128-row panels x 8 n-splits: every split repeats the panel's row prologue, and two
+// workgroups per CU re-stream 1 MiB of rows + weights through a 37 - 50 bytes / clock L2 -> LDS path (38 us per launch for 12 us of matrix work).
+// Here a workgroup owns (sample, slice of 192 outputs): its 8 waves normalise the sample's 256 rows ONCE into register fragments
+// (rows_to_fragments) and then run six passes over K, one per 64-row half block of the packed GEGLU image (32 value rows + their 32 gate
+// rows), through the same 4-slot ring as the attention block; a pass ends with the GEGLU of the lane's own row (in registers) and two 16-byte
+// stores.  Same products in the same order as gemm_astat_kernel<NC, KD_EPI_GEGLU>: bit-identical.
+struct UArgs {
+  const u16* x; const char* Wp; u16* out;
+  const float* scale; int scale_stride; float eps;
+  int batch, slices, d_ff;            // 256 tokens per sample; slices = d_ff / 192
+  int warm;
+};
+
+__device__ __forceinline__ void wait_vm_any(int n) {
+  switch (n) {
+#define KD_C(v) case v: asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); break;
+    KD_C(0) KD_C(1) KD_C(2) KD_C(3) KD_C(4) KD_C(5) KD_C(6) KD_C(7) KD_C(8) KD_C(9) KD_C(10) KD_C(11) KD_C(12)
+#undef KD_C
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+  }
+}
+
+template <int NC /* K / 16 */>
+__global__ __launch_bounds__(512, 1) void geglu_block_bf16_kernel(const UArgs p) {
+  constexpr int K = NC * 16, NK = NC / 4, SPP = NK / 2, NPASS = 6, NSTAGE = NPASS * SPP, NSLOT = 4, PDIST = 3, T = 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
+  const auto warm = code_warm_begin<24 * 1024>((int)blockIdx.x < p.warm && tid < 64);
+  int b, slice;                                          // the slices of one sample on one XCD (ids 8 apart), as the attention block's heads
+  if ((p.batch & 7) == 0) {
+    const int j = blockIdx.x >> 3;
+    b = (j / p.slices) * 8 + (blockIdx.x & 7);
+    slice = j % p.slices;
+  } else {
+    b = blockIdx.x / p.slices;
+    slice = blockIdx.x % p.slices;
+  }
+  const size_t row = (size_t)b * T + wid * 32 + l31;
+  KD_ROWS_TO_FRAGMENTS(p.x, p.scale + (size_t)b * p.scale_stride, p.eps)
+  code_warm_end(warm);
+  KD_BARRIER();                                        // every wave has taken its rows out of the slot it borrowed
+
+  // stage s = pass s / SPP (half block 6 slice + pass: 32 outputs), k-steps 2 kk and 2 kk + 1; wave w brings piece w of each half block
+  const char* wbase = p.Wp + wid * 1024 + lane * 16;
+  auto issue = [&](int s) {
+    const int hb = NPASS * slice + s / SPP, kk = s % SPP;
+    const char* src = wbase + ((size_t)(hb >> 1) * NK + 2 * kk) * WBLK + (hb & 1) * 8192;
+    char* dst = smem + (s % NSLOT) * WBLK + wid * 1024;
+    glds16(src, dst);
+    glds16(src + WBLK, dst + 8192);
+  };
+#pragma unroll
+  for (int s = 0; s < PDIST; ++s) issue(s);
+  int off4[4];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) off4[cc] = swz128(l31, 2 * cc + lh);
+  u16* crow = p.out + row * (size_t)p.d_ff + (size_t)NPASS * slice * 32;
+  f32x16 acc[2];
+#pragma unroll
+  for (int s = 0; s < NSTAGE; ++s) {
+    const int pass = s / SPP, kk = s % SPP;
+    if (kk == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    }
+    {
+      // behind stage s in the queue (loads and stores retire in issue order): the stages requested after it and the two stores of every pass
+      // that ended since its request (iterations s - PDIST .. s - 1)
+      int allow = 2 * min(PDIST - 1, NSTAGE - 1 - s);
+#pragma unroll
+      for (int e = s - PDIST; e <= s - 1; ++e)
+        if (e >= 0 && e % SPP == SPP - 1) allow += 2;
+      wait_vm_any(allow);
+    }
+    KD_BARRIER();
+    if (s + PDIST < NSTAGE) issue(s + PDIST);
+    const char* st = smem + (s % NSLOT) * WBLK;
+    bf16x8 wf[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wf[0][j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 128 + off4[0]);
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+      if (c8 + 1 < 8) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          wf[(c8 + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(st + ((c8 + 1) >> 2) * 8192 + j * 32 * 128 + off4[(c8 + 1) & 3]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c8 & 1][j], a[4 * (2 * kk + (c8 >> 2)) + (c8 & 3)], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kk == SPP - 1) {                                // GEGLU of the lane's row: value block acc[0], gate block acc[1] (gemm_astat_kernel's epilogue)
+      float v[16];
+      const float rsh = 0.5f * rs;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 o = geglu_pair(f32x2{acc[0][r], acc[0][r + 1]} * rsh, f32x2{acc[1][r], acc[1][r + 1]} * rs);
+        v[r] = o.x;
+        v[r + 1] = o.y;
+      }
+      store_block_bf16(crow + 32 * pass, v, lh, true);
+    }
+  }
 }
 
 // ---- global core for T > 256: 128-key blocks double-buffered through LDS, online softmax ---------------------------------------
@@ -1092,6 +1210,42 @@ extern "C" int kd_attn_block_bf16(const KdGemm* dp, const KdGemm* op, int* sync,
 #undef KD_BLK2
 #undef KD_BLK
   return check_launch("kd_attn_block_bf16");
+}
+
+// AdaRMSNorm -> up projection + GEGLU at 256 tokens per sample in the attention block's form (geglu_block_bf16_kernel above).  `d` is the up
+// projection's descriptor exactly as kd_gemm_bf16 takes it (epi = KD_EPI_GEGLU, norm = 1, N = d_ff); results bit-identical to that call.
+extern "C" int kd_geglu_block_bf16_supported(int tokens_per_sample, int width, int d_ff) {
+  return tokens_per_sample == 256 && (width == 256 || width == 512) && d_ff > 0 && d_ff % 192 == 0 && option("geglu_block_bf16", 1) ? 1 : 0;
+}
+
+extern "C" int kd_geglu_block_bf16(const KdGemm* dp, void* stream) {
+  if (!dp) return fail(KD_EINVAL, "kd_geglu_block_bf16: null descriptor");
+  const KdGemm& d = *dp;
+  if (!d.A || !d.Wp || !d.C || !d.scale) return fail(KD_EINVAL, "kd_geglu_block_bf16: null operand");
+  if (d.epi != KD_EPI_GEGLU || !d.norm || d.a_mode != KD_A_PLAIN || d.precision != KD_PREC_BF16)
+    return fail(KD_EINVAL, "kd_geglu_block_bf16: the descriptor must be a bf16 norm -> GEGLU projection");
+  if (!kd_geglu_block_bf16_supported(d.rows_per_sample, d.K, d.N) || d.M <= 0 || d.M % 256)
+    return fail(KD_EINVAL, "kd_geglu_block_bf16: shape M=%d d_ff=%d K=%d, %d tokens per sample is not taken (256 tokens per sample, K in {256, 512}, "
+                "d_ff a multiple of 192)", d.M, d.N, d.K, d.rows_per_sample);
+  UArgs a{reinterpret_cast<const u16*>(d.A), reinterpret_cast<const char*>(d.Wp), reinterpret_cast<u16*>(d.C), d.scale, d.scale_stride, d.eps,
+          d.M / 256, d.N / 192, d.N, option("code_warm", KD_CODE_WARM_DEFAULT)};
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int LDS = 8 * WBLK + 8 * 512 * 4;
+  const double flops = 2.0 * d.M * 2.0 * d.N * d.K;
+  const double bytes = 2.0 * ((double)d.M * d.K + 2.0 * d.N * d.K + (double)d.M * d.N);
+  char nm[96] = "geglu_block_bf16";
+  if (prof_on()) snprintf(nm, sizeof(nm), "geglu_block_bf16 M=%d N=%d K=%d", d.M, d.N, d.K);
+  LaunchScope prof(nm, flops, bytes, s);
+  if (d.K == 512) {
+    static LdsAttr set;
+    set.ensure(reinterpret_cast<const void*>(geglu_block_bf16_kernel<32>), LDS);
+    hipLaunchKernelGGL(geglu_block_bf16_kernel<32>, dim3((unsigned)(a.batch * a.slices)), dim3(512), LDS, s, a);
+  } else {
+    static LdsAttr set;
+    set.ensure(reinterpret_cast<const void*>(geglu_block_bf16_kernel<16>), LDS);
+    hipLaunchKernelGGL(geglu_block_bf16_kernel<16>, dim3((unsigned)(a.batch * a.slices)), dim3(512), LDS, s, a);
+  }
+  return check_launch("kd_geglu_block_bf16");
 }
 
 extern "C" int kd_attn_window_bf16(const void* qkv, void* out, int batch, int H, int W, int nh, int ws, int shift, void* stream) {

@@ -831,6 +831,28 @@ def test_bf16_qkv_epilogue(ops, H, W, nh, B, K):
     assert relerr(qkv[..., 2, :, :], ref[..., 2, :, :]) < 1.2e-2
 
 
+@pytest.mark.parametrize("B,K,d_ff", [(32, 512, 1536), (3, 512, 1536), (16, 256, 768), (5, 256, 384), (2, 512, 192)])
+def test_geglu_block_bf16_matches_the_projection_kernel(KD, ops, B, K, d_ff):
+    """kd_geglu_block_bf16 (round 5: the FF block's norm -> up projection + GEGLU at 256 tokens per sample, a workgroup per (sample, 192-output
+    slice) with the rows normalised once) against kd_gemm_bf16 on the same descriptor: same products in the same order, BIT-IDENTICAL; and
+    against the oracle at the bf16 mode's tolerance."""
+    from k_diffusion_amd import _native as nat
+    T = 256
+    assert nat.lib().kd_geglu_block_bf16_supported(T, K, d_ff) == 1
+    x, scale = rn(B, T, K, seed=8) * (1 + rn(B, T, 1, seed=3).abs()), 1 + 0.2 * rn(B, K, seed=9)
+    wg = rn(2 * d_ff, K, seed=7, scale=K ** -0.5)
+    xb, sc, wd = _bf(x), g(scale), g(wg)
+    two = ops.norm_linear(xb, sc, wd, rows_per_sample=T, epi=nat.EPI_GEGLU)
+    one = ops.geglu_block(xb, sc, wd, rows_per_sample=T)
+    assert one.dtype == BF and one.shape == (B, T, d_ff)
+    ndiff = int((one != two).sum())
+    print(f"geglu_block B={B} K={K} d_ff={d_ff}: {ndiff} of {one.numel()} outputs differ")
+    assert torch.equal(one, two)
+    assert relerr(one.float().cpu(), hdit.linear_geglu(hdit.rms_norm(_rt(x), scale[:, None, :]), _rt(wg))) < 1.5e-2
+    with pytest.raises(RuntimeError):
+        ops.geglu_block(_bf(rn(2, 64, K, seed=1)), g(scale[:2]), wd, rows_per_sample=64)
+
+
 @pytest.mark.parametrize("nh,B,K", [(8, 32, 512), (8, 3, 512), (4, 16, 256), (4, 5, 256)])
 def test_attn_block_bf16_matches_two_launches(KD, ops, nh, B, K):
     """kd_attn_block_bf16 (round 5: AdaRMSNorm -> qkv projection of a head -> cosine-sim + RoPE -> dense attention in one launch per
