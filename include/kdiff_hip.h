@@ -270,12 +270,14 @@ int kd_attn_na2d_bf16(const void* qkv, void* out, int batch, int H, int W, int n
 int kd_attn_block_bf16_supported(int tokens_per_sample, int width, int n_heads);
 int kd_attn_block_bf16(const KdGemm* d, const KdGemm* out_proj, int* sync, void* stream);
 
-/* The FF block's norm -> up projection + GEGLU (image_transformer_v2.py:487-491) at 256 tokens per sample in the same form (round 5): a
- * workgroup per (sample, 192-output slice), the sample's rows normalised once into register fragments, six passes over K.  `d` is the up
- * projection's descriptor as kd_gemm_bf16 takes it (epi = KD_EPI_GEGLU, norm = 1, N = d_ff, precision = KD_PREC_BF16); the result is
- * bit-identical to kd_gemm_bf16(d).  Shapes: 256 tokens per sample, K in {256, 512}, d_ff % 192 == 0, M % 256 == 0; else KD_EINVAL. */
-int kd_geglu_block_bf16_supported(int tokens_per_sample, int width, int d_ff);
-int kd_geglu_block_bf16(const KdGemm* d, void* stream);
+/* AdaRMSNorm -> wide projection in the same form (round 5): the FF block's norm -> up projection + GEGLU (image_transformer_v2.py:487-491) and,
+ * for the levels whose attention core is a launch of its own, norm -> qkv projection + cosine-sim scale + RoPE (:370-380, :415-425).  A workgroup
+ * per (256-row group, slice of six 64-row half blocks of the packed weight), the group's rows normalised once into register fragments, six passes
+ * over K.  `d` is the projection's descriptor as kd_gemm_bf16 takes it (epi = KD_EPI_GEGLU with N = d_ff, or KD_EPI_QKV with N = 3 K; norm = 1,
+ * precision = KD_PREC_BF16); the result is bit-identical to kd_gemm_bf16(d).  Shapes: rows per sample a multiple of 256, K in {256, 512},
+ * d_ff % 192 == 0 (kd_proj_block_bf16_supported tells); else KD_EINVAL. */
+int kd_proj_block_bf16_supported(int tokens_per_sample, int width, int n, int epi);
+int kd_proj_block_bf16(const KdGemm* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Solver step arithmetic (k_diffusion/sampling.py), one fused elementwise launch per step with
@@ -377,11 +379,11 @@ int kd_prof_clock_buffer(void* dev_ptr);
  *   KD_OP_ATTN_WINDOW_F32 : p as above; i = batch, H, W, nh, ws, shift, prep, precision        KD_OP_ATTN_NA2D_F32 : i = batch, H, W, nh, ks, prep, precision
  *   KD_OP_ATTN_GLOBAL_BF16 : p = qkv, out; i = batch, T, nh      KD_OP_ATTN_WINDOW_BF16 : i = batch, H, W, nh, ws, shift      KD_OP_ATTN_NA2D_BF16 : i = batch, H, W, nh, ks
  *   KD_OP_NORM_SPLIT_F32 : p = x, scale, hi, lo; i = scale_stride, rows_per_sample, M, K; f = eps
- *   KD_OP_ATTN_BLOCK_BF16 : p = const KdGemm* (qkv), const KdGemm* (out projection or NULL), sync      KD_OP_GEGLU_BLOCK_BF16 : p[0] = const KdGemm* */
+ *   KD_OP_ATTN_BLOCK_BF16 : p = const KdGemm* (qkv), const KdGemm* (out projection or NULL), sync      KD_OP_PROJ_BLOCK_BF16 : p[0] = const KdGemm* */
 enum { KD_OP_GEMM_F32 = 0, KD_OP_GEMM_BF16 = 1, KD_OP_FFN_F32 = 2, KD_OP_FFN_BF16 = 3,
        KD_OP_ATTN_GLOBAL_F32 = 4, KD_OP_ATTN_WINDOW_F32 = 5, KD_OP_ATTN_NA2D_F32 = 6,
        KD_OP_ATTN_GLOBAL_BF16 = 7, KD_OP_ATTN_WINDOW_BF16 = 8, KD_OP_ATTN_NA2D_BF16 = 9, KD_OP_NORM_SPLIT_F32 = 10,
-       KD_OP_ATTN_BLOCK_BF16 = 11, KD_OP_GEGLU_BLOCK_BF16 = 12 };
+       KD_OP_ATTN_BLOCK_BF16 = 11, KD_OP_PROJ_BLOCK_BF16 = 12 };
 typedef struct {
   int op;             /* KD_OP_* */
   float f;

@@ -89,8 +89,8 @@ SIGNATURES = {
     "kd_attn_na2d_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "kd_attn_block_bf16_supported": [_i, _i, _i],
     "kd_attn_block_bf16": [C.POINTER(KdGemm), C.POINTER(KdGemm), _vp, _vp],
-    "kd_geglu_block_bf16_supported": [_i, _i, _i],
-    "kd_geglu_block_bf16": [C.POINTER(KdGemm), _vp],
+    "kd_proj_block_bf16_supported": [_i, _i, _i, _i],
+    "kd_proj_block_bf16": [C.POINTER(KdGemm), _vp],
     "kd_packed_weight_bytes": [_i, _i, _i],
     "kd_pack_weight_bf16x3": [_vp, _vp, _i, _i, _i, _vp],
     "kd_rmsnorm_f32": [_vp, _vp, _vp, _i, _i, _f, _vp],
@@ -127,7 +127,7 @@ SIGNATURES = {
 # entry points a kd_run_list entry can name (include/kdiff_hip.h: KD_OP_*)
 RUN_LIST_OPS = {"kd_gemm_f32": 0, "kd_gemm_bf16": 1, "kd_ffn_f32": 2, "kd_ffn_bf16": 3, "kd_attn_global_f32": 4, "kd_attn_window_f32": 5,
                 "kd_attn_na2d_f32": 6, "kd_attn_global_bf16": 7, "kd_attn_window_bf16": 8, "kd_attn_na2d_bf16": 9, "kd_norm_split_f32": 10,
-                "kd_attn_block_bf16": 11, "kd_geglu_block_bf16": 12}
+                "kd_attn_block_bf16": 11, "kd_proj_block_bf16": 12}
 
 
 def encode_call(call, name, args):

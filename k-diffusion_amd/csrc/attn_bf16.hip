@@ -311,8 +311,9 @@ __device__ __forceinline__ void glds16_sc1(const void* src, void* dst) {       /
 // K = 512 the row-halves schedule of the projection kernel leaves half the lanes idle in each round) -- and the second half is in flight while
 // the first is converted; scales two chunks at a time, one pair ahead (32 registers of scales: the block kernels carry 2 waves per SIMD).
 // A MACRO, not a function: as a forceinline function taking / returning the fragments the same code compiled to 40 more registers and, at
-// K = 512, 600 bytes of scratch per lane.  Uses the enclosing kernel's smem, wid, lane, l31, lh, b and the constants NC, K, T; declares a, rs.
-#define KD_ROWS_TO_FRAGMENTS(XPTR, SVEC, EPS) \
+// K = 512, 600 bytes of scratch per lane.  Uses the enclosing kernel's smem, wid, lane, l31, lh and the constants NC, K; declares a, rs.
+// ROW0: first of the workgroup's 256 rows.
+#define KD_ROWS_TO_FRAGMENTS(XPTR, ROW0, SVEC, EPS) \
   bf16x8 a[NC]; \
   float rs; \
   { \
@@ -326,7 +327,7 @@ _Pragma("unroll") \
 _Pragma("unroll") \
       for (int i = 0; i < 16; ++i) { \
         const int rr = (i * 64 + lane) >> 5, qs = (i * 64 + lane) & 31; \
-        const size_t grow = (size_t)b * T + wid * 32 + rr; \
+        const size_t grow = (size_t)(ROW0) + wid * 32 + rr; \
         glds16(reinterpret_cast<const char*>((XPTR) + grow * K) + h * 512 + ((qs ^ (rr & 15)) << 4), stage + i * 1024); \
       } \
     }; \
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(512, 1) void attn_block_bf16_kernel(const BArgs p) 
   const size_t row = (size_t)b * T + tok;
 
   // ---- the wave's 32 rows -> normalised, scaled B fragments ---------------------------------------------------------------------------
-  KD_ROWS_TO_FRAGMENTS(p.x, p.scale + (size_t)b * p.scale_stride, p.eps)
+  KD_ROWS_TO_FRAGMENTS(p.x, (size_t)b * T, p.scale + (size_t)b * p.scale_stride, p.eps)
   float py = p.pos[2 * tok], px = p.pos[2 * tok + 1];
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(py), "+v"(px) : : "memory");
   code_warm_end(warm);
@@ -636,51 +637,64 @@ __global__ __launch_bounds__(512, 1) void attn_block_bf16_kernel(const BArgs p) 
   if (TS && wg_slot) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); wg_slot[1] = __builtin_amdgcn_s_memrealtime(); }
 }
 
-// ---- AdaRMSNorm -> up projection + GEGLU of a 256-token level in the attention block's form --------------------------------------------------
-// (image_transformer_v2.py:487-491: norm, up_proj / linear_geglu.)  The A-stationary projection kernel (gemm_bf16.hip: gemm_astat_kernel) runs
-// this shape -- 8 192 rows, K = 512, 3 072 W rows -- as 128-row panels x 8 n-splits: every split repeats the panel's row prologue, and two
-// workgroups per CU re-stream 1 MiB of rows + weights through a 37 - 50 bytes / clock L2 -> LDS path (38 us per launch for 12 us of matrix work).
-// Here a workgroup owns (sample, slice of 192 outputs): its 8 waves normalise the sample's 256 rows ONCE into register fragments
-// (rows_to_fragments) and then run six passes over K, one per 64-row half block of the packed GEGLU image (32 value rows + their 32 gate
-// rows), through the same 4-slot ring as the attention block; a pass ends with the GEGLU of the lane's own row (in registers) and two 16-byte
-// stores.  Same products in the same order as gemm_astat_kernel<NC, KD_EPI_GEGLU>: bit-identical.
+// ---- AdaRMSNorm -> wide projection (GEGLU up projection, qkv) in the attention block's form ------------------------------------------------
+// (image_transformer_v2.py:487-491: norm, up_proj / linear_geglu; :370-380 / :415-425: norm, qkv_proj, cosine-sim scale, RoPE -- for the levels
+// whose attention core is a separate launch.)  The A-stationary projection kernel (gemm_bf16.hip: gemm_astat_kernel) runs these shapes --
+// 8 192 rows x K = 512 x 3 072 W rows, 32 768 rows x K = 256 x 1 536 / 768 W rows -- as 128-row panels x n-splits: every split repeats the
+// panel's row prologue, and two workgroups per CU re-stream up to 1 MiB of rows + weights through a 37 - 50 bytes / clock L2 -> LDS path.
+// Here a workgroup owns (256-row group, slice of six 64-row half blocks of the packed image): its 8 waves normalise the group's rows ONCE into
+// register fragments (KD_ROWS_TO_FRAGMENTS) and then run six passes over K through the attention block's 4-slot ring; a pass ends with the
+// epilogue of the lane's own row (GEGLU of 32 value / 32 gate columns; cosine-sim scale + RoPE of a q / k head vector; the row factor for v) and
+// its 16-byte stores.  Same products in the same order as gemm_astat_kernel<NC, EPI>: bit-identical.
 struct UArgs {
   const u16* x; const char* Wp; u16* out;
   const float* scale; int scale_stride; float eps;
-  int batch, slices, d_ff;            // 256 tokens per sample; slices = d_ff / 192
+  int groups, groups_per_sample, slices, n_out;      // 256-row groups; groups of one sample; slices of 6 half blocks; output row width
+  int n_heads; const float* qk_scale; const float* pos; const float* freq;      // EPI_QKV
   int warm;
 };
 
 __device__ __forceinline__ void wait_vm_any(int n) {
   switch (n) {
 #define KD_C(v) case v: asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); break;
-    KD_C(0) KD_C(1) KD_C(2) KD_C(3) KD_C(4) KD_C(5) KD_C(6) KD_C(7) KD_C(8) KD_C(9) KD_C(10) KD_C(11) KD_C(12)
+    KD_C(0) KD_C(1) KD_C(2) KD_C(3) KD_C(4) KD_C(5) KD_C(6) KD_C(7) KD_C(8) KD_C(9) KD_C(10) KD_C(11) KD_C(12) KD_C(13) KD_C(14) KD_C(15) KD_C(16)
 #undef KD_C
-    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
   }
 }
 
-template <int NC /* K / 16 */>
-__global__ __launch_bounds__(512, 1) void geglu_block_bf16_kernel(const UArgs p) {
-  constexpr int K = NC * 16, NK = NC / 4, SPP = NK / 2, NPASS = 6, NSTAGE = NPASS * SPP, NSLOT = 4, PDIST = 3, T = 256;
+template <int NC /* K / 16 */, int EPI>
+__global__ __launch_bounds__(512, 1) void proj_block_bf16_kernel(const UArgs p) {
+  constexpr int K = NC * 16, NK = NC / 4, SPP = NK / 2, NPASS = 6, NSTAGE = NPASS * SPP, NSLOT = 4, PDIST = 3;
+  constexpr int NST = EPI == KD_EPI_GEGLU ? 2 : 4;      // 16-byte stores per lane at the end of a pass
+  constexpr int COLS = EPI == KD_EPI_GEGLU ? 32 : 64;   // output columns of a half block
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
   const auto warm = code_warm_begin<24 * 1024>((int)blockIdx.x < p.warm && tid < 64);
-  int b, slice;                                          // the slices of one sample on one XCD (ids 8 apart), as the attention block's heads
-  if ((p.batch & 7) == 0) {
+  int grp, slice;                                        // the slices of one row group on one XCD (ids 8 apart), as the attention block's heads
+  if ((p.groups & 7) == 0) {
     const int j = blockIdx.x >> 3;
-    b = (j / p.slices) * 8 + (blockIdx.x & 7);
+    grp = (j / p.slices) * 8 + (blockIdx.x & 7);
     slice = j % p.slices;
   } else {
-    b = blockIdx.x / p.slices;
+    grp = blockIdx.x / p.slices;
     slice = blockIdx.x % p.slices;
   }
-  const size_t row = (size_t)b * T + wid * 32 + l31;
-  KD_ROWS_TO_FRAGMENTS(p.x, p.scale + (size_t)b * p.scale_stride, p.eps)
+  const int b = grp / p.groups_per_sample;
+  const size_t row0 = (size_t)grp * 256;
+  const size_t row = row0 + wid * 32 + l31;
+  KD_ROWS_TO_FRAGMENTS(p.x, row0, p.scale + (size_t)b * p.scale_stride, p.eps)
+  float py = 0.f, px = 0.f;
+  if (EPI == KD_EPI_QKV) {
+    const int tok = (int)(row - (size_t)b * p.groups_per_sample * 256);
+    py = p.pos[2 * tok];
+    px = p.pos[2 * tok + 1];
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(py), "+v"(px) : : "memory");
+  }
   code_warm_end(warm);
   KD_BARRIER();                                        // every wave has taken its rows out of the slot it borrowed
 
-  // stage s = pass s / SPP (half block 6 slice + pass: 32 outputs), k-steps 2 kk and 2 kk + 1; wave w brings piece w of each half block
+  // stage s = pass s / SPP (half block 6 slice + pass), k-steps 2 kk and 2 kk + 1; wave w brings piece w of each half block
   const char* wbase = p.Wp + wid * 1024 + lane * 16;
   auto issue = [&](int s) {
     const int hb = NPASS * slice + s / SPP, kk = s % SPP;
@@ -694,7 +708,7 @@ __global__ __launch_bounds__(512, 1) void geglu_block_bf16_kernel(const UArgs p)
   int off4[4];
 #pragma unroll
   for (int cc = 0; cc < 4; ++cc) off4[cc] = swz128(l31, 2 * cc + lh);
-  u16* crow = p.out + row * (size_t)p.d_ff + (size_t)NPASS * slice * 32;
+  u16* crow = p.out + row * (size_t)p.n_out + (size_t)NPASS * slice * COLS;
   f32x16 acc[2];
 #pragma unroll
   for (int s = 0; s < NSTAGE; ++s) {
@@ -706,12 +720,12 @@ __global__ __launch_bounds__(512, 1) void geglu_block_bf16_kernel(const UArgs p)
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     }
     {
-      // behind stage s in the queue (loads and stores retire in issue order): the stages requested after it and the two stores of every pass
+      // behind stage s in the queue (loads and stores retire in issue order): the stages requested after it and the stores of every pass
       // that ended since its request (iterations s - PDIST .. s - 1)
       int allow = 2 * min(PDIST - 1, NSTAGE - 1 - s);
 #pragma unroll
       for (int e = s - PDIST; e <= s - 1; ++e)
-        if (e >= 0 && e % SPP == SPP - 1) allow += 2;
+        if (e >= 0 && e % SPP == SPP - 1) allow += NST;
       wait_vm_any(allow);
     }
     KD_BARRIER();
@@ -734,16 +748,42 @@ __global__ __launch_bounds__(512, 1) void geglu_block_bf16_kernel(const UArgs p)
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (kk == SPP - 1) {                                // GEGLU of the lane's row: value block acc[0], gate block acc[1] (gemm_astat_kernel's epilogue)
-      float v[16];
-      const float rsh = 0.5f * rs;
+    if (kk == SPP - 1) {
+      if (EPI == KD_EPI_GEGLU) {                        // value block acc[0], gate block acc[1] (gemm_astat_kernel's epilogue)
+        float v[16];
+        const float rsh = 0.5f * rs;
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const f32x2 o = geglu_pair(f32x2{acc[0][r], acc[0][r + 1]} * rsh, f32x2{acc[1][r], acc[1][r + 1]} * rs);
-        v[r] = o.x;
-        v[r + 1] = o.y;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 o = geglu_pair(f32x2{acc[0][r], acc[0][r + 1]} * rsh, f32x2{acc[1][r], acc[1][r + 1]} * rs);
+          v[r] = o.x;
+          v[r + 1] = o.y;
+        }
+        store_block_bf16(crow + 32 * pass, v, lh, true);
+      } else {                                          // one 64-column vector of q, k or v: dims 0..31 in acc[0], 32..63 in acc[1]
+        const int vec = NPASS * slice + pass;
+        const int which = vec / p.n_heads, head = vec - which * p.n_heads;
+        if (which < 2) {
+          typedef float f32x8s __attribute__((ext_vector_type(8)));
+          f32x8s fq;
+          float qsc;
+          asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                       : "=s"(fq), "=s"(qsc) : "s"(p.freq + head * 8), "s"(p.qk_scale + head) : "memory");
+          float fr[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) fr[u] = pick_half(fq[u], fq[4 + u], 0u - (unsigned)lh);
+          qk_prep_blocks(acc[0], acc[1], rs, sqrtf(qsc), p.eps, py, px, fr);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc[0][r] *= rs; acc[1][r] *= rs; }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = acc[jj][r];
+          store_block_bf16(crow + 64 * pass + 32 * jj, v, lh, true);
+        }
       }
-      store_block_bf16(crow + 32 * pass, v, lh, true);
     }
   }
 }
@@ -1212,40 +1252,44 @@ extern "C" int kd_attn_block_bf16(const KdGemm* dp, const KdGemm* op, int* sync,
   return check_launch("kd_attn_block_bf16");
 }
 
-// AdaRMSNorm -> up projection + GEGLU at 256 tokens per sample in the attention block's form (geglu_block_bf16_kernel above).  `d` is the up
-// projection's descriptor exactly as kd_gemm_bf16 takes it (epi = KD_EPI_GEGLU, norm = 1, N = d_ff); results bit-identical to that call.
-extern "C" int kd_geglu_block_bf16_supported(int tokens_per_sample, int width, int d_ff) {
-  return tokens_per_sample == 256 && (width == 256 || width == 512) && d_ff > 0 && d_ff % 192 == 0 && option("geglu_block_bf16", 1) ? 1 : 0;
+// AdaRMSNorm -> wide projection in the attention block's form (proj_block_bf16_kernel above).  `d` is the projection's descriptor exactly as
+// kd_gemm_bf16 takes it -- epi = KD_EPI_GEGLU (N = d_ff) or KD_EPI_QKV (N = 3 K; the qkv tensor is written, for the levels whose attention core
+// is its own launch), norm = 1 -- and the results are bit-identical to that call.  Rows per sample a multiple of 256, K in {256, 512}, the W rows
+// a multiple of 6 half blocks (d_ff % 192 == 0; 3 K % 384 == 0 holds for both widths).
+extern "C" int kd_proj_block_bf16_supported(int tokens_per_sample, int width, int n, int epi) {
+  if (tokens_per_sample <= 0 || tokens_per_sample % 256 || (width != 256 && width != 512) || !option("proj_block_bf16", 1)) return 0;
+  if (epi == KD_EPI_GEGLU) return n > 0 && n % 192 == 0;
+  if (epi == KD_EPI_QKV) return n == 3 * width;
+  return 0;
 }
 
-extern "C" int kd_geglu_block_bf16(const KdGemm* dp, void* stream) {
-  if (!dp) return fail(KD_EINVAL, "kd_geglu_block_bf16: null descriptor");
+extern "C" int kd_proj_block_bf16(const KdGemm* dp, void* stream) {
+  if (!dp) return fail(KD_EINVAL, "kd_proj_block_bf16: null descriptor");
   const KdGemm& d = *dp;
-  if (!d.A || !d.Wp || !d.C || !d.scale) return fail(KD_EINVAL, "kd_geglu_block_bf16: null operand");
-  if (d.epi != KD_EPI_GEGLU || !d.norm || d.a_mode != KD_A_PLAIN || d.precision != KD_PREC_BF16)
-    return fail(KD_EINVAL, "kd_geglu_block_bf16: the descriptor must be a bf16 norm -> GEGLU projection");
-  if (!kd_geglu_block_bf16_supported(d.rows_per_sample, d.K, d.N) || d.M <= 0 || d.M % 256)
-    return fail(KD_EINVAL, "kd_geglu_block_bf16: shape M=%d d_ff=%d K=%d, %d tokens per sample is not taken (256 tokens per sample, K in {256, 512}, "
-                "d_ff a multiple of 192)", d.M, d.N, d.K, d.rows_per_sample);
+  if (!d.A || !d.Wp || !d.C || !d.scale) return fail(KD_EINVAL, "kd_proj_block_bf16: null operand");
+  if ((d.epi != KD_EPI_GEGLU && d.epi != KD_EPI_QKV) || !d.norm || d.a_mode != KD_A_PLAIN || d.precision != KD_PREC_BF16)
+    return fail(KD_EINVAL, "kd_proj_block_bf16: the descriptor must be a bf16 norm -> GEGLU or norm -> qkv projection");
+  if (d.epi == KD_EPI_QKV && (!d.qk_scale || !d.rope_pos || !d.rope_freq || d.n_heads * 64 != d.K))
+    return fail(KD_EINVAL, "kd_proj_block_bf16: the qkv projection needs qk_scale, rope_pos, rope_freq and n_heads * 64 == K");
+  if (!kd_proj_block_bf16_supported(d.rows_per_sample, d.K, d.N, d.epi) || d.M <= 0 || d.M % d.rows_per_sample)
+    return fail(KD_EINVAL, "kd_proj_block_bf16: shape M=%d N=%d K=%d, %d tokens per sample is not taken (tokens per sample a multiple of 256, K in "
+                "{256, 512}, d_ff a multiple of 192)", d.M, d.N, d.K, d.rows_per_sample);
+  const int w_rows = d.epi == KD_EPI_GEGLU ? 2 * d.N : d.N;
   UArgs a{reinterpret_cast<const u16*>(d.A), reinterpret_cast<const char*>(d.Wp), reinterpret_cast<u16*>(d.C), d.scale, d.scale_stride, d.eps,
-          d.M / 256, d.N / 192, d.N, option("code_warm", KD_CODE_WARM_DEFAULT)};
+          d.M / 256, d.rows_per_sample / 256, w_rows / 384, d.N, d.n_heads, d.qk_scale, d.rope_pos, d.rope_freq, option("code_warm", KD_CODE_WARM_DEFAULT)};
   hipStream_t s = (hipStream_t)stream;
   constexpr int LDS = 8 * WBLK + 8 * 512 * 4;
-  const double flops = 2.0 * d.M * 2.0 * d.N * d.K;
-  const double bytes = 2.0 * ((double)d.M * d.K + 2.0 * d.N * d.K + (double)d.M * d.N);
-  char nm[96] = "geglu_block_bf16";
-  if (prof_on()) snprintf(nm, sizeof(nm), "geglu_block_bf16 M=%d N=%d K=%d", d.M, d.N, d.K);
+  const double flops = 2.0 * d.M * (double)w_rows * d.K;
+  const double bytes = 2.0 * ((double)d.M * d.K + (double)w_rows * d.K + (double)d.M * d.N);
+  char nm[96] = "proj_block_bf16";
+  if (prof_on()) snprintf(nm, sizeof(nm), "proj_block_bf16<e%d> M=%d N=%d K=%d", d.epi, d.M, d.N, d.K);
   LaunchScope prof(nm, flops, bytes, s);
-  if (d.K == 512) {
-    static LdsAttr set;
-    set.ensure(reinterpret_cast<const void*>(geglu_block_bf16_kernel<32>), LDS);
-    hipLaunchKernelGGL(geglu_block_bf16_kernel<32>, dim3((unsigned)(a.batch * a.slices)), dim3(512), LDS, s, a);
-  } else {
-    static LdsAttr set;
-    set.ensure(reinterpret_cast<const void*>(geglu_block_bf16_kernel<16>), LDS);
-    hipLaunchKernelGGL(geglu_block_bf16_kernel<16>, dim3((unsigned)(a.batch * a.slices)), dim3(512), LDS, s, a);
-  }
-  return check_launch("kd_geglu_block_bf16");
+#define KD_PB(NCV, EP) { static LdsAttr set; set.ensure(reinterpret_cast<const void*>(proj_block_bf16_kernel<NCV, EP>), LDS); \
+    hipLaunchKernelGGL((proj_block_bf16_kernel<NCV, EP>), dim3((unsigned)(a.groups * a.slices)), dim3(512), LDS, s, a); }
+  if (d.K == 512) { if (d.epi == KD_EPI_GEGLU) KD_PB(32, KD_EPI_GEGLU) else KD_PB(32, KD_EPI_QKV) }
+  else { if (d.epi == KD_EPI_GEGLU) KD_PB(16, KD_EPI_GEGLU) else KD_PB(16, KD_EPI_QKV) }
+#undef KD_PB
+  return check_launch("kd_proj_block_bf16");
 }
 
 extern "C" int kd_attn_window_bf16(const void* qkv, void* out, int batch, int H, int W, int nh, int ws, int shift, void* stream) {

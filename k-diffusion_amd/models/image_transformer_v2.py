@@ -46,7 +46,7 @@ SCHEDULE_TABLE_MAX_BYTES = 1 << 30
 SCHEDULES_KEPT = 4            # a run of a two-stage solver hints two tables; older records (and their tensors) are dropped
 SCHEDULE_CHAINS_KEPT = 2      # conditioning workspaces kept per plan, by schedule length (least recently used dropped)
 # environment switches read while a plan is built (name, default): part of the plan key
-PLAN_SWITCHES = (("KDIFF_ATTN_BLOCK", "1"), ("KDIFF_GEGLU_BLOCK", "1"), ("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "0"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "1"), ("KDIFF_X3_PLANES", "1"),
+PLAN_SWITCHES = (("KDIFF_ATTN_BLOCK", "1"), ("KDIFF_PROJ_BLOCK", "1"), ("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "0"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "1"), ("KDIFF_X3_PLANES", "1"),
                  ("KDIFF_X3_DOWN", "0"), ("KDIFF_RUN_LIST", "1"))
 CLASS_IDS_KEPT = 4            # range-checked class_cond tensors remembered per plan (cond / uncond pairs of a guidance wrapper)
 
@@ -496,6 +496,11 @@ class _Plan:
                 else:
                     dq = gemm(prefix + "qkv_proj", x, sa.qkv_proj.weight, qkv, T, 3 * d, d, epi=nat.EPI_QKV,
                               scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps, qk=qk)
+                    # bf16 mode, K = 256 / 512 with an attention core of its own (neighbourhood / window levels): the projection in the block
+                    # form (kd_proj_block_bf16: a workgroup per (256-row group, 6 head vectors), rows normalised once) from 32 workgroups on
+                    if bf and target is self.launches and os.environ.get("KDIFF_PROJ_BLOCK", "1") != "0" \
+                            and bool(lib.kd_proj_block_bf16_supported(rps, d, 3 * d, nat.EPI_QKV)) and 32 <= (T // 256) * (3 * d // 384) <= 256:
+                        target[-1] = _Launch(lib.kd_proj_block_bf16, (C.byref(dq),), prefix + "qkv_proj(block)", enc=("kd_proj_block_bf16", (dq,)))
                 dq.qkv_packed = 1 if packed_qkv else 0
                 prep = (2 if packed_qkv else 0, None, None, None, C.c_float(1e-6), precision)
                 shift = 0
@@ -561,11 +566,12 @@ class _Plan:
                     du = gemm(prefix + "up_proj", x, mod.ff.up_proj.weight, hid, T, lv.d_ff, d, epi=nat.EPI_GEGLU,
                               scale_ptr=scale_ptr(prefix + "ff.norm"), scale_stride=total, rows_per_sample=rps,
                               c_planes=hid_planes if (d in (128, 256) and T >= 512) else None)
-                    # bf16 mode at 256 tokens per sample: the projection in the attention block's form (a workgroup per (sample, 192-output
-                    # slice), rows normalised once; csrc/attn_bf16.hip: geglu_block_bf16_kernel) from 32 workgroups on; same bits
-                    if bf and target is self.launches and T % 256 == 0 and os.environ.get("KDIFF_GEGLU_BLOCK", "1") != "0" \
-                            and bool(lib.kd_geglu_block_bf16_supported(rps, d, lv.d_ff)) and B * (lv.d_ff // 192) >= 32:
-                        target[-1] = _Launch(lib.kd_geglu_block_bf16, (C.byref(du),), prefix + "up_proj(block)", enc=("kd_geglu_block_bf16", (du,)))
+                    # bf16 mode, rows per sample a multiple of 256: the projection in the attention block's form (a workgroup per (256-row group,
+                    # 192-output slice), rows normalised once; csrc/attn_bf16.hip: proj_block_bf16_kernel) for grids of 32 workgroups up to ONE round
+                    # of the chip's 256 CUs (two rounds measured level with the A-stationary kernel: 42.3 against 41.5 us at level 1); same bits
+                    if bf and target is self.launches and os.environ.get("KDIFF_PROJ_BLOCK", "1") != "0" \
+                            and bool(lib.kd_proj_block_bf16_supported(rps, d, lv.d_ff, nat.EPI_GEGLU)) and 32 <= (T // 256) * (lv.d_ff // 192) <= 256:
+                        target[-1] = _Launch(lib.kd_proj_block_bf16, (C.byref(du),), prefix + "up_proj(block)", enc=("kd_proj_block_bf16", (du,)))
                     if not (d in (128, 256) and T >= 512):
                         hid_planes = None
                 gemm(prefix + "down_proj", None if hid_planes else hid, mod.ff.down_proj.weight, x, T, d, lv.d_ff, epi=nat.EPI_RESIDUAL, R=x,

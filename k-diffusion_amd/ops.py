@@ -224,17 +224,18 @@ def attn_block(x, scale, weight, *, rows_per_sample, qk, out=None, eps=1e-6, w_o
     return out, x, sync
 
 
-def geglu_block(x, scale, weight, *, rows_per_sample, out=None, eps=1e-6):
-    """AdaRMSNorm -> up projection + GEGLU (image_transformer_v2.py:487-491) at 256 tokens per sample in the attention block's form
-    (kd_geglu_block_bf16): x [B, T, K] bf16, ``scale`` [B, K], ``weight`` [2 d_ff, K] -> [B, T, d_ff] bf16; bit-identical to
-    ``norm_linear(..., epi=EPI_GEGLU)``.  K in {256, 512}, d_ff a multiple of 192."""
+def proj_block(x, scale, weight, *, rows_per_sample, epi=nat.EPI_GEGLU, qk=None, out=None, eps=1e-6):
+    """AdaRMSNorm -> wide projection in the attention block's form (kd_proj_block_bf16): the FF block's up projection + GEGLU
+    (image_transformer_v2.py:487-491; ``weight`` [2 d_ff, K] -> [.., d_ff]) or, with ``epi=EPI_QKV`` and ``qk`` as in ``norm_linear``, the qkv
+    projection with cosine-sim scale + RoPE (``weight`` [3 K, K] -> [.., 3 K]).  x [B, T, K] bf16 with T a multiple of 256, K in {256, 512};
+    bit-identical to ``norm_linear(..., epi=epi)``."""
     K = x.shape[-1]
     M = x.numel() // K
-    d_ff = weight.shape[0] // 2
-    out = torch.empty(*x.shape[:-1], d_ff, device=x.device, dtype=x.dtype) if out is None else out
-    d = gemm(x, weight, out, M=M, N=d_ff, K=K, epi=nat.EPI_GEGLU, norm_scale=scale, scale_stride=K, rows_per_sample=rows_per_sample, eps=eps,
+    N = weight.shape[0] // (2 if epi == nat.EPI_GEGLU else 1)
+    out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=x.dtype) if out is None else out
+    d = gemm(x, weight, out, M=M, N=N, K=K, epi=epi, norm_scale=scale, scale_stride=K, rows_per_sample=rows_per_sample, eps=eps, qk=qk,
              precision=nat.PREC_BF16, launch=False)
-    nat.check(nat.lib().kd_geglu_block_bf16(C.byref(d), _stream()), "kd_geglu_block_bf16")
+    nat.check(nat.lib().kd_proj_block_bf16(C.byref(d), _stream()), "kd_proj_block_bf16")
     return out
 
 

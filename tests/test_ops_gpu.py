@@ -831,26 +831,34 @@ def test_bf16_qkv_epilogue(ops, H, W, nh, B, K):
     assert relerr(qkv[..., 2, :, :], ref[..., 2, :, :]) < 1.2e-2
 
 
-@pytest.mark.parametrize("B,K,d_ff", [(32, 512, 1536), (3, 512, 1536), (16, 256, 768), (5, 256, 384), (2, 512, 192)])
-def test_geglu_block_bf16_matches_the_projection_kernel(KD, ops, B, K, d_ff):
-    """kd_geglu_block_bf16 (round 5: the FF block's norm -> up projection + GEGLU at 256 tokens per sample, a workgroup per (sample, 192-output
-    slice) with the rows normalised once) against kd_gemm_bf16 on the same descriptor: same products in the same order, BIT-IDENTICAL; and
-    against the oracle at the bf16 mode's tolerance."""
+@pytest.mark.parametrize("B,T,K,d_ff", [(32, 256, 512, 1536), (3, 256, 512, 1536), (8, 1024, 256, 768), (5, 256, 256, 384), (2, 512, 512, 192), (3, 768, 256, 768)])
+def test_proj_block_bf16_matches_the_projection_kernel(KD, ops, B, T, K, d_ff):
+    """kd_proj_block_bf16 (round 5: AdaRMSNorm -> up projection + GEGLU, and AdaRMSNorm -> qkv projection + cosine-sim scale + RoPE, as a
+    workgroup per (256-row group, six 64-row half blocks of the packed weight) with the group's rows normalised once) against kd_gemm_bf16 on
+    the same descriptor: same products in the same order, BIT-IDENTICAL; and against the oracle at the bf16 mode's tolerance.  One and
+    several row groups per sample, group counts that are and are not multiples of 8 (the XCD-aware and the plain workgroup order)."""
     from k_diffusion_amd import _native as nat
-    T = 256
-    assert nat.lib().kd_geglu_block_bf16_supported(T, K, d_ff) == 1
+    assert nat.lib().kd_proj_block_bf16_supported(T, K, d_ff, nat.EPI_GEGLU) == 1 and nat.lib().kd_proj_block_bf16_supported(T, K, 3 * K, nat.EPI_QKV) == 1
     x, scale = rn(B, T, K, seed=8) * (1 + rn(B, T, 1, seed=3).abs()), 1 + 0.2 * rn(B, K, seed=9)
     wg = rn(2 * d_ff, K, seed=7, scale=K ** -0.5)
     xb, sc, wd = _bf(x), g(scale), g(wg)
     two = ops.norm_linear(xb, sc, wd, rows_per_sample=T, epi=nat.EPI_GEGLU)
-    one = ops.geglu_block(xb, sc, wd, rows_per_sample=T)
+    one = ops.proj_block(xb, sc, wd, rows_per_sample=T)
     assert one.dtype == BF and one.shape == (B, T, d_ff)
-    ndiff = int((one != two).sum())
-    print(f"geglu_block B={B} K={K} d_ff={d_ff}: {ndiff} of {one.numel()} outputs differ")
+    print(f"proj_block GEGLU B={B} T={T} K={K} d_ff={d_ff}: {int((one != two).sum())} of {one.numel()} outputs differ")
     assert torch.equal(one, two)
     assert relerr(one.float().cpu(), hdit.linear_geglu(hdit.rms_norm(_rt(x), scale[:, None, :]), _rt(wg))) < 1.5e-2
+    # the qkv form: q, k prepared (cosine-sim scale + RoPE from the token's position inside ITS sample), v scaled by the row factor
+    nh = K // 64
+    H, W = T // 16, 16
+    w = rn(3 * K, K, seed=10, scale=K ** -0.5)
+    qk = (g(torch.linspace(5.0, 12.0, nh)), g(hdit.axial_pos(H, W).reshape(T, 2).contiguous()), g((hdit.rope_freqs(nh) / (2 * np.pi)).contiguous()), nh)
+    q2 = ops.norm_linear(xb, sc, g(w), rows_per_sample=T, epi=nat.EPI_QKV, qk=qk)
+    q1 = ops.proj_block(xb, sc, g(w), rows_per_sample=T, epi=nat.EPI_QKV, qk=qk)
+    print(f"proj_block QKV B={B} T={T} K={K}: {int((q1 != q2).sum())} of {q1.numel()} outputs differ")
+    assert q1.shape == (B, T, 3 * K) and torch.equal(q1, q2)
     with pytest.raises(RuntimeError):
-        ops.geglu_block(_bf(rn(2, 64, K, seed=1)), g(scale[:2]), wd, rows_per_sample=64)
+        ops.proj_block(_bf(rn(2, 64, K, seed=1)), g(scale[:2]), wd, rows_per_sample=64)
 
 
 @pytest.mark.parametrize("nh,B,K", [(8, 32, 512), (8, 3, 512), (4, 16, 256), (4, 5, 256)])
