@@ -19,7 +19,12 @@
  *     alike: every shipped config, k_diffusion/config.py:135-136).  The reference's `d_head` (image_transformer_v2.py:355-363:
  *     n_heads = d_model // d_head, RoPE on d_head // 2) is therefore not an argument of any entry point -- n_heads is, and the feature
  *     width is n_heads * 64; the Python mirror's model constructor refuses other values with a ValueError that says so
- *     (k-diffusion_amd/models/image_transformer_v2.py) instead of handing the kernels a layout they would misread.
+ *     (k-diffusion_amd/models/image_transformer_v2.py) instead of handing the kernels a layout they would misread;
+ *   - reproducibility: a call's result is a function of its arguments and of which kernel serves it; the choice between a throughput
+ *     kernel and a few-rows / block form of the same projection follows the ROW COUNT and the device's CU count (cost rules of the
+ *     launchers), and the forms sum in different orders.  So the same sample can differ in its last bits between batch sizes or chips with
+ *     another CU count (inside every tolerance stated here; forms documented as bit-identical to each other are exactly that).  The options
+ *     that pin a form (x3s_max_rows / b16s_max_rows = 0, attn_block_bf16 / proj_block_bf16 = 0) give batch-invariant results.
  */
 #ifndef KDIFF_HIP_H
 #define KDIFF_HIP_H

@@ -46,6 +46,21 @@ void prof_end(ProfTicket t, hipStream_t s) {
 
 }  // namespace kd
 
+namespace kd {
+int cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (n <= 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+}  // namespace kd
+
 using namespace kd;
 
 // ---- library options (explicit switches instead of environment variables read inside the library) -------------------------

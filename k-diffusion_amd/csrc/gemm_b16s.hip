@@ -244,17 +244,6 @@ __global__ __launch_bounds__(512) void gemm_b16s_kernel(const SArgs p) {
   }
 }
 
-static int cu_count() {
-  static std::atomic<int> n{0};
-  int v = n.load(std::memory_order_relaxed);
-  if (!v) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n.store(v, std::memory_order_relaxed);
-  }
-  return v;
-}
 
 template <int EPI, bool NORM>
 static int launch(const SArgs& a, const char* nm, double flops, double bytes, hipStream_t s) {

@@ -279,15 +279,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_wstat_kernel(const GArgs p) {
 
 unsigned long long* g_clk = nullptr;
 
-static int cu_count() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  }
-  return n;
-}
 
 constexpr int WSTAT_LDS_MAX = 144 * 1024;
 

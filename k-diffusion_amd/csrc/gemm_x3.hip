@@ -767,15 +767,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(const XArgs p) {
 
 unsigned long long* g_clk = nullptr;
 
-static int cu_count() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  }
-  return n;
-}
 
 template <int NC, int EPI>
 static int launch(const XArgs& a0, const char* nm, double flops, double bytes, hipStream_t s, int force_splits = 0) {

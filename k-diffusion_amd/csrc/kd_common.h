@@ -61,6 +61,9 @@ struct LdsAttr {
   }
 };
 
+// CUs of the CURRENT device (hipGetDevice), cached per device ordinal: the grid / split / kernel-selection rules of the launchers use it
+int cu_count();
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(KD_ELAUNCH, "%s: %s", what, hipGetErrorString(e));

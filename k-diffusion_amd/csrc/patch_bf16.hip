@@ -229,22 +229,13 @@ __global__ __launch_bounds__(PNW * 64) void patchin4_kernel(const PArgs p) {
   }
 }
 
-static int cu_count_p() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  }
-  return n;
-}
 
 template <auto kern>                  // (the kernel is a template ARGUMENT: one LdsAttr per kernel, although all of them share one function type)
 static int launch_patch(const PArgs& a, int lds, const char* nm, double flops, double bytes, hipStream_t s) {
   static LdsAttr attr_set;
   attr_set.ensure(reinterpret_cast<const void*>(kern), 64 * 1024);
   const int chunks = (a.M + 31) / 32;
-  int groups = cu_count_p();
+  int groups = cu_count();
   const int need = (chunks + PNW - 1) / PNW;
   if (groups > need) groups = need;
   LaunchScope prof(nm, flops, bytes, s);
