@@ -301,8 +301,8 @@ def job_rate(args, modes, dev):
     k_diffusion/evaluation.py:80-90), timed end to end: ``sample.main([... --random-weights --seed S -n N --batch-size B --steps 50 --sampler dpmpp_2m
     --no-png])`` builds its own model, draws every batch's noise, runs the sampler over N / B batches and assembles the N finished images on the
     device; ``seconds`` is sample.py's own "N images in ... s" region (first batch's plan building included) and images / seconds is the job rate.
-    Both noise sources of --seed are timed: `host` (per-image CPU generators, drawn ahead by worker threads -- the recipe of the committed
-    fixtures) and `device` (kd_randn_f32, keyed by (seed, global index)).  `value` above times the sampler on a resident x0; `ratio_to_value`
+    Both noise sources of --seed are timed: `device` (the CLI's default: kd_randn_f32, keyed by (seed, global index)) and `host` (per-image CPU
+    generators drawn ahead by worker threads -- the recipe of the committed fixtures; its rate depends on what else the host's cores do).  `value` above times the sampler on a resident x0; `ratio_to_value`
     says how much of that the whole job keeps."""
     import contextlib
     import sample as cli
@@ -314,7 +314,7 @@ def job_rate(args, modes, dev):
         for m in modes:
             os.environ["KDIFF_GEMM"] = m
             ent = {}
-            for noise in ("host", "device"):
+            for noise in ("device", "host"):
                 with contextlib.redirect_stdout(sys.stderr):                      # the CLI's own prints must not join the JSON line on stdout
                     cli.main(base + ["-n", str(args.batch), "--noise", noise])     # one batch: what a fresh model pays once (plans, packed weights)
                     first = dict(cli.LAST_RUN)
@@ -328,7 +328,7 @@ def job_rate(args, modes, dev):
     finally:
         os.environ["KDIFF_GEMM"] = saved if saved is not None else "split3"
     return {"workload": f"sample.py --config {os.path.basename(args.config)} --random-weights --seed {args.seed} -n {args.job_images} --batch-size {args.batch} "
-                        f"--steps {args.sampler_steps} --sampler {args.sampler.replace('sample_', '')} --no-png [--noise host|device]",
+                        f"--steps {args.sampler_steps} --sampler {args.sampler.replace('sample_', '')} --no-png [--noise device|host]",
             "timed_region": "sample.py's own 'N images in ... s': schedule, every batch's noise draw, sampler, assembly of the N finished fp32 images on "
                             "the device, final synchronize (model construction / weight upload before it are in main_wall_seconds)",
             "modes": out}
@@ -809,8 +809,8 @@ def main():
                 ref_value = head["value"] if m == args.mode else result["modes"][m]["value"]
                 for e in ent.values():
                     e["ratio_to_value"] = round(e["value"] / ref_value, 4)
-            job["value"] = job["modes"][args.mode]["host"]["value"]          # the CLI's default noise source
-            job["ratio_to_value"] = job["modes"][args.mode]["host"]["ratio_to_value"]
+            job["value"] = job["modes"][args.mode]["device"]["value"]          # the CLI's default noise source
+            job["ratio_to_value"] = job["modes"][args.mode]["device"]["ratio_to_value"]
             result["job"] = job
         if "modes" in result:
             # short copy of the per-mode throughputs (the full entries carry their rooflines: a truncated log tail may cut them off)

@@ -497,9 +497,9 @@ class _Plan:
                     dq = gemm(prefix + "qkv_proj", x, sa.qkv_proj.weight, qkv, T, 3 * d, d, epi=nat.EPI_QKV,
                               scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps, qk=qk)
                     # bf16 mode, K = 256 / 512 with an attention core of its own (neighbourhood / window levels): the projection in the block
-                    # form (kd_proj_block_bf16: a workgroup per (256-row group, 6 head vectors), rows normalised once) from 32 workgroups on
+                    # form (kd_proj_block_bf16: a workgroup per (256-row group, 6 head vectors), rows normalised once) for one-round grids (192 .. 256)
                     if bf and target is self.launches and os.environ.get("KDIFF_PROJ_BLOCK", "1") != "0" \
-                            and bool(lib.kd_proj_block_bf16_supported(rps, d, 3 * d, nat.EPI_QKV)) and 32 <= (T // 256) * (3 * d // 384) <= 256:
+                            and bool(lib.kd_proj_block_bf16_supported(rps, d, 3 * d, nat.EPI_QKV)) and 192 <= (T // 256) * (3 * d // 384) <= 256:
                         target[-1] = _Launch(lib.kd_proj_block_bf16, (C.byref(dq),), prefix + "qkv_proj(block)", enc=("kd_proj_block_bf16", (dq,)))
                 dq.qkv_packed = 1 if packed_qkv else 0
                 prep = (2 if packed_qkv else 0, None, None, None, C.c_float(1e-6), precision)
@@ -567,10 +567,12 @@ class _Plan:
                               scale_ptr=scale_ptr(prefix + "ff.norm"), scale_stride=total, rows_per_sample=rps,
                               c_planes=hid_planes if (d in (128, 256) and T >= 512) else None)
                     # bf16 mode, rows per sample a multiple of 256: the projection in the attention block's form (a workgroup per (256-row group,
-                    # 192-output slice), rows normalised once; csrc/attn_bf16.hip: proj_block_bf16_kernel) for grids of 32 workgroups up to ONE round
-                    # of the chip's 256 CUs (two rounds measured level with the A-stationary kernel: 42.3 against 41.5 us at level 1); same bits
+                    # 192-output slice), rows normalised once; csrc/attn_bf16.hip: proj_block_bf16_kernel) for grids that fill ONE round of the
+                    # chip's 256 CUs (192 .. 256 workgroups): two rounds measured level with the A-stationary kernel (42.3 against 41.5 us at
+                    # level 1), and a workgroup's six passes are a serial chain -- at 32 - 128 workgroups the A-stationary kernel, which splits
+                    # the same work over up to 512 slots, is faster (batch 4: 0.645 against 0.759 ms per forward; batch 16: level); same bits
                     if bf and target is self.launches and os.environ.get("KDIFF_PROJ_BLOCK", "1") != "0" \
-                            and bool(lib.kd_proj_block_bf16_supported(rps, d, lv.d_ff, nat.EPI_GEGLU)) and 32 <= (T // 256) * (lv.d_ff // 192) <= 256:
+                            and bool(lib.kd_proj_block_bf16_supported(rps, d, lv.d_ff, nat.EPI_GEGLU)) and 192 <= (T // 256) * (lv.d_ff // 192) <= 256:
                         target[-1] = _Launch(lib.kd_proj_block_bf16, (C.byref(du),), prefix + "up_proj(block)", enc=("kd_proj_block_bf16", (du,)))
                     if not (d in (128, 256) and T >= 512):
                         hid_planes = None

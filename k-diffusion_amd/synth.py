@@ -90,7 +90,7 @@ class NoisePrefetcher:
         from concurrent.futures import ThreadPoolExecutor
         self.shape, self.seed, self.sigma_max, self.device = tuple(shape_chw), int(seed), float(sigma_max), torch.device(device)
         self.depth = max(1, int(depth))
-        self.pool = ThreadPoolExecutor(max_workers=threads or max(1, min(16, (os.cpu_count() or 2) - 1)), thread_name_prefix='kd-noise')
+        self.pool = ThreadPoolExecutor(max_workers=threads or int(os.environ.get('KDIFF_NOISE_THREADS', '0')) or max(1, min(16, (os.cpu_count() or 2) - 1)), thread_name_prefix='kd-noise')
         self.plan, self.pending, self.next_to_fill, self.slots, self.copy_stream = [], {}, 0, [], None
         if width:                         # the pinned ring now (set-up, like the model's construction) instead of at schedule()
             self._ring(int(width))

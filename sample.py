@@ -14,14 +14,11 @@ sample.py:59-60, and therefore cannot run its own class-conditional configs):
   --class-cond C       class id for every image (-1: image index mod num_classes) for class-conditional configs
   --random-weights     no checkpoint: synthetic weights (K.synth), for smoke runs and benchmarking
   --no-png             skip PNG encoding (timing runs)
-  --noise host|device  where --seed's per-image noise is drawn.  host (default): one CPU torch.Generator per global image index
-                       (K.synth.synth_noise: the recipe of the committed fixtures), drawn by worker threads AHEAD of the sampler and
-                       handed over as an asynchronous pinned copy, so the draw runs beside the previous batch's GPU pass;
-                       device: the keyed Philox generator of the HIP library (kd_randn_f32; seed, global index, draw number ->
-                       values), no host work at all -- also for the ancestral samplers' per-step noise
-  --gather-uint8       8-bit conversion on the GPU before the all-gather of finished images (same PNG bytes, 4x less xGMI traffic).
-                       The DEFAULT whenever there is a gather (more than one process) and PNG files are written -- the writer needs
-                       nothing else; --gather-fp32 keeps the reference's fp32 gather (main() then returns fp32 images)
+  --noise device|host  where --seed's per-image noise is drawn.  device (default): the keyed Philox generator of the HIP library
+                       (kd_randn_f32; seed, global index, draw number -> values), no host work at all -- also for the ancestral samplers'
+                       per-step noise; host: one CPU torch.Generator per global image index (K.synth.synth_noise: the recipe of the
+                       committed fixtures), drawn by worker threads AHEAD of the sampler and handed over as an asynchronous pinned copy on a
+                       side stream, so the draw runs beside the previous batch's GPU pass
 With --seed the stochastic samplers are index-addressed too: one Brownian tree per global image index for the SDE samplers,
 a per-(index, call) stream for the ancestral ones (the reference draws both from rank-local global RNG state).
 """
@@ -52,8 +49,8 @@ def parse(argv=None):
     p.add_argument('--class-cond', type=int, default=None, help='class id for all images; -1 = index mod num_classes')
     p.add_argument('--random-weights', action='store_true', help='synthetic weights instead of a checkpoint')
     p.add_argument('--no-png', action='store_true', help='do not write PNG files')
-    p.add_argument('--noise', choices=['host', 'device'], default='host',
-                   help="where --seed's per-image noise is drawn: CPU generators ahead of the sampler (default) or the library's keyed device generator")
+    p.add_argument('--noise', choices=['device', 'host'], default='device',
+                   help="where --seed's per-image noise is drawn: the library's keyed device generator (default) or per-image CPU generators ahead of the sampler")
     p.add_argument('--gather-uint8', action='store_true',
                    help='convert finished images to uint8 on the GPU before the all-gather (what the PNG writer needs; 4x less xGMI traffic)')
     p.add_argument('--gather-fp32', action='store_true', help='all-gather the finished images as fp32 even when only PNG files are wanted')
@@ -115,7 +112,7 @@ def device_noise(seed, indices, shape, device, draw=0, scale=1.0):
     return K.ops.randn_indexed(torch.empty((len(indices), *shape), device=device, dtype=torch.float32), keys, draw=draw, scale=scale)
 
 
-def indexed_noise_sampler(seed, indices, shape, device, where='host'):
+def indexed_noise_sampler(seed, indices, shape, device, where='host'):   # (the CLI passes --noise; the default here is the fixtures' recipe)
     """noise_sampler(sigma, sigma_next) for the ancestral samplers (default: randn_like on the global stream, sampling.py:73-75)
     whose draw for image i is a function of (seed, i, call number) only.  ``where``: 'host' = one CPU generator per (image, call)
     (the recipe of the round-1 fixtures; slow -- every call draws on the host), 'device' = kd_randn_f32 with the call number as
