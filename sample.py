@@ -19,6 +19,9 @@ sample.py:59-60, and therefore cannot run its own class-conditional configs):
                        per-step noise; host: one CPU torch.Generator per global image index (K.synth.synth_noise: the recipe of the
                        committed fixtures), drawn by worker threads AHEAD of the sampler and handed over as an asynchronous pinned copy on a
                        side stream, so the draw runs beside the previous batch's GPU pass
+  --gather-uint8       8-bit conversion on the GPU before the all-gather of finished images (same PNG bytes, 4x less xGMI traffic).
+                       The DEFAULT whenever there is a gather (more than one process) and PNG files are written -- the writer needs
+                       nothing else; --gather-fp32 keeps the reference's fp32 gather (main() then returns fp32 images)
 With --seed the stochastic samplers are index-addressed too: one Brownian tree per global image index for the SDE samplers,
 a per-(index, call) stream for the ancestral ones (the reference draws both from rank-local global RNG state).
 """
