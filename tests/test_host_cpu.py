@@ -740,3 +740,68 @@ def test_oracle_index_addressed_normals():
     d1 = ob.randn_indexed([5], 200_000, draw=1)[0]
     assert abs(np.corrcoef(d1, z[0])[0, 1]) < 8e-3 and not np.array_equal(d1, z[0])
     assert np.allclose(ob.randn_indexed([5], 64, scale=160.0)[0], 160.0 * z[0][:64], rtol=1e-6)
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(REPO, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    return mod
+
+
+def test_bench_global_attention_block_figure_from_a_recorded_kernel_table(KD):
+    """bench.py's `roofline.global_attention_block` (north_star's one named efficiency figure) is derived from the per-launch event table of a pass:
+    every launch at the last level's row count except the merge into / split out of it, plus that level's attention launches.  Checked here on
+    the committed round-5 tables (no GPU): which kernels are picked, the per-layer arithmetic, useful vs executed fraction."""
+    import json
+    bench = _load_bench()
+    cfg = KD.config.load_config(os.path.join(REPO, "configs", "config_oxford_flowers.json"))
+    for mode, fname in (("bf16", "r05_kernel_table_bf16.json"), ("split3", "r05_kernel_table_split3.json")):
+        table = json.load(open(os.path.join(REPO, "profiles", fname)))["kernels"]
+        g = bench.global_attention_block(table, mode, cfg, 32, 50)
+        assert g["level_width"] == 512 and g["tokens_per_sample"] == 256 and g["layers_timed"] == 4 * 50
+        names = list(g["kernels_us"])
+        assert all(" M=8192 " in n + " " or n.startswith(("attn_global", "attn_block")) for n in names)
+        assert not any("<a1," in n or ",e3>" in n for n in names)                       # neither the merge into the level nor the split out of it
+        assert abs(g["gflop_per_layer"] - 60.13) < 0.05                                   # 2 M N K of qkv / out / up / down + 4 T^2 d of the cores
+        assert g["launches_per_layer"] == (4.0 if mode == "bf16" else 5.0)
+        ms = sum(v["ms"] for n, v in table.items() if n in names)
+        assert abs(g["us_per_layer"] - ms * 1e3 / 200) < 0.02
+        assert abs(g["frac_of_bf16_mfma_peak"] - g["gflop_per_layer"] / g["us_per_layer"] * 1e3 / 2500.0) < 2e-4       # GFLOP / us = PFLOP/s
+        assert g["executed_frac_of_bf16_mfma_peak"] == pytest.approx(g["frac_of_bf16_mfma_peak"] * (3 if mode == "split3" else 1), abs=2e-4)
+    # a model whose last level is not global attention has no such figure
+    sw = KD.config.load_config({"model": {"type": "image_transformer_v2", "input_channels": 3, "input_size": [32, 32], "patch_size": [2, 2], "depths": [2],
+                                          "widths": [128], "self_attns": [{"type": "shifted-window", "d_head": 64, "window_size": 8}],
+                                          "sigma_data": 0.5, "sigma_min": 1e-2, "sigma_max": 80}})
+    assert bench.global_attention_block(table, "bf16", sw, 32, 50) is None
+
+
+def test_bench_throttle_accumulators_and_the_reading(monkeypatch):
+    """bench.py's `power` object: amd-smi's throttle accumulators are parsed from its JSON whatever the nesting, a missing tool gives None, and
+    the sentence it prints grades the power limiter's share of the ticks instead of asserting a cause."""
+    import json
+    import subprocess
+    bench = _load_bench()
+    sample = {"gpu_data": [{"gpu": 0, "throttle": {"accumulation_counter": 1000, "prochot_accumulated": 0, "ppt_accumulated": {"value": 250, "unit": "ticks"},
+                                                    "socket_thermal_accumulated": 0, "vr_thermal_accumulated": 0, "hbm_thermal_accumulated": 0,
+                                                    "gfx_clk_below_host_limit_accumulated": "N/A"}}]}
+
+    class Done:
+        def __init__(self, out):
+            self.stdout = out
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: Done(json.dumps(sample)))
+    acc = bench.throttle_accumulators()
+    assert acc == {"accumulation_counter": 1000, "prochot_accumulated": 0, "ppt_accumulated": 250, "socket_thermal_accumulated": 0,
+                   "vr_thermal_accumulated": 0, "hbm_thermal_accumulated": 0}
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: Done("amd-smi: command not found"))
+    assert bench.throttle_accumulators() is None
+
+    def boom(*a, **k):
+        raise FileNotFoundError("amd-smi")
+    monkeypatch.setattr(subprocess, "run", boom)
+    assert bench.throttle_accumulators() is None and bench._smi("--showpower") == ""
