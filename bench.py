@@ -2,6 +2,7 @@
 """Benchmark of the k-diffusion sampling hot path on MI355X (contract: see the task statement).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (starts its own ranks: re-executes itself under the launcher below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -19,8 +20,12 @@ fp32-PARITY mode -- the reference samples in fp32 (sample.py:39-47, no mixed pre
   bf16    bf16 activations, one bf16 MFMA per product, fp32 accumulate / statistics (the reference under autocast(bfloat16);
           1.1e-2 from the fp32 reference after 50 steps: NOT parity-grade, reported for what it is)
   exact   fp32 activations, fp32-input MFMA, bit-for-bit an fmaf chain
-``other_configs`` carries BASELINE configs[2] (shifted-window) and configs[4] (neighbourhood attention, sample_dpmpp_sde x 50 with
-Brownian-tree noise, fp8-stored weights) at a few passes each.
+Beside the contract's keys (N = 1): ``job`` -- the job the CLI runs (sample.py --seed, 512 images: noise draw -> finished images on the device), timed
+end to end for both noise sources and both measured modes, with its ratio to ``value``; ``roofline.global_attention_block`` -- the last (global-attention)
+level's layers from the pass's own events: us per layer, fraction of the dense bf16 MFMA peak; ``other_configs`` -- all five BASELINE configurations
+(MNIST Euler-10 batch 4, CIFAR-10 Heun-50 batch 64, shifted-window, the headline itself, sample_dpmpp_sde x 50 with Brownian-tree noise and fp8-stored
+weights), each with its distance to the reference's golden at that batch; ``parity``; ``small_batch`` (batch 1 / 4 latency); ``power`` -- socket power,
+shader clock, the board's cap and the firmware's throttle accumulators over extra untimed passes; ``cpu_baseline``.
 """
 import argparse
 import json
