@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bf16 mode, the global-attention block in front of its out projection (csrc/attn_bf16.hip): the one-launch form (kd_attn_block_bf16)
+"""bf16 mode, the global-attention block in front of its out projection (csrc/block_bf16.hip): the one-launch form (kd_attn_block_bf16)
 against the two launches it replaces, with workgroup 0's in-kernel time line.
 
     python benchmarks/attn_block_bench.py [iters]"""

@@ -14,7 +14,7 @@ def main():
     src = sys.argv[1]
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-    if os.path.basename(src).startswith("attn_"):
+    if os.path.basename(src).startswith(("attn_", "block_")):
         flags += ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
     if os.path.basename(src) == "elementwise.hip":
         flags += ["-ffp-contract=off"]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Race screen of the round-5 block kernels (csrc/attn_bf16.hip): kd_attn_block_bf16 (with and without the fused out projection and its
+"""Race screen of the round-5 block kernels (csrc/block_bf16.hip): kd_attn_block_bf16 (with and without the fused out projection and its
 per-sample rendezvous) and kd_proj_block_bf16 run the same products in the same order as the launches they replace, so every launch must
 reproduce those bit for bit.  Each shape is launched `reps` times with fresh random inputs every few launches, interleaved with a memory-bound
 kernel on a second stream (uneven load, workgroups that start late), and every word is compared; the rendezvous counters must stay zero.

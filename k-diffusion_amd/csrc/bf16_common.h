@@ -122,7 +122,7 @@ __device__ __forceinline__ float pick_half(float f_lo, float f_hi, unsigned hi_m
 __device__ __forceinline__ void qk_prep_blocks(f32x16& a0, f32x16& a1, float rs, float sqrt_scale, float eps, float py, float px,
                                                const float (&fr)[4]) {
   // Every product / sum below is written as the instruction it must become (contraction off, explicit fmaf): this function is inlined
-  // into several kernels -- the qkv projections and the fused attention block (attn_bf16.hip), whose results are tested BIT-IDENTICAL
+  // into several kernels -- the qkv projections and the fused attention block (block_bf16.hip), whose results are tested BIT-IDENTICAL
   // against each other -- and left to itself the compiler fuses `x1 * c - x2 * s` one way in one kernel and the other way in the next.
 #pragma clang fp contract(off)
   float ss = 0.f;

@@ -461,7 +461,7 @@ class _Plan:
                 # (the tiled qkv epilogue keeps its per-head constants in a 16-head LDS table, csrc/gemm_x3t.hip: wider levels -- 1152 =
                 # 18 heads and up -- take the fp32-A norm -> projection kernels of round 1 like every shape the fused kernels refuse)
                 # bf16 mode, global attention at 256 tokens per sample: norm -> qkv projection of a head -> cosine-sim + RoPE -> attention in
-                # ONE launch per layer (csrc/attn_bf16.hip: attn_block_bf16_kernel; q, k, v never reach HBM).  The descriptor is the qkv
+                # ONE launch per layer (csrc/block_bf16.hip: attn_block_bf16_kernel; q, k, v never reach HBM).  The descriptor is the qkv
                 # projection's, its C the attention output
                 # From 32 (sample, head) workgroups on: below that (batch 1 - 2 at level 2) the few-rows projection + the dense core are faster
                 # (0.514 against 0.543 ms per forward at batch 1; from batch 4 on the one-launch form wins: profiles/r05_attn_block.md)
@@ -567,7 +567,7 @@ class _Plan:
                               scale_ptr=scale_ptr(prefix + "ff.norm"), scale_stride=total, rows_per_sample=rps,
                               c_planes=hid_planes if (d in (128, 256) and T >= 512) else None)
                     # bf16 mode, rows per sample a multiple of 256: the projection in the attention block's form (a workgroup per (256-row group,
-                    # 192-output slice), rows normalised once; csrc/attn_bf16.hip: proj_block_bf16_kernel) for grids that fill ONE round of the
+                    # 192-output slice), rows normalised once; csrc/block_bf16.hip: proj_block_bf16_kernel) for grids that fill ONE round of the
                     # chip's 256 CUs (192 .. 256 workgroups): two rounds measured level with the A-stationary kernel (42.3 against 41.5 us at
                     # level 1), and a workgroup's six passes are a serial chain -- at 32 - 128 workgroups the A-stationary kernel, which splits
                     # the same work over up to 512 slots, is faster (batch 4: 0.645 against 0.759 ms per forward; batch 16: level); same bits
