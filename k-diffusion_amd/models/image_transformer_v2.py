@@ -46,7 +46,7 @@ SCHEDULE_TABLE_MAX_BYTES = 1 << 30
 SCHEDULES_KEPT = 4            # a run of a two-stage solver hints two tables; older records (and their tensors) are dropped
 SCHEDULE_CHAINS_KEPT = 2      # conditioning workspaces kept per plan, by schedule length (least recently used dropped)
 # environment switches read while a plan is built (name, default): part of the plan key
-PLAN_SWITCHES = (("KDIFF_ATTN_BLOCK", "1"), ("KDIFF_PROJ_BLOCK", "1"), ("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "0"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "1"), ("KDIFF_X3_PLANES", "1"),
+PLAN_SWITCHES = (("KDIFF_ATTN_BLOCK", "1"), ("KDIFF_PROJ_BLOCK", "1"), ("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "0"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "all"), ("KDIFF_X3_PLANES", "1"),
                  ("KDIFF_X3_DOWN", "0"), ("KDIFF_RUN_LIST", "1"))
 CLASS_IDS_KEPT = 4            # range-checked class_cond tensors remembered per plan (cond / uncond pairs of a guidance wrapper)
 
@@ -431,9 +431,12 @@ class _Plan:
             rps = gh * gw
             ffn_x3 = precision == nat.PREC_SPLIT3 and target is self.launches and lib.kd_ffn_f32_supported(T, d, lv.d_ff) \
                 and os.environ.get("KDIFF_FFN_X3", "1") != "0"
-            # out projection fused into the FF kernel: width 128 (+3.5 % images/s; at width 256, one wave per SIMD, it measured level:
-            # 176.1 vs 176.0).  KDIFF_FFN_OUT: 0 never, 1 default, all = every width the kernel takes, or ONE width
-            fo = os.environ.get("KDIFF_FFN_OUT", "1")
+            # out projection fused into the FF kernel: width 128 (+3.5 % images/s in round 3) and, since round 5, width 256 too: in round 3
+            # that measured level (176.1 vs 176.0: one wave per SIMD there); with the round-4 / 5 kernels around it the removed launch + the
+            # attention rows' HBM round trip are worth +1.5 .. +3.0 % on two boxes (same box, back to back: 207.9 / 207.9 / 208.7 vs 214.3;
+            # 186.9 / 186.9 / 187.0 vs 189.4 / 190.0).  KDIFF_FFN_OUT: 0 never, 1 = width 128 only, all (default) = every width the kernel
+            # takes, or ONE width
+            fo = os.environ.get("KDIFF_FFN_OUT", "all")
             ffn_bf = bf and target is self.launches and bool(lib.kd_ffn_bf16_supported(T, d, lv.d_ff))
             fuse_out = hasattr(mod, "self_attn") and ((ffn_x3 and d in (128, 256)) or (ffn_bf and d == 128)) \
                 and (d == 128 if fo == "1" else fo in ("all", str(d)))
