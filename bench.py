@@ -773,7 +773,11 @@ def main():
             result["modes"][args.mode]["roofline"] = "see the top-level `roofline`"
             for m in [m for m in args.modes.split(",") if m and m != args.mode]:
                 os.environ["KDIFF_GEMM"] = m
-                dt_m, out_m, groups_m = Timed(ctx, args.steps, args.warmup, not args.no_kernel_events).run(compute_only)
+                try:
+                    dt_m, out_m, groups_m = Timed(ctx, args.steps, args.warmup, not args.no_kernel_events).run(compute_only)
+                except Exception as e:                    # a secondary mode must not cost the line
+                    result["modes"][m] = {"error": f"{type(e).__name__}: {e}"[:600]}
+                    continue
                 ent, fam_m = mode_entry(m, dt_m, args.steps, args.warmup, B * args.steps, groups_m, 1)
                 if groups_m and nfe_of and "roofline" in ent:
                     ent["roofline"]["global_attention_block"] = global_attention_block(groups_m, m, cfg, B, nfe_of)
@@ -783,11 +787,22 @@ def main():
                     with open(args.kernel_table.replace(".json", f"_{m}.json"), "w") as f:
                         json.dump({"mode": m, "families": fam_m, "kernels": groups_m, "timed_seconds": dt_m}, f, indent=1)
             os.environ["KDIFF_GEMM"] = args.mode
-        if args.gpus == 1 and not args.no_other_configs and os.path.basename(args.config) == "config_oxford_flowers.json":
+        def guarded(key, fn):
+            """An optional block must never cost the line itself (the contract's keys are complete above): a failure is recorded under the block's key."""
+            try:
+                out = fn()
+                if out is not None:
+                    result[key] = out
+            except (Exception, SystemExit) as e:          # SystemExit: what sample.main raises on a refused argument / missing device
+                result[key] = {"error": f"{type(e).__name__}: {e}"[:600]}
+            finally:
+                os.environ["KDIFF_GEMM"] = args.mode
+
+        def block_other_configs():
             sw, na = "configs/config_oxford_flowers_shifted_window.json", "configs/config_oxford_flowers.json"
             from tests.golden import cases
             c64 = cases.SAMPLE_B64_CASE
-            result["other_configs"] = {
+            return {
                 # BASELINE configs[0]: the reference's CPU-runnable plumbing case, here on the GPU (batch 4: the latency regime)
                 "configs[0] mnist, euler x 10, batch 4": {
                     **{m: other_config("mnist", CONFIG_OF["mnist"], dev, args, "sample_euler", m, batch=4, steps=10, passes=20) for m in ("split3", "bf16")},
@@ -810,21 +825,20 @@ def main():
                     "split3": other_config("sde", na, dev, args, "sample_dpmpp_sde", "split3", brownian=True),
                     "bf16+fp8w": other_config("sde", na, dev, args, "sample_dpmpp_sde", "bf16", fp8=True, brownian=True)},
             }
-        if args.gpus == 1 and not args.no_power:
-            os.environ["KDIFF_GEMM"] = args.mode
-            result["power"] = power_and_clock(compute_only)
-        if args.gpus == 1 and not args.no_parity:
+
+        good_modes = [m for m, e in result.get("modes", {}).items() if "value" in e]
+
+        def block_parity():
             # parity magnitudes where the driver's record shows them: after the timed regions, every measured mode against the reference's golden
-            measured = [args.mode] + [m for m in result.get("modes", {}) if m != args.mode]
+            measured = [args.mode] + [m for m in good_modes if m != args.mode]
             par = parity_vs_reference_golden(dev, measured)
             head_par = par[args.mode]
-            result["parity"] = {"case": par["case"], "measure": par["measure"], "mode": args.mode,
-                                "rel_err": head_par["rel_err_vs_reference_golden"], "gate": head_par["gate"], "pass": head_par.get("pass"),
-                                "modes": {m: par[m] for m in measured}}
-        if args.gpus == 1 and not args.no_small_batch:
-            result["small_batch"] = small_batch_latency(cfg, model, dev, args, measured_modes=[args.mode] + [m for m in result.get("modes", {}) if m != args.mode and m != "exact"])
-        if args.gpus == 1 and not args.no_job:
-            measured = [args.mode] + [m for m in result.get("modes", {}) if m not in (args.mode, "exact")]
+            return {"case": par["case"], "measure": par["measure"], "mode": args.mode,
+                    "rel_err": head_par["rel_err_vs_reference_golden"], "gate": head_par["gate"], "pass": head_par.get("pass"),
+                    "modes": {m: par[m] for m in measured}}
+
+        def block_job():
+            measured = [args.mode] + [m for m in good_modes if m not in (args.mode, "exact")]
             job = job_rate(args, measured, dev)
             for m, ent in job["modes"].items():
                 ref_value = head["value"] if m == args.mode else result["modes"][m]["value"]
@@ -833,12 +847,23 @@ def main():
                         e["ratio_to_value"] = round(e["value"] / ref_value, 4)
             job["value"] = job["modes"][args.mode]["device"]["value"]          # the CLI's default noise source
             job["ratio_to_value"] = job["modes"][args.mode]["device"]["ratio_to_value"]
-            result["job"] = job
+            return job
+
+        if args.gpus == 1 and not args.no_other_configs and os.path.basename(args.config) == "config_oxford_flowers.json":
+            guarded("other_configs", block_other_configs)
+        if args.gpus == 1 and not args.no_power:
+            guarded("power", lambda: power_and_clock(compute_only))
+        if args.gpus == 1 and not args.no_parity:
+            guarded("parity", block_parity)
+        if args.gpus == 1 and not args.no_small_batch:
+            guarded("small_batch", lambda: small_batch_latency(cfg, model, dev, args, measured_modes=[args.mode] + [m for m in good_modes if m != args.mode and m != "exact"]))
+        if args.gpus == 1 and not args.no_job:
+            guarded("job", block_job)
         if "modes" in result:
             # short copy of the per-mode throughputs (the full entries carry their rooflines: a truncated log tail may cut them off)
-            result["mode_values"] = {m: e["value"] for m, e in result["modes"].items()}
+            result["mode_values"] = {m: e.get("value") for m, e in result["modes"].items()}
         if not args.no_cpu_baseline and args.gpus == 1:
-            result["cpu_baseline"] = cpu_baseline(cfg, args.seed, args.sampler_steps, args.cpu_seconds)
+            guarded("cpu_baseline", lambda: cpu_baseline(cfg, args.seed, args.sampler_steps, args.cpu_seconds))
         print(json.dumps(result), flush=True)
     ctx.wait_for_everyone()
     ctx.shutdown()
