@@ -636,6 +636,20 @@ def other_config(name, path, dev, args, sampler_name, mode, fp8=False, brownian=
     return ent
 
 
+def run_guarded(result, key, fn, mode):
+    """An optional block must never cost the line itself (the contract's keys are complete before the first of them runs): its result goes
+    under ``key``; a failure -- an exception, or the SystemExit sample.main raises on a refused argument / missing device -- is recorded there
+    instead.  The arithmetic mode of the process is put back to ``mode`` either way."""
+    try:
+        out = fn()
+        if out is not None:
+            result[key] = out
+    except (Exception, SystemExit) as e:
+        result[key] = {"error": f"{type(e).__name__}: {e}"[:600]}
+    finally:
+        os.environ["KDIFF_GEMM"] = mode
+
+
 def launch_ranks(args):
     """``python bench.py --gpus N`` typed plainly (no WORLD_SIZE in the environment): replace this process by the launcher the contract
     names -- ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
@@ -787,16 +801,7 @@ def main():
                     with open(args.kernel_table.replace(".json", f"_{m}.json"), "w") as f:
                         json.dump({"mode": m, "families": fam_m, "kernels": groups_m, "timed_seconds": dt_m}, f, indent=1)
             os.environ["KDIFF_GEMM"] = args.mode
-        def guarded(key, fn):
-            """An optional block must never cost the line itself (the contract's keys are complete above): a failure is recorded under the block's key."""
-            try:
-                out = fn()
-                if out is not None:
-                    result[key] = out
-            except (Exception, SystemExit) as e:          # SystemExit: what sample.main raises on a refused argument / missing device
-                result[key] = {"error": f"{type(e).__name__}: {e}"[:600]}
-            finally:
-                os.environ["KDIFF_GEMM"] = args.mode
+        guarded = lambda key, fn: run_guarded(result, key, fn, args.mode)      # noqa: E731
 
         def block_other_configs():
             sw, na = "configs/config_oxford_flowers_shifted_window.json", "configs/config_oxford_flowers.json"

@@ -805,3 +805,25 @@ def test_bench_throttle_accumulators_and_the_reading(monkeypatch):
         raise FileNotFoundError("amd-smi")
     monkeypatch.setattr(subprocess, "run", boom)
     assert bench.throttle_accumulators() is None and bench._smi("--showpower") == ""
+
+
+def test_bench_optional_blocks_never_cost_the_line(monkeypatch):
+    """bench.py runs its optional blocks (other configs, power, parity, small batches, the CLI job, the CPU baseline) behind run_guarded: a block
+    that raises -- or exits, as sample.main does on a refused argument -- leaves an `error` entry under its key, the line is still printed, and
+    the process's arithmetic mode is restored."""
+    bench = _load_bench()
+    monkeypatch.setenv("KDIFF_GEMM", "bf16")
+    line = {"value": 1.0}
+    bench.run_guarded(line, "ok", lambda: {"x": 1}, "split3")
+    bench.run_guarded(line, "nothing", lambda: None, "split3")
+    bench.run_guarded(line, "boom", lambda: 1 / 0, "split3")
+
+    def exits():
+        os.environ["KDIFF_GEMM"] = "exact"
+        raise SystemExit("unknown sampler 'nope'")
+    bench.run_guarded(line, "exit", exits, "split3")
+    assert line["ok"] == {"x": 1} and "nothing" not in line and line["value"] == 1.0
+    assert line["boom"]["error"].startswith("ZeroDivisionError") and "unknown sampler" in line["exit"]["error"]
+    assert os.environ["KDIFF_GEMM"] == "split3"
+    with pytest.raises(KeyboardInterrupt):                      # an interrupt is not swallowed
+        bench.run_guarded(line, "int", lambda: (_ for _ in ()).throw(KeyboardInterrupt()), "split3")
