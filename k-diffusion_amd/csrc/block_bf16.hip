@@ -23,7 +23,7 @@ namespace b16 {
 //   * the head's 64 rows of W_k, W_v, W_q stream past them (three passes over K, 8 KiB half blocks of the packed image, 4-slot ring of
 //     two k-steps each, one barrier per 16 MFMAs per wave); k and v leave their epilogues as bf16 rows of the K / V images in LDS
 //     (the dense core's swizzle), q -- the last pass -- stays in registers as the B fragments of S^T = K Q^T;
-//   * then the dense core above, unchanged: scores, softmax, O^T = V^T P^T, 16-byte stores of the attention output.
+//   * then the dense core of attn_bf16.hip (attn_dense_bf16_kernel), unchanged: scores, softmax, O^T = V^T P^T, 16-byte stores of the attention output.
 // Neither q, k nor v ever reaches HBM.  The arithmetic is that of the two-launch form operation for operation (the results are
 // bit-identical: tests/test_ops_gpu.py::test_attn_block_bf16_matches_two_launches).  144 KiB of LDS, one workgroup per CU.
 struct BArgs {
