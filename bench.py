@@ -9,23 +9,26 @@
 One "step" = one pass of the hot path over one batch: a complete 50-step ``sample_dpmpp_2m`` run
 (50 denoiser evaluations of the 256x256 image_transformer_v2 + the fused solver steps) for
 ``--batch`` images per GPU, followed -- for N > 1 -- by the path's one exchange step, the RCCL
-all-gather of the finished images (k_diffusion/evaluation.py:87).  Initial noise, weights and the
-sigma table are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+all-gather of the finished images (k_diffusion/evaluation.py:87; uint8 as the CLI gathers them, ``--gather fp32`` for the reference's).
+Initial noise, weights and the sigma table are resident in HBM before the timed region.
+
+OUTPUT (round 6).  Rank 0 prints ONE compact JSON line (< 4 KiB, the LAST line of stdout; nothing else goes to stdout and stderr stays
+quiet) with the contract's keys -- metric / value / unit / n_gpus / steps / warmup / ms_per_step / dtype / config / roofline /
+cpu_baseline -- plus ``parity`` (distance of this build on this box to the reference's 50-step batch-32 golden of this workload),
+``mode_values`` and ``detail_file``.  Everything longer (per-mode entries with their per-family rooflines, and the opt-in blocks) goes to
+``bench_detail.json`` (``--detail-file``).
 
 Arithmetic mode (``--mode``, default split3): ``value`` / ``dtype`` / ``roofline`` belong to that mode.  The default is the
 fp32-PARITY mode -- the reference samples in fp32 (sample.py:39-47, no mixed precision) and north_star asks for images within
-1e-3 of it, which only the fp32 modes meet.  At N = 1 the other modes are measured right after it on the same box with the SAME
---steps / --warmup and their own HIP-event pass, and reported as first-class entries (value, ms_per_step, roofline) under ``modes``:
+1e-3 of it, which only the fp32 modes meet.  At N = 1 the bf16 mode is measured right after it on the same box with the SAME
+--steps / --warmup and its own HIP-event pass (``mode_values``; full entry in the detail file):
   split3  fp32 activations, 3 split-bf16 MFMA terms per product: the fp32-parity mode (< 5e-4 from the fp32 reference end to end)
   bf16    bf16 activations, one bf16 MFMA per product, fp32 accumulate / statistics (the reference under autocast(bfloat16);
           1.1e-2 from the fp32 reference after 50 steps: NOT parity-grade, reported for what it is)
-  exact   fp32 activations, fp32-input MFMA, bit-for-bit an fmaf chain
-Beside the contract's keys (N = 1): ``job`` -- the job the CLI runs (sample.py --seed, 512 images: noise draw -> finished images on the device), timed
-end to end for both noise sources and both measured modes, with its ratio to ``value``; ``roofline.global_attention_block`` -- the last (global-attention)
-level's layers from the pass's own events: us per layer, fraction of the dense bf16 MFMA peak; ``other_configs`` -- all five BASELINE configurations
-(MNIST Euler-10 batch 4, CIFAR-10 Heun-50 batch 64, shifted-window, the headline itself, sample_dpmpp_sde x 50 with Brownian-tree noise and fp8-stored
-weights), each with its distance to the reference's golden at that batch; ``parity``; ``small_batch`` (batch 1 / 4 latency); ``power`` -- socket power,
-shader clock, the board's cap and the firmware's throttle accumulators over extra untimed passes; ``cpu_baseline``.
+  exact   fp32 activations, fp32-input MFMA, bit-for-bit an fmaf chain (``--detail`` or ``--modes split3,bf16,exact``)
+Opt-in blocks (``--detail`` = all of them; they lengthen the run from ~1 to ~3 minutes and only ever write to the detail file):
+``--other-configs`` (all five BASELINE configurations with their parity), ``--small-batch`` (batch 1 / 4 latency), ``--job`` (the
+sample.py CLI job timed end to end), ``--power`` (benchmarks/power_report.py).
 """
 import argparse
 import json
@@ -43,6 +46,7 @@ sys.path.insert(0, REPO)
 import k_diffusion_amd as K  # noqa: E402
 
 # /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+FP8_MFMA_PEAK_TFLOPS = 5000.0      # v_mfma_scale_f32_32x32x64_f8f6f4 dense peak (KDIFF_GEMM=fp8: the gemm_mx8 kernels)
 FP32_MFMA_PEAK_TFLOPS = 157.3      # v_mfma_f32_32x32x2_f32 dense peak (KDIFF_GEMM=exact)
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak (split3 mode executes 3 bf16 products per fp32 product)
 BF16_MFMA_SUSTAINED_TFLOPS = 2000.0  # measured: a pure MFMA kernel on all 256 CUs (profiles/r02_pipe_overlap.md); informational only
@@ -59,26 +63,36 @@ def parse(argv=None):
     p.add_argument("--sampler", default="sample_dpmpp_2m")
     p.add_argument("--sampler-steps", type=int, default=50)
     p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--mode", default=os.environ.get("KDIFF_GEMM", "split3"), choices=["bf16", "split3", "exact"], help="arithmetic mode of `value`")
-    p.add_argument("--modes", default="split3,bf16,exact", help="modes measured (same steps / warm-up, own roofline) and reported under `modes` at N = 1")
+    p.add_argument("--mode", default=os.environ.get("KDIFF_GEMM", "split3"), choices=["bf16", "split3", "exact", "fp8"], help="arithmetic mode of `value`")
+    p.add_argument("--modes", default=None, help="modes measured at N = 1 (same steps / warm-up, own roofline); default: split3,bf16 (+ exact with --detail)")
     p.add_argument("--no-other-modes", action="store_true", help="measure --mode only")
+    p.add_argument("--gather", default="uint8", choices=["uint8", "fp32"],
+                   help="what the N > 1 exchange step moves: uint8 images (what sample.py gathers when it writes PNGs) or the reference's fp32")
+    p.add_argument("--detail-file", default=os.path.join(REPO, "bench_detail.json"), help="where the long form of the result goes")
+    p.add_argument("--detail", action="store_true", help="all opt-in blocks: exact mode, --other-configs, --small-batch, --job")
+    p.add_argument("--other-configs", action="store_true", help="all five BASELINE configurations, each with its parity (detail file)")
     p.add_argument("--other-passes", type=int, default=5, help="timed passes of each `other_configs` entry (1 warm-up)")
-    p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time for the baseline sample")
-    p.add_argument("--no-kernel-events", action="store_true", help="do not record per-launch HIP events in the timed region")
-    p.add_argument("--kernel-table", default=None, help="write the per-kernel event timings to this JSON file")
-    p.add_argument("--no-other-configs", action="store_true", help="skip the short secondary measurement of the shifted-window config")
-    p.add_argument("--no-power", action="store_true", help="skip the socket power / shader clock samples (a few extra untimed passes with rocm-smi beside them)")
-    p.add_argument("--no-small-batch", action="store_true", help="skip the batch-1 / batch-4 latency entries (`small_batch`)")
-    p.add_argument("--no-parity", action="store_true", help="skip the golden-vector parity block (5-step batch-32 run per measured mode)")
-    p.add_argument("--no-job", action="store_true", help="skip the `job` block (the sample.py CLI job timed end to end: noise draw -> finished images)")
+    p.add_argument("--small-batch", action="store_true", help="batch-1 / batch-4 latency entries (detail file)")
+    p.add_argument("--job", action="store_true", help="the sample.py CLI job timed end to end: noise draw -> finished images (detail file)")
     p.add_argument("--job-images", type=int, default=512, help="images of the timed CLI job (`job`)")
     p.add_argument("--job-repeats", type=int, default=3, help="repeats of each timed CLI job (the median counts)")
+    p.add_argument("--power", action="store_true", help="socket power / shader clock / throttle accumulators over extra untimed passes (detail file)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time for the baseline sample")
+    p.add_argument("--cpu-batch", type=int, default=2, help="images of the CPU baseline's sample (BASELINE.md section 4: 2 - 4)")
+    p.add_argument("--no-kernel-events", action="store_true", help="do not record per-launch HIP events in the extra pass behind the timed region")
+    p.add_argument("--kernel-table", default=None, help="write the per-kernel event timings to this JSON file")
+    p.add_argument("--no-parity", action="store_true", help="skip the golden-vector parity block (the 50-step batch-32 golden of this workload per measured mode)")
     p.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="process-group backend (default: nccl = RCCL on a GPU box; gloo is for the "
                                                                               "launcher's CPU test together with --stub-workload)")
     p.add_argument("--stub-workload", action="store_true",
                    help="launcher / rank-plumbing test: a tiny CPU tensor op per pass instead of the sampler (no GPU, no kernels; the line says so and is no measurement)")
-    return p.parse_args(argv)
+    args = p.parse_args(argv)
+    if args.detail:
+        args.other_configs = args.small_batch = args.job = True
+    if args.modes is None:
+        args.modes = "split3,bf16,exact" if args.detail else "split3,bf16"
+    return args
 
 
 def build_model(cfg, device, seed):
@@ -118,7 +132,9 @@ def family_roofline(name, g, mode, total_ms):
     is_bf16 = "bf16" in name and "bf16x3" not in name
     is_x3 = "bf16x3" in name or "_x3" in name or name in ("gemm_astat", "attn_na2d") or (mode == "split3" and name.startswith("gemm_bf16x3"))
     has_mfma = name.startswith("gemm") or name.startswith("attn")
-    if is_bf16 or is_x3:
+    if name.startswith("gemm_mx8"):
+        mult, peak = 1.0, FP8_MFMA_PEAK_TFLOPS
+    elif is_bf16 or is_x3:
         mult, peak = (3.0 if is_x3 else 1.0), BF16_MFMA_PEAK_TFLOPS
     elif has_mfma and not name.startswith("gemm_skinny"):
         mult, peak = 1.0, FP32_MFMA_PEAK_TFLOPS          # exact fp32-input MFMA kernels
@@ -128,6 +144,7 @@ def family_roofline(name, g, mode, total_ms):
     # time the algorithmic work needs at the roof of each resource (matrix flops priced at the instruction the kernel issues)
     t_hbm, t_mfma = g["bytes"] / (HBM_PEAK_GBS * 1e9), (g["flops"] * mult / (peak * 1e12) if mult else 0.0)
     common = {"kernel": name, "launches": g["launches"], "avg_launch_ms": round(g["ms"] / max(g["launches"], 1), 5),
+              "algorithmic_bytes_per_launch": int(g["bytes"] / max(g["launches"], 1)), "algorithmic_flops_per_launch": int(g["flops"] / max(g["launches"], 1)),
               "share_of_kernel_time": None if name.startswith(SIDE_STREAM) or not total_ms else round(g["ms"] / total_ms, 4),
               "algorithmic_gbs": round(gbs, 1), "algorithmic_tflops": round(tfl_alg, 2)}
     if name.startswith(SIDE_STREAM):
@@ -174,48 +191,65 @@ def pmc_traffic(kernel_family):
     return None
 
 
-def cpu_baseline(cfg, seed, sampler_steps, target_seconds):
+def reference_cpu_figure():
+    """The REFERENCE's own wall time for this workload -- config_oxford_flowers.json, sample_dpmpp_2m x 50, batch 32, fp32 -- recorded while
+    oracle/make_golden_r6.py generated the headline golden from the imported reference in the build container (the reference cannot travel
+    to the GPU box): read from that file's metadata.  None if the file is missing."""
+    from safetensors import safe_open
+    from tests.golden import cases
+    try:
+        with safe_open(os.path.join(cases.GOLDEN_DIR, "samples_r6.safetensors"), "pt") as f:
+            md = f.metadata() or {}
+        return {"value": round(float(md["reference_images_per_s"]), 4), "unit": "images/sec", "cores": int(md["threads"]), "kind": "reference",
+                "seconds": float(md["reference_seconds"]), "torch": md.get("torch"), "cpu": md.get("cpu"),
+                "sample": "k_diffusion (the reference, imported) sample_dpmpp_2m x 50, THIS config, batch 32, fp32, build container "
+                          "(tests/golden/samples_r6.safetensors metadata)"}
+    except Exception:
+        return None
+
+
+def cpu_baseline(cfg, seed, sampler_steps, target_seconds, batch=2):
     """The CPU oracle (a port of the reference's algorithm: oracle/hdit.py + oracle/solvers.py) timed on
     this host's cores for a bounded sample of the same workload (same weights / noise recipe)."""
     from oracle import hdit, solvers
     na2d_recorded, hdit.na2d = hdit.na2d, hdit.na2d_shifted     # same op, one window offset at a time (no 49x gather): ~5x faster on the CPU
     try:
-        return _cpu_baseline(hdit, solvers, cfg, seed, sampler_steps, target_seconds)
+        return _cpu_baseline(hdit, solvers, cfg, seed, sampler_steps, target_seconds, batch)
     finally:
         hdit.na2d = na2d_recorded
 
 
-def _cpu_baseline(hdit, solvers, cfg, seed, sampler_steps, target_seconds):
+CPU_THREAD_CAP = 32
+
+
+def _cpu_baseline(hdit, solvers, cfg, seed, sampler_steps, target_seconds, batch):
     mc = cfg["model"]
-    cores = min(os.cpu_count(), 32)      # torch's intra-op pool stops scaling (and thrashes) far below 256 threads on these op sizes
+    avail = os.cpu_count()
+    cores = min(avail, CPU_THREAD_CAP)   # torch's intra-op pool stops scaling (and thrashes) far below 256 threads on these op sizes
     torch.set_num_threads(cores)
     model = K.config.make_model(cfg)
     sd = K.synth.synth_state_dict(model.state_dict(), seed=seed)
     den = solvers.denoiser(lambda x, s, **kw: hdit.forward(sd, mc, x, s, **kw), mc["sigma_data"])
     shape = (mc["input_channels"], *mc["input_size"])
-    x = K.synth.synth_noise(shape, seed, 0, mc["sigma_max"])[None]
+    x = K.synth.synth_noise_batch(shape, seed, 0, batch, mc["sigma_max"])
     sig = solvers.sigmas_karras(sampler_steps, mc["sigma_min"], mc["sigma_max"])
     t0 = time.perf_counter()
-    den(x, sig[:1])
+    den(x, sig[:1].expand(batch))
     one = time.perf_counter() - t0
     n = max(2, min(sampler_steps, int(target_seconds / max(one, 1e-3))))
     t0 = time.perf_counter()
     with torch.no_grad():
         solvers.sample_dpmpp_2m(den, x, torch.cat([sig[:n], sig[-1:]]))
     dt = time.perf_counter() - t0
-    per_image = dt / n * sampler_steps
-    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 image, {n} of {sampler_steps} DPM++2M steps of THIS workload with the oracle (oracle/hdit.py + solvers.py: the reference's "
-                      f"algorithm in torch CPU fp32, neighbourhood attention as the restated na2d evaluated per window offset; {cores} threads), "
+    per_batch = dt / n * sampler_steps
+    capped = f" of {avail} available (capped: torch's intra-op pool gets slower beyond {CPU_THREAD_CAP} threads at these op sizes)" if avail > cores else ""
+    return {"value": round(batch / per_batch, 5), "unit": "images/sec", "cores": cores, "cores_available": avail, "kind": "port",
+            "sample": f"batch {batch}, {n} of {sampler_steps} DPM++2M steps of THIS workload with the oracle port (torch CPU fp32, {cores} threads{capped}), "
                       f"{dt:.1f} s measured, scaled to {sampler_steps} steps",
-            # the reference itself cannot travel to the GPU box; the number the survey took from it in the build container:
-            "reference_figure": {"value": 0.29, "unit": "images/sec", "cores": 8, "kind": "reference",
-                                 "sample": "k_diffusion (reference) sample_dpmpp_2m, config_oxford_flowers_shifted_window.json, fp32, 8 CPU cores "
-                                           "(BASELINE.md section 3): the port above is 3-4x slower than the reference's own torch modules on a "
-                                           "comparable core count -- GPU/CPU ratios should be taken against THIS figure"}}
+            "reference": reference_cpu_figure()}
 
 
-PARITY_CASE = "smp32_flowers_na_2m5"     # tests/golden/cases.SAMPLE_B32_CASES[0]: this workload's config at this batch, 5 DPM++2M steps
+PARITY_CASE = "smp32_flowers_na_2m50"    # tests/golden/cases.HEADLINE_CASE: THIS workload -- config, sampler, 50 steps, batch 32 -- recorded from the reference
 
 
 def golden_parity(dev, modes, golden_file, case, cfgname, sampler, steps, batch, keep, autocast_file=None):
@@ -229,7 +263,7 @@ def golden_parity(dev, modes, golden_file, case, cfgname, sampler, steps, batch,
     ref16 = None
     if autocast_file and os.path.exists(os.path.join(cases.GOLDEN_DIR, autocast_file)):
         t16 = load_file(os.path.join(cases.GOLDEN_DIR, autocast_file))       # (round-1 autocast file: same case names; later ones: case + "_bf16")
-        ref16 = t16.get(case + "_bf16", t16.get(case) if autocast_file != golden_file else None)
+        ref16 = t16.get(case + "_bf16", t16.get(case) if autocast_file != golden_file else None)      # (absent: the bf16 entry stands alone)
     cfg = K.config.load_config(cases.raw_config(cfgname))
     mc = cfg["model"]
     model = K.config.make_model(cfg).eval().requires_grad_(False)
@@ -246,7 +280,7 @@ def golden_parity(dev, modes, golden_file, case, cfgname, sampler, steps, batch,
             os.environ["KDIFF_GEMM"] = m
             y = getattr(K.sampling, sampler)(den, x, sigmas, extra_args=extra, disable=True)
             y = (y if keep is None else y[keep]).float().cpu()
-            gate = 1e-3 if m != "bf16" else None         # north_star's tolerance applies to the fp32-parity modes
+            gate = 1e-3 if m in ("split3", "exact") else None         # north_star's tolerance applies to the fp32-parity modes
             ent = {"rel_err_vs_reference_golden": round(rel(y, ref), 7), "gate": gate}
             if gate is not None:
                 ent["pass"] = ent["rel_err_vs_reference_golden"] < gate
@@ -263,11 +297,13 @@ def golden_parity(dev, modes, golden_file, case, cfgname, sampler, steps, batch,
 
 
 def parity_vs_reference_golden(dev, modes):
-    """The headline workload's parity case: the reference's fp32 output of a 5-step DPM++2M run of config_oxford_flowers.json at batch 32
-    (samples_r3.safetensors, images cases.B32_KEEP; the bf16 mode also against the reference's autocast run, samples_r4.safetensors)."""
+    """The headline workload's parity case IS the headline workload: the reference's fp32 output of the 50-step DPM++2M run of
+    config_oxford_flowers.json at batch 32 (samples_r6.safetensors, images cases.B32_KEEP, oracle/make_golden_r6.py; the bf16 mode also
+    against the reference's autocast run of the same case where recorded)."""
     from tests.golden import cases
-    case, cfgname, sampler, steps, batch = next(c for c in cases.SAMPLE_B32_CASES if c[0] == PARITY_CASE)
-    return golden_parity(dev, modes, "samples_r3.safetensors", case, cfgname, sampler, steps, batch, cases.B32_KEEP, "samples_r4.safetensors")
+    case, cfgname, sampler, steps, batch = cases.HEADLINE_CASE
+    assert case == PARITY_CASE
+    return golden_parity(dev, modes, "samples_r6.safetensors", case, cfgname, sampler, steps, batch, cases.B32_KEEP, "samples_r6.safetensors")
 
 
 def small_batch_latency(cfg, model, dev, args, measured_modes, batches=(1, 4)):
@@ -313,6 +349,8 @@ def job_rate(args, modes, dev):
     says how much of that the whole job keeps."""
     import contextlib
     import sample as cli
+    quiet = open(os.devnull, "w")                                               # the CLI's own prints and progress bars go nowhere: the driver reads our tails
+    os.environ["TQDM_DISABLE"] = "1"
     cfgpath = os.path.join(REPO, args.config) if not os.path.isabs(args.config) else args.config
     out, saved = {}, os.environ.get("KDIFF_GEMM")
     base = ["--config", cfgpath, "--random-weights", "--seed", str(args.seed), "--batch-size", str(args.batch), "--steps", str(args.sampler_steps),
@@ -321,7 +359,7 @@ def job_rate(args, modes, dev):
         for m in modes:
             os.environ["KDIFF_GEMM"] = m
             ent = {}
-            with contextlib.redirect_stdout(sys.stderr):                          # the CLI's own prints must not join the JSON line on stdout
+            with contextlib.redirect_stdout(quiet), contextlib.redirect_stderr(quiet):
                 # warm-up, like the W passes in front of `value`: the same job once.  The FIRST job of a process in a mode is 3 - 5 % slower than
                 # every later one whichever noise source it uses (first growth of the caching allocator by the 400 MB result + the batches'
                 # workspaces, first plans of the mode): reported as first_job_seconds, not timed as the job rate
@@ -330,7 +368,7 @@ def job_rate(args, modes, dev):
             for noise in ("device", "host"):
                 runs = []
                 for _ in range(args.job_repeats):
-                    with contextlib.redirect_stdout(sys.stderr):
+                    with contextlib.redirect_stdout(quiet), contextlib.redirect_stderr(quiet):
                         cli.main(base + ["-n", str(args.job_images), "--noise", noise])
                     runs.append(dict(cli.LAST_RUN))
                 secs = sorted(r["seconds"] for r in runs)
@@ -354,126 +392,6 @@ CONFIG_OF = {"flowers_na": "configs/config_oxford_flowers.json", "flowers_sw": "
              "mnist": "configs/config_mnist_transformer.json", "cifar": "configs/config_cifar10_transformer.json"}
 
 
-def _smi(*args):
-    import subprocess
-    try:
-        return subprocess.run(["rocm-smi", *args], capture_output=True, text=True, timeout=10).stdout
-    except Exception:
-        return ""
-
-
-def power_limits():
-    """What the board says about its own limits, read once (idle): the power cap the firmware enforces (rocm-smi --showmaxpower), the
-    performance level policy and the clock range of the shader domain.  None-valued keys = the tool did not print that field here."""
-    import re
-    cap = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", _smi("--showmaxpower"))
-    perf = re.search(r"Performance Level: (\S+)", _smi("--showperflevel"))
-    levels = [int(m) for m in re.findall(r"\b\d+: (\d+)Mhz", _smi("--showclkfrq").split("sclk")[-1].split("Supported")[0])] if "sclk" in _smi("--showclkfrq") else []
-    return {"cap_w": float(cap.group(1)) if cap else None, "perf_level": perf.group(1) if perf else None,
-            "sclk_levels_mhz": levels or None}
-
-
-def throttle_accumulators():
-    """The firmware's own throttle accounting (amd-smi metric --violation, MI300 and newer): a free-running accumulation counter and, per
-    limiter, how many of its ticks were spent limited -- package power tracking (PPT), PROCHOT, socket / VR / HBM thermal.  None where the
-    tool or a field is missing."""
-    import subprocess
-    try:
-        txt = subprocess.run(["amd-smi", "metric", "--violation", "--json"], capture_output=True, text=True, timeout=15).stdout
-        data = json.loads(txt)
-    except Exception:
-        return None
-    found = {}
-    def walk(node):
-        if isinstance(node, dict):
-            for k, v in node.items():
-                kl = str(k).lower()
-                if kl in ("accumulation_counter", "ppt_accumulated", "prochot_accumulated", "socket_thermal_accumulated", "vr_thermal_accumulated",
-                          "hbm_thermal_accumulated") and kl not in found:
-                    val = v.get("value") if isinstance(v, dict) else v
-                    if isinstance(val, (int, float)):
-                        found[kl] = int(val)
-                walk(v)
-        elif isinstance(node, list):
-            for v in node:
-                walk(v)
-    walk(data)
-    return found if "accumulation_counter" in found else None
-
-
-def power_and_clock(one_pass, passes=16):
-    """Socket power and shader clock while the path runs: `passes` more untimed passes with rocm-smi sampled from a side thread (the timed
-    region is not touched), next to the board's power cap.  None if rocm-smi is unavailable."""
-    import re
-    import threading
-    limits = power_limits()
-    acc0 = throttle_accumulators()
-    stop, out = threading.Event(), []
-
-    def sample():
-        while not stop.is_set():
-            txt = _smi("--showpower", "--showclocks")
-            if not txt:
-                return
-            p = re.search(r"Socket Graphics Package Power \(W\): ([0-9.]+)", txt)
-            c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
-            if p and c:
-                out.append((float(p.group(1)), int(c.group(1))))
-            time.sleep(0.1)
-    th = threading.Thread(target=sample, daemon=True)
-    th.start()
-    for _ in range(passes):
-        one_pass()
-    torch.cuda.synchronize()
-    stop.set()
-    th.join(timeout=10)
-    acc1 = throttle_accumulators()
-    throttle = None
-    if acc0 and acc1 and acc1["accumulation_counter"] > acc0["accumulation_counter"]:
-        ticks = acc1["accumulation_counter"] - acc0["accumulation_counter"]
-        throttle = {"ticks": ticks, "source": "amd-smi metric --violation, accumulator deltas over the sampled passes (share = ticks spent limited / ticks)"}
-        for k in ("ppt", "prochot", "socket_thermal", "vr_thermal", "hbm_thermal"):
-            if k + "_accumulated" in acc0 and k + "_accumulated" in acc1:
-                throttle[k + "_share"] = round((acc1[k + "_accumulated"] - acc0[k + "_accumulated"]) / ticks, 4)
-    body = out[len(out) // 3:-1] if len(out) > 5 else out          # (the first second still rides the boost after an idle gap: the steady state follows)
-    if not body:
-        return None
-    pw, ck = [p for p, _ in body], [c for _, c in body]
-    mean_w = sum(pw) / len(pw)
-    cap = limits["cap_w"]
-    head = None if cap is None else round(cap - mean_w, 1)
-    if throttle and throttle.get("ppt_share") is not None:
-        other = 100 * max(throttle.get(k + "_share") or 0 for k in ("prochot", "socket_thermal", "vr_thermal", "hbm_thermal"))
-        facts = (f"the firmware's own accounting (amd-smi throttle accumulators over the sampled passes): the package-power limiter (PPT) was throttling on "
-                 f"{100 * throttle['ppt_share']:.0f} % of the ticks, the thermal and PROCHOT limiters on {other:.0f} %, while rocm-smi's averaged socket power read "
-                 f"{mean_w:.0f} W of a {cap if cap is not None else float('nan'):.0f} W cap and the shader clock sat at {round(sum(ck) / len(ck))} of 2400 MHz (no clock locked, "
-                 f"performance level {limits['perf_level']})")
-        if throttle["ppt_share"] >= 0.2:
-            verdict = facts + (": power management is the one active limiter of this path on this box -- it acts on a faster power estimate than the averaged "
-                               "reading, and a controller that holds the part at its limit reports a violation only on the ticks where the estimate exceeds it")
-        elif throttle["ppt_share"] >= 0.05:
-            verdict = facts + (": the power limiter engages intermittently and is the only limiter that reports any activity; boxes of the pool sit at 2 - 30 % PPT "
-                               "ticks and 1.98 - 2.19 GHz under this same path (DESIGN.md section 5 A')")
-        else:
-            verdict = facts + (": NO limiter reports activity worth the name on this box, yet the clock stays below its top level -- what holds it there is not visible "
-                               "in these counters (DESIGN.md section 5 A')")
-    elif head is None:
-        verdict = "no power cap reported by rocm-smi on this box: the clock figure stands alone"
-    elif head <= 100:
-        verdict = (f"average draw within {head:.0f} W of the {cap:.0f} W cap (peaks at or above it) with the shader clock below its top level: "
-                   "the firmware's power management sets the pace of this path on this box")
-    else:
-        verdict = (f"average draw {head:.0f} W under the {cap:.0f} W cap: on THIS box the power cap is not what holds the clock at "
-                   f"{round(sum(ck) / len(ck))} MHz -- see DESIGN.md (power section) for what the samples do and do not show")
-    return {"socket_power_w": round(mean_w, 1), "socket_power_w_min": min(pw), "socket_power_w_max": max(pw),
-            "shader_clock_mhz": round(sum(ck) / len(ck)), "shader_clock_mhz_min": min(ck), "shader_clock_mhz_max": max(ck),
-            "max_shader_clock_mhz": max(limits["sclk_levels_mhz"]) if limits["sclk_levels_mhz"] else 2400, "samples": len(body),
-            "cap_w": cap, "headroom_w": head, "perf_level": limits["perf_level"], "sclk_levels_mhz": limits["sclk_levels_mhz"],
-            "throttle": throttle, "reading": verdict,
-            "note": "rocm-smi sampled every ~0.15 s (a ~1 ms-averaged register, not an energy counter) during extra untimed passes of this mode right "
-                    "after its timed region; cap from rocm-smi --showmaxpower"}
-
-
 MODE_DTYPE = {
     "bf16": ("bf16", "bf16 activations in HBM (residual stream, qkv, attention out, FF hidden), one bf16 MFMA per product, fp32 accumulation, fp32 RMS "
                      "statistics / softmax / GELU / RoPE; fp32 image, solver state and conditioning chain -- the arithmetic of the reference under "
@@ -482,6 +400,9 @@ MODE_DTYPE = {
     "split3": ("f32", "fp32-parity mode: fp32 in HBM, fp32 accumulation everywhere; matrix products as 3 split-bf16 MFMA terms per fp32 product "
                       "(hi*hi + hi*lo + lo*hi, per-product error <= ~2^-15): < 5e-4 from the fp32 reference end to end, inside north_star's 1e-3"),
     "exact": ("f32", "exact fp32-input MFMA (bit-for-bit an fmaf chain)"),
+    "fp8": ("fp8", "the bf16 mode with the AdaRMSNorm -> qkv / -> GEGLU projections of the width-256 / 512 levels as e4m3 x e4m3 products on the block-scaled "
+                   "fp8 matrix instruction (weights: one power-of-two scale per output channel; activations: one per 32-k block), fp32 accumulation: "
+                   "BASELINE configs[4]'s arithmetic, NOT parity-grade"),
 }
 
 
@@ -584,7 +505,7 @@ class Timed:
 
 def mode_entry(mode, dt, steps, warmup, n_img, groups, n_gpus):
     ent = {"value": round(n_img / dt, 3), "unit": "images/sec", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
-           "dtype": MODE_DTYPE[mode][0], "dtype_note": MODE_DTYPE[mode][1], "parity_grade": mode != "bf16"}
+           "dtype": MODE_DTYPE[mode][0], "dtype_note": MODE_DTYPE[mode][1], "parity_grade": mode in ("split3", "exact")}
     fam = None
     if groups:
         ent["roofline"], fam = roofline_of(groups, mode, dt / steps)
@@ -650,6 +571,76 @@ def run_guarded(result, key, fn, mode):
         os.environ["KDIFF_GEMM"] = mode
 
 
+LINE_LIMIT = 3800        # bytes of the one stdout line: the driver reads a 2 000-character tail of the log and an 8 000-character tail of stdout
+
+
+def _cut(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def compact_line(result, detail_file=None):
+    """The driver's line: the contract's keys and the few figures that make the number mean something, every string bounded.  The long form
+    (`result` itself) goes to the detail file.  Never longer than LINE_LIMIT: optional parts are dropped in a fixed order if it ever is."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "mode", "data")
+    line = {k: (_cut(result[k], 120) if isinstance(result[k], str) else result[k]) for k in keep if k in result}
+    cfg = dict(result.get("config") or {})
+    if isinstance(cfg.get("gather"), dict):
+        cfg["gather"] = {k: v for k, v in cfg["gather"].items() if k != "note"}
+    line["config"] = {k: (_cut(v, 160) if isinstance(v, str) else v) for k, v in cfg.items() if v is not None}
+    roof = result.get("roofline") or {}
+    line["roofline"] = {k: roof[k] for k in ("bound", "kernel", "launches", "avg_launch_ms", "achieved", "peak", "unit", "frac", "traffic",
+                                             "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "share_of_kernel_time",
+                                             "mfma_useful_frac", "mfma_executed_frac") if k in roof}
+    line["roofline"].setdefault("traffic", None)
+    gab = {}
+    per_mode = {m: e for m, e in (result.get("modes") or {}).items() if isinstance(e, dict)}
+    per_mode[result.get("mode")] = {"roofline": roof}               # (the headline mode's entry under `modes` only points at the top-level roofline)
+    for m, ent in per_mode.items():
+        g = (ent.get("roofline") or {}).get("global_attention_block") if isinstance(ent.get("roofline"), dict) else None
+        if g:
+            gab[m] = {k: g[k] for k in ("us_per_layer", "launches_per_layer", "frac_of_bf16_mfma_peak", "executed_frac_of_bf16_mfma_peak") if g.get(k) is not None}
+    if gab:
+        line["roofline"]["global_attention_block"] = gab
+    cb = result.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {k: (_cut(cb[k], 220) if isinstance(cb[k], str) else cb[k]) for k in ("value", "unit", "cores", "cores_available", "kind", "sample", "error") if k in cb}
+        if isinstance(cb.get("reference"), dict):
+            line["cpu_baseline"]["reference"] = {k: cb["reference"].get(k) for k in ("value", "unit", "cores", "kind", "seconds")}
+    par = result.get("parity")
+    if isinstance(par, dict):
+        line["parity"] = {k: (_cut(par[k], 160) if isinstance(par[k], str) else par[k]) for k in ("case", "rel_err", "gate", "pass", "error") if k in par}
+        if isinstance(par.get("modes"), dict):
+            line["parity"]["rel_err_by_mode"] = {m: e.get("rel_err_vs_reference_golden") for m, e in par["modes"].items()}
+    if "mode_values" in result:
+        line["mode_values"] = result["mode_values"]
+    if isinstance(result.get("job"), dict) and "value" in result["job"]:
+        line["job"] = {"value": result["job"]["value"], "ratio_to_value": result["job"].get("ratio_to_value")}
+    if detail_file:
+        line["detail_file"] = os.path.basename(detail_file)
+    for drop in (("parity", "case"), ("cpu_baseline", "sample"), ("roofline", "global_attention_block"), ("config", "gather"), ("job",), ("parity",), ("mode_values",)):
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        node = line
+        for k in drop[:-1]:
+            node = node.get(k, {})
+        node.pop(drop[-1], None)
+    return line
+
+
+def emit(result, detail_file):
+    """Long form -> the detail file; the compact line -> stdout, alone and last."""
+    if detail_file:
+        try:
+            with open(detail_file, "w") as f:
+                json.dump(result, f, indent=1)
+        except OSError as e:
+            result = dict(result, detail_file_error=str(e))
+            detail_file = None
+    sys.stderr.flush()
+    print(json.dumps(compact_line(result, detail_file)), flush=True)
+
+
 def launch_ranks(args):
     """``python bench.py --gpus N`` typed plainly (no WORLD_SIZE in the environment): replace this process by the launcher the contract
     names -- ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
@@ -688,12 +679,12 @@ def stub_line(args, ctx):
         dt = t.item()
     ranks_seen = sorted({int(v) for v in out[::B, 0, 0, 0].tolist()})
     if ctx.is_main_process:
-        print(json.dumps({"metric": "STUB (launcher / rank plumbing test, no GPU work)", "value": round(args.gpus * B * args.steps / dt, 3), "unit": "stub items/sec",
-                          "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
-                          "config": {"workload": "stub", "global_batch": B * args.gpus, "nranks": torch.distributed.get_world_size() if args.gpus > 1 else 1,
-                                     "backend": torch.distributed.get_backend() if args.gpus > 1 else None, "ranks_in_gather": ranks_seen,
-                                     "launcher": os.environ.get("KDIFF_BENCH_LAUNCHER", "external")}}), flush=True)
+        emit({"metric": "STUB (launcher / rank plumbing test, no GPU work)", "value": round(args.gpus * B * args.steps / dt, 3), "unit": "stub items/sec",
+              "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
+              "config": {"workload": "stub", "global_batch": B * args.gpus, "nranks": torch.distributed.get_world_size() if args.gpus > 1 else 1,
+                         "backend": torch.distributed.get_backend() if args.gpus > 1 else None, "ranks_in_gather": ranks_seen,
+                         "launcher": os.environ.get("KDIFF_BENCH_LAUNCHER", "external")}}, None)
     ctx.wait_for_everyone()
     ctx.shutdown()
 
@@ -730,7 +721,8 @@ def main():
         extra["class_cond"] = (torch.arange(lo, lo + B) % cfg["dataset"]["num_classes"]).to(dev)
     sigmas = K.sampling.get_sigmas_karras(args.sampler_steps, mc["sigma_min"], mc["sigma_max"], rho=7., device=dev)
     sampler = getattr(K.sampling, args.sampler)
-    gather_events = []
+    gather_events, last_gathered = [], [None]
+    post = K.ops.to_uint8 if args.gather == "uint8" else (lambda t: t)
 
     def one_pass():
         imgs = sampler(den, x0, sigmas, extra_args=extra, disable=True)
@@ -738,10 +730,11 @@ def main():
             return imgs
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = ctx.gather(imgs)                       # the path's one exchange step: RCCL all-gather over xGMI (evaluation.py:87)
+        gathered = ctx.gather(post(imgs))            # the path's one exchange step: RCCL all-gather over xGMI (evaluation.py:87), as sample.py does it
         e1.record()
         gather_events.append((e0, e1))
-        return out
+        last_gathered[0] = gathered
+        return imgs
 
     def compute_only():
         return sampler(den, x0, sigmas, extra_args=extra, disable=True)
@@ -749,6 +742,9 @@ def main():
     timed = Timed(ctx, args.steps, args.warmup, not args.no_kernel_events)
     dt, out, groups = timed.run(one_pass, compute_only)
     gather_ms = sum(a.elapsed_time(b) for a, b in gather_events[-args.steps:]) / args.steps if gather_events else 0.0
+    if gather_events:
+        g = last_gathered[0]
+        assert g.shape[0] == args.gpus * B and (g.dtype == torch.uint8) == (args.gather == "uint8")
 
     if ctx.is_main_process:
         n_img = args.gpus * B * args.steps
@@ -762,11 +758,12 @@ def main():
                 json.dump({"mode": args.mode, "families": fam, "kernels": groups, "timed_seconds": dt}, f, indent=1)
         mac = K.models.flops.forward_cost_mac(mc)["total"]
         nfe = args.sampler_steps if args.sampler == "sample_dpmpp_2m" else None
+        px = B * shape[0] * shape[1] * shape[2]
         result = {
             "metric": "images/sec, 256x256 image_transformer_v2, 50-step DPM++2M (whole job)",
             "value": head["value"], "unit": "images/sec", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": MODE_DTYPE[args.mode][0], "mode": args.mode, "dtype_note": MODE_DTYPE[args.mode][1], "parity_grade": args.mode != "bf16",
+            "dtype": MODE_DTYPE[args.mode][0], "mode": args.mode, "dtype_note": MODE_DTYPE[args.mode][1], "parity_grade": args.mode in ("split3", "exact"),
             "data": "synthetic (seeded noise, random-init weights incl. re-randomised zero-init projections)",
             "per_gpu": round(n_img / dt / args.gpus, 3),
             "config": {"workload": f"{os.path.basename(args.config)} {mc['input_size'][0]}x{mc['input_size'][1]}, {args.sampler} "
@@ -774,10 +771,10 @@ def main():
                        "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus} (independent images, one final all-gather)",
                        "rccl_nranks": torch.distributed.get_world_size() if args.gpus > 1 else 1,
                        "launcher": os.environ.get("KDIFF_BENCH_LAUNCHER", "external") if args.gpus > 1 else None,
-                       "gather": {"ms_per_step": round(gather_ms, 3), "bytes_per_rank": int(out[:B].numel() * out.element_size()),
-                                  "dtype": str(out.dtype).replace("torch.", ""),
-                                  "note": "all_gather_into_tensor of the finished fp32 images, timed by HIP events on the compute stream "
-                                          "(sample.py gathers uint8 when it writes PNGs: 4x fewer bytes)"}},
+                       "gather": {"ms_per_step": round(gather_ms, 3), "dtype": args.gather, "bytes_per_rank": px * (1 if args.gather == "uint8" else 4),
+                                  "bytes_per_rank_uint8": px, "bytes_per_rank_fp32": 4 * px,
+                                  "note": "all_gather_into_tensor of the finished images as sample.py gathers them (uint8 conversion on the GPU first; "
+                                          "--gather fp32 = the reference's fp32 gather), HIP events on the compute stream"}},
             "algorithmic_tflops": round(n_img * 2 * mac * (nfe or 0) / dt / 1e12, 2) if nfe else None,
             "roofline": head.get("roofline", {"bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}),
         }
@@ -828,7 +825,9 @@ def main():
                 # image), fp8-stored weights where the arithmetic can hold them exactly (bf16 mode); the fp32-parity mode runs fp32 weights
                 "configs[4] neighbourhood, dpmpp_sde + Brownian tree": {
                     "split3": other_config("sde", na, dev, args, "sample_dpmpp_sde", "split3", brownian=True),
-                    "bf16+fp8w": other_config("sde", na, dev, args, "sample_dpmpp_sde", "bf16", fp8=True, brownian=True)},
+                    "bf16+fp8w": other_config("sde", na, dev, args, "sample_dpmpp_sde", "bf16", fp8=True, brownian=True),
+                    # round 6: the fp8 ARITHMETIC mode on the same fp8-stored weights (kd_gemm_mx8: e4m3 x e4m3 on the block-scaled matrix instruction)
+                    "fp8": other_config("sde", na, dev, args, "sample_dpmpp_sde", "fp8", fp8=True, brownian=True)},
             }
 
         good_modes = [m for m, e in result.get("modes", {}).items() if "value" in e]
@@ -850,26 +849,31 @@ def main():
                 for e in ent.values():
                     if isinstance(e, dict):
                         e["ratio_to_value"] = round(e["value"] / ref_value, 4)
-            job["value"] = job["modes"][args.mode]["device"]["value"]          # the CLI's default noise source
-            job["ratio_to_value"] = job["modes"][args.mode]["device"]["ratio_to_value"]
+            job["value"] = job["modes"][args.mode]["host"]["value"]            # the CLI's default noise source
+            job["ratio_to_value"] = job["modes"][args.mode]["host"]["ratio_to_value"]
             return job
 
-        if args.gpus == 1 and not args.no_other_configs and os.path.basename(args.config) == "config_oxford_flowers.json":
-            guarded("other_configs", block_other_configs)
-        if args.gpus == 1 and not args.no_power:
-            guarded("power", lambda: power_and_clock(compute_only))
-        if args.gpus == 1 and not args.no_parity:
+        def block_power():
+            sys.path.insert(0, os.path.join(REPO, "benchmarks"))
+            import power_report
+            return power_report.power_and_clock(compute_only)
+
+        headline_cfg = os.path.basename(args.config) == "config_oxford_flowers.json"
+        if args.gpus == 1 and not args.no_parity and headline_cfg and args.sampler == "sample_dpmpp_2m" and args.sampler_steps == 50 and B == 32:
             guarded("parity", block_parity)
-        if args.gpus == 1 and not args.no_small_batch:
-            guarded("small_batch", lambda: small_batch_latency(cfg, model, dev, args, measured_modes=[args.mode] + [m for m in good_modes if m != args.mode and m != "exact"]))
-        if args.gpus == 1 and not args.no_job:
-            guarded("job", block_job)
         if "modes" in result:
-            # short copy of the per-mode throughputs (the full entries carry their rooflines: a truncated log tail may cut them off)
             result["mode_values"] = {m: e.get("value") for m, e in result["modes"].items()}
         if not args.no_cpu_baseline and args.gpus == 1:
-            guarded("cpu_baseline", lambda: cpu_baseline(cfg, args.seed, args.sampler_steps, args.cpu_seconds))
-        print(json.dumps(result), flush=True)
+            guarded("cpu_baseline", lambda: cpu_baseline(cfg, args.seed, args.sampler_steps, args.cpu_seconds, args.cpu_batch))
+        if args.gpus == 1 and args.other_configs and headline_cfg:
+            guarded("other_configs", block_other_configs)
+        if args.gpus == 1 and args.small_batch:
+            guarded("small_batch", lambda: small_batch_latency(cfg, model, dev, args, measured_modes=[args.mode] + [m for m in good_modes if m != args.mode and m != "exact"]))
+        if args.gpus == 1 and args.job:
+            guarded("job", block_job)
+        if args.gpus == 1 and args.power:
+            guarded("power", block_power)
+        emit(result, args.detail_file)
     ctx.wait_for_everyone()
     ctx.shutdown()
 

@@ -267,13 +267,10 @@ int kd_attn_na2d_bf16(const void* qkv, void* out, int batch, int H, int W, int n
  * KD_PREC_BF16), except that C receives the ATTENTION OUTPUT [M, n_heads * 64] bf16: q, k, v never reach HBM.  One workgroup per (sample,
  * head).  Shapes: 256 tokens per sample, K = 64 * n_heads in {256, 512}, N = 3 K, M % 256 == 0 (kd_attn_block_bf16_supported tells);
  * anything else returns KD_EINVAL and the caller issues kd_gemm_bf16 + kd_attn_global_bf16, whose results this entry reproduces bit for bit.
- * `out_proj` (may be NULL): the descriptor of the block's out projection + residual (:393-396; epi = KD_EPI_RESIDUAL, A = the attention
- * output = d->C, C = R = the residual stream = d->A, N = K = d->K) -- then that projection runs in the same launch: the n_heads workgroups of a
- * sample meet once their attention columns are stored, and workgroup (sample, h) computes the output columns 64 h .. of x += att W_out^T in
- * place (bit-identical to kd_gemm_bf16 on that descriptor).  `sync`: 2 * batch + 1 ints of device memory owned by the caller, zeroed once
- * (the kernel leaves the counters zero; entry [2 * batch] is set if a rendezvous timed out -- it never should). */
+ * (Round 5 also offered the block's out projection in the same launch behind a cross-workgroup rendezvous; it measured level with the separate
+ * launch and was removed in round 6 -- a spin-wait between workgroups has no place in a library that must never hang or corrupt silently.) */
 int kd_attn_block_bf16_supported(int tokens_per_sample, int width, int n_heads);
-int kd_attn_block_bf16(const KdGemm* d, const KdGemm* out_proj, int* sync, void* stream);
+int kd_attn_block_bf16(const KdGemm* d, void* stream);
 
 /* AdaRMSNorm -> wide projection in the same form (round 5): the FF block's norm -> up projection + GEGLU (image_transformer_v2.py:487-491) and,
  * for the levels whose attention core is a launch of its own, norm -> qkv projection + cosine-sim scale + RoPE (:370-380, :415-425).  A workgroup
@@ -283,6 +280,22 @@ int kd_attn_block_bf16(const KdGemm* d, const KdGemm* out_proj, int* sync, void*
  * d_ff % 192 == 0 (kd_proj_block_bf16_supported tells); else KD_EINVAL. */
 int kd_proj_block_bf16_supported(int tokens_per_sample, int width, int n, int epi);
 int kd_proj_block_bf16(const KdGemm* d, void* stream);
+
+/* fp8 arithmetic mode (round 6; BASELINE configs[4] "fp8 MFMA weights" -- no reference counterpart: convert_for_inference.py:23 stops at
+ * fp16 / bf16): the AdaRMSNorm -> wide projections of the K = 256 / 512 levels (image_transformer_v2.py:370-380 / :415-425 norm -> qkv_proj +
+ * cosine-sim scale + RoPE; :487-491 norm -> up_proj + GEGLU; norm -> plain store) on the block-scaled fp8 matrix instruction
+ * (v_mfma_scale_f32_32x32x64_f8f6f4, 2x the bf16 MFMA rate).  Weights: OCP e4m3 with ONE power-of-two scale per output channel
+ * (checkpoint.quantize_fp8's rule: an fp8 checkpoint enters bit for bit; any other fp32 weight is rounded by kd_pack_weight_mx8).
+ * Activations: x (bf16) * AdaRMSNorm scale (fp32) quantised per (row, 32-k block) to e4m3 with a power-of-two block scale 2^ceil(log2(amax / 448))
+ * (OCP microscaling: one E8M0 byte per block, no saturation); fp32 accumulation; the RMS row factor (fp32 statistics of the unquantised row)
+ * and the epilogues as in kd_gemm_bf16.  `d` is the projection's descriptor as kd_gemm_bf16 takes it (bf16 A / C, norm = 1, epi = KD_EPI_STORE /
+ * KD_EPI_QKV / KD_EPI_GEGLU, precision = KD_PREC_BF16, rows_per_sample set) except that Wp points at the kd_pack_weight_mx8 image.
+ * Shapes: K in {256, 512}, N a multiple of 128 (GEGLU: d_ff a multiple of 64), M >= 128 (kd_gemm_mx8_supported tells); else KD_EINVAL.
+ * The arithmetic is restated in oracle/hdit.py (mx8_quantize_rows / mx8_quantize_weight). */
+long long kd_packed_weight_bytes_mx8(int N, int K, int geglu);
+int kd_pack_weight_mx8(const float* W, void* out, int N, int K, int geglu, void* stream);
+int kd_gemm_mx8_supported(int M, int N, int K, int epi, int norm);
+int kd_gemm_mx8(const KdGemm* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Solver step arithmetic (k_diffusion/sampling.py), one fused elementwise launch per step with
@@ -384,11 +397,11 @@ int kd_prof_clock_buffer(void* dev_ptr);
  *   KD_OP_ATTN_WINDOW_F32 : p as above; i = batch, H, W, nh, ws, shift, prep, precision        KD_OP_ATTN_NA2D_F32 : i = batch, H, W, nh, ks, prep, precision
  *   KD_OP_ATTN_GLOBAL_BF16 : p = qkv, out; i = batch, T, nh      KD_OP_ATTN_WINDOW_BF16 : i = batch, H, W, nh, ws, shift      KD_OP_ATTN_NA2D_BF16 : i = batch, H, W, nh, ks
  *   KD_OP_NORM_SPLIT_F32 : p = x, scale, hi, lo; i = scale_stride, rows_per_sample, M, K; f = eps
- *   KD_OP_ATTN_BLOCK_BF16 : p = const KdGemm* (qkv), const KdGemm* (out projection or NULL), sync      KD_OP_PROJ_BLOCK_BF16 : p[0] = const KdGemm* */
+ *   KD_OP_ATTN_BLOCK_BF16 / KD_OP_PROJ_BLOCK_BF16 / KD_OP_GEMM_MX8 : p[0] = const KdGemm* */
 enum { KD_OP_GEMM_F32 = 0, KD_OP_GEMM_BF16 = 1, KD_OP_FFN_F32 = 2, KD_OP_FFN_BF16 = 3,
        KD_OP_ATTN_GLOBAL_F32 = 4, KD_OP_ATTN_WINDOW_F32 = 5, KD_OP_ATTN_NA2D_F32 = 6,
        KD_OP_ATTN_GLOBAL_BF16 = 7, KD_OP_ATTN_WINDOW_BF16 = 8, KD_OP_ATTN_NA2D_BF16 = 9, KD_OP_NORM_SPLIT_F32 = 10,
-       KD_OP_ATTN_BLOCK_BF16 = 11, KD_OP_PROJ_BLOCK_BF16 = 12 };
+       KD_OP_ATTN_BLOCK_BF16 = 11, KD_OP_PROJ_BLOCK_BF16 = 12, KD_OP_GEMM_MX8 = 13 };
 typedef struct {
   int op;             /* KD_OP_* */
   float f;

@@ -13,7 +13,10 @@ LIB_PATH = os.environ.get("KDIFF_HIP_LIB") or os.path.join(_HERE, "csrc", "libkd
 A_PLAIN, A_MERGE2x2, A_PATCH_NCHW = 0, 1, 2
 EPI_STORE, EPI_RESIDUAL, EPI_GEGLU, EPI_SPLIT_LERP, EPI_UNPATCH_NCHW, EPI_QKV = 0, 1, 2, 3, 4, 5
 PREC_EXACT, PREC_SPLIT3, PREC_BF16 = 0, 1, 2
-_MODES = {"exact": PREC_EXACT, "split3": PREC_SPLIT3, "bf16": PREC_BF16}
+# PREC_FP8 is a mode of the NETWORK, not a KdGemm.precision value: the bf16 mode with the AdaRMSNorm -> wide projections of the K = 256 / 512
+# levels on the block-scaled fp8 matrix instruction (kd_gemm_mx8); every descriptor of such a plan says KD_PREC_BF16
+PREC_FP8 = 3
+_MODES = {"exact": PREC_EXACT, "split3": PREC_SPLIT3, "bf16": PREC_BF16, "fp8": PREC_FP8}
 
 
 def default_precision():
@@ -22,11 +25,19 @@ def default_precision():
     split3  (default) every fp32 operand split into two bf16, 3 bf16 MFMAs per product, fp32 accumulate (fp32 activations):
             the fp32-parity mode, inside the 1e-3 tolerance of the reference's fp32 path;
     bf16    bf16 activations in HBM, one bf16 MFMA per product, fp32 accumulate / statistics / softmax: the arithmetic of the
-            reference under torch.autocast(bfloat16)."""
+            reference under torch.autocast(bfloat16);
+    fp8     the bf16 mode with the norm -> qkv / norm -> GEGLU projections of the K = 256 / 512 levels as e4m3 x e4m3 products with
+            power-of-two block scales (weights per output channel, activations per 32-k block) on the fp8 matrix instruction."""
     mode = os.environ.get("KDIFF_GEMM", "split3").lower()
     if mode not in _MODES:
         raise ValueError(f"KDIFF_GEMM={mode!r}: expected one of {sorted(_MODES)}")
     return _MODES[mode]
+
+
+def kernel_precision():
+    """KdGemm.precision of the default mode: the fp8 mode's descriptors are bf16 descriptors (see PREC_FP8)."""
+    p = default_precision()
+    return PREC_BF16 if p == PREC_FP8 else p
 
 
 def precision_name(p):
@@ -88,9 +99,13 @@ SIGNATURES = {
     "kd_attn_window_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "kd_attn_na2d_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "kd_attn_block_bf16_supported": [_i, _i, _i],
-    "kd_attn_block_bf16": [C.POINTER(KdGemm), C.POINTER(KdGemm), _vp, _vp],
+    "kd_attn_block_bf16": [C.POINTER(KdGemm), _vp],
     "kd_proj_block_bf16_supported": [_i, _i, _i, _i],
     "kd_proj_block_bf16": [C.POINTER(KdGemm), _vp],
+    "kd_packed_weight_bytes_mx8": [_i, _i, _i],
+    "kd_pack_weight_mx8": [_vp, _vp, _i, _i, _i, _vp],
+    "kd_gemm_mx8_supported": [_i, _i, _i, _i, _i],
+    "kd_gemm_mx8": [C.POINTER(KdGemm), _vp],
     "kd_packed_weight_bytes": [_i, _i, _i],
     "kd_pack_weight_bf16x3": [_vp, _vp, _i, _i, _i, _vp],
     "kd_rmsnorm_f32": [_vp, _vp, _vp, _i, _i, _f, _vp],
@@ -127,7 +142,7 @@ SIGNATURES = {
 # entry points a kd_run_list entry can name (include/kdiff_hip.h: KD_OP_*)
 RUN_LIST_OPS = {"kd_gemm_f32": 0, "kd_gemm_bf16": 1, "kd_ffn_f32": 2, "kd_ffn_bf16": 3, "kd_attn_global_f32": 4, "kd_attn_window_f32": 5,
                 "kd_attn_na2d_f32": 6, "kd_attn_global_bf16": 7, "kd_attn_window_bf16": 8, "kd_attn_na2d_bf16": 9, "kd_norm_split_f32": 10,
-                "kd_attn_block_bf16": 11, "kd_proj_block_bf16": 12}
+                "kd_attn_block_bf16": 11, "kd_proj_block_bf16": 12, "kd_gemm_mx8": 13}
 
 
 def encode_call(call, name, args):
@@ -192,11 +207,10 @@ def lib():
     return _lib
 
 
-# The library reads no environment variables; the package's documented A/B switches are mapped onto kd_set_option here
-# (re-read whenever they change, so that tests can flip them inside one process).
-_ENV_OPTIONS = {"KDIFF_SKINNY": ("skinny", 1), "KDIFF_ASTAT": ("astat", 1), "KDIFF_KSPLIT": ("ksplit", 1), "KDIFF_ASTAT_MAXK": ("astat_max_k", 512),
-                "KDIFF_ASTAT_WAVES": ("astat_waves", 4), "KDIFF_ASTAT_STOREWAIT": ("astat_storewait", 0), "KD_GEMM_DEBUG": ("gemm_debug", 0),
-                "KDIFF_BF16_FAST": ("bf16_fast", 1)}
+# The library reads no environment variables; KDIFF_OPTIONS="name=value,..." is mapped onto kd_set_option here (re-read whenever it changes,
+# so that tests can flip options inside one process).  (Rounds 2 - 5 also mapped eight per-option variables -- KDIFF_SKINNY, KDIFF_ASTAT_WAVES,
+# ... -- onto the same calls; every one of them is reachable through KDIFF_OPTIONS by its library name and they were removed in round 6.)
+_ENV_OPTIONS = {}
 _env_applied = None       # (value of every mapped variable, {name: value} parsed from KDIFF_OPTIONS) as last applied
 _programmatic = set()     # option names set through set_option(): the environment sync leaves them alone
 option_epoch = 0          # bumped whenever a library option may have changed: captured launch graphs are bound to one epoch

@@ -284,8 +284,7 @@ __global__ __launch_bounds__(256, NaGeo<KS>::LDS <= 80 * 1024 ? 2 : 1) void attn
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4*>(op + e * 32 + 8 * g + 4 * h2) =
-            f32x4{O[e][4 * g], O[e][4 * g + 1], O[e][4 * g + 2], O[e][4 * g + 3]} * inv;
+        st16(op + e * 32 + 8 * g + 4 * h2, f32x4(f32x4{O[e][4 * g], O[e][4 * g + 1], O[e][4 * g + 2], O[e][4 * g + 3]} * inv));
   }
   x3::wg_stamp_end(wgs);
 }
@@ -461,8 +460,7 @@ __global__ __launch_bounds__(256, 1) void attn_na2d_x3_wide_kernel(const NArgs a
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4*>(op + e * 32 + 8 * g + 4 * h2) =
-            f32x4{O[e][4 * g], O[e][4 * g + 1], O[e][4 * g + 2], O[e][4 * g + 3]} * inv;
+        st16(op + e * 32 + 8 * g + 4 * h2, f32x4(f32x4{O[e][4 * g], O[e][4 * g + 1], O[e][4 * g + 2], O[e][4 * g + 3]} * inv));
   }
 }
 
@@ -618,8 +616,7 @@ __global__ __launch_bounds__((NT < 4 ? NT : 4) * 64, 2) void attn_global_x3_kern
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4*>(op + e * 32 + 8 * g + 4 * h2) =
-            f32x4{O[e][4 * g], O[e][4 * g + 1], O[e][4 * g + 2], O[e][4 * g + 3]} * inv;
+        st16(op + e * 32 + 8 * g + 4 * h2, f32x4(f32x4{O[e][4 * g], O[e][4 * g + 1], O[e][4 * g + 2], O[e][4 * g + 3]} * inv));
   }
   x3::wg_stamp_end(wgs);
 }

@@ -73,7 +73,7 @@ __device__ __forceinline__ void store_block_bf16(u16* crow, const float (&v)[16]
     half_swap(p[gp][0], p[gp + 1][0]);
     half_swap(p[gp][1], p[gp + 1][1]);
     // lanes 0-31: features 8gp .. 8gp+7; lanes 32-63: features 8(gp+1) .. +7
-    if (ok && 8 * (gp + lh) < nvalid) *reinterpret_cast<u32x4*>(crow + 8 * (gp + lh)) = u32x4{p[gp][0], p[gp][1], p[gp + 1][0], p[gp + 1][1]};
+    if (ok && 8 * (gp + lh) < nvalid) st16(crow + 8 * (gp + lh), u32x4{p[gp][0], p[gp][1], p[gp + 1][0], p[gp + 1][1]});
   }
 }
 

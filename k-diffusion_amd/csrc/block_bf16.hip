@@ -33,7 +33,6 @@ struct BArgs {
   const float* qk_scale; const float* pos; const float* freq;
   int warm;
   unsigned long long* clk;            // kd_prof_clock_buffer (TS instantiation only): workgroup 0's time line, s_memtime stamps
-  const char* Wp_out; u16* xio; int* sync;      // OUTP: packed out-projection weight, the residual stream (= x, updated in place), per-sample counters
 };
 extern unsigned long long* g_clk;     // gemm_bf16.hip
 
@@ -64,29 +63,6 @@ __device__ __forceinline__ void row_to_image(char* img, int rowi, const f32x16& 
       *reinterpret_cast<u32x4*>(img + rowi * 128 + ((c ^ asw(rowi)) << 4)) = u32x4{pk[gp][0], pk[gp][1], pk[gp + 1][0], pk[gp + 1][1]};
     }
   }
-}
-
-// Rendezvous of the n workgroups that share a sample (OUTP): one thread per workgroup arrives and waits until all n have.  They are resident
-// together -- ids 8 apart inside one group of 8 n consecutive ids, one workgroup per CU, dispatched in id order -- so nobody waits for a
-// workgroup that cannot start; a bounded wait (~1 s) guards the assumption: on expiry the flag behind the counters is set and the workgroup goes
-// on (wrong numbers, reported by the host wrapper's check, no hang).
-// Memory order.  With the XCD-aware placement (batch % 8 == 0) the n workgroups sit on ONE XCD and exchange through its L2: a store is
-// acknowledged by the L2 (vmcnt), atomics execute there, and the readers fetch the attention rows with sc1 loads that do not stop in their
-// CU's vector cache -- no cache maintenance at all (`same_l2`).  An agent-scope release / acquire pair instead writes back and invalidates the
-// WHOLE L2 (buffer_wbl2 / buffer_inv sc1): measured 15 k clocks per rendezvous and an out-projection pass that then missed on every line; it is
-// kept for the plain placement only, where the workgroups of a sample are spread over the XCDs.
-__device__ __forceinline__ void sample_rendezvous(int* arrive, int target, int* flag, bool same_l2) {
-  if (!same_l2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int spins = 0;
-  while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    __builtin_amdgcn_s_sleep(2);
-    if (++spins > (1 << 23)) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-  }
-  if (!same_l2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-__device__ __forceinline__ void glds16_sc1(const void* src, void* dst) {       // sc1: served by the L2, not by this CU's vector cache
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 16);
 }
 
 // TS: in-kernel time line of workgroup 0 (kd_prof_clock_buffer; a template flag so that the measured kernel's loops stay what they are):
@@ -164,13 +140,7 @@ _Pragma("unroll") \
     rs = rsqrtf(ssq / (float)K + (EPS)); \
   }
 
-// OUTP: the block's out projection + residual in the same launch (image_transformer_v2.py:393-396).  The attention output of a sample is
-// complete when its n_heads workgroups have stored their 64 columns; after a rendezvous of those workgroups (same XCD: the exchange stays in
-// one L2) workgroup (sample, h) takes the sample's 256 attention rows as B fragments (LDS-DMA, no arithmetic) and runs ONE more pass: the 64
-// rows 64 h .. of W_out, i.e. the output columns 64 h .. of the new residual stream, x[:, 64 h ..] += att W_out^T -- written in place (every
-// workgroup of the sample finished reading x before it arrived; column slices are disjoint).  Same products in the same order as the tiled
-// projection kernel it replaces: bit-identical.
-template <int NC /* K / 16 */, bool OUTP = false, bool TS = false>
+template <int NC /* K / 16 */, bool TS = false>
 __global__ __launch_bounds__(512, 1) void attn_block_bf16_kernel(const BArgs p) {
   constexpr int K = NC * 16, NK = NC / 4, SPP = NK / 2, NSTAGE = 3 * SPP, NSLOT = 4, PDIST = 3, T = 256, NT = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -326,99 +296,6 @@ __global__ __launch_bounds__(512, 1) void attn_block_bf16_kernel(const BArgs p) 
 #pragma unroll
     for (int u = 0; u < 2; ++u) pv_step(O, Vimg + (32 * t + 16 * u) * 128, va, p_frag(S[t], u));
   store_o(p.out + row * (size_t)(p.nh * DH) + head * DH, O, 1.0f / l, lh, true);
-  if (OUTP) {
-    if (probe) p.clk[10] = __builtin_amdgcn_s_memtime();
-    // the residual operand: this lane's row, columns 64 head .. + 63 of the OLD x (nobody writes them but this workgroup, below)
-    u16* xrow = p.xio + row * (size_t)K + head * DH;
-    u32x4 rraw[2][2];
-    load_block_raw(xrow, rraw[0], lh);
-    load_block_raw(xrow + 32, rraw[1], lh);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's attention rows are out (and the residual pieces in)
-    KD_BARRIER();
-    if (tid == 0) {
-      sample_rendezvous(p.sync + 2 * b, p.nh, p.sync + 2 * p.batch, (p.batch & 7) == 0);
-      // everybody of this sample is past its wait once all have departed: the last one clears the counters for the next launch
-      if (__hip_atomic_fetch_add(p.sync + 2 * b + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.nh - 1) {
-        __hip_atomic_store(p.sync + 2 * b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(p.sync + 2 * b + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    KD_BARRIER();
-    if (probe) p.clk[11] = __builtin_amdgcn_s_memtime();
-    bf16x8 a2[NC];                                    // (its own array: the live range of the projection fragments ends with the q pass)
-    // ---- the sample's attention rows -> B fragments (the staging of the prologue, no arithmetic) --------------------------------------------
-    {
-      constexpr int RPR = WBLK / (2 * K), NR = 32 / RPR, CPR = K / 8;
-      char* stage = smem + wid * WBLK;
-      int lane_o = lane, l31_o = l31, lh_o = lh;      // opaque copies: the source offsets and read addresses below are those of the prologue, and
-      asm volatile("" : "+v"(lane_o), "+v"(l31_o), "+v"(lh_o));   // CSE kept all of them alive (in scratch) across the whole kernel instead of recomputing them
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int rr = (i * 64 + lane_o) / CPR, qs = (i * 64 + lane_o) % CPR;
-          const size_t grow = (size_t)b * T + wid * 32 + r * RPR + rr;
-          glds16_sc1(reinterpret_cast<const char*>(p.out + grow * K) + ((qs ^ (rr & 15)) << 4), stage + i * 1024);
-        }
-        KD_WAIT_VM(0);
-        if (NR == 1 || (l31_o / RPR) == r) {
-          const int rr = l31_o % RPR;
-          const char* rowp = stage + rr * (2 * K);
-#pragma unroll
-          for (int c = 0; c < NC; ++c) a2[c] = *reinterpret_cast<const bf16x8*>(rowp + (((2 * c + lh_o) ^ (rr & 15)) << 4));
-          // a real branch (exec mask), not 128 selects between the old and the new fragments: an if-converted form needs both sets live
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-    }
-    KD_BARRIER();                                      // the staging slots become the ring again
-    const char* wo = p.Wp_out + ((size_t)(head >> 1) * NK) * WBLK + (head & 1) * 8192 + wid * 1024 + lane * 16;
-    auto issue_o = [&](int s) {
-      char* dst = smem + (s % NSLOT) * WBLK + wid * 1024;
-      glds16(wo + (size_t)(2 * s) * WBLK, dst);
-      glds16(wo + (size_t)(2 * s + 1) * WBLK, dst + 8192);
-    };
-    constexpr int PD2 = SPP < PDIST ? SPP : PDIST;
-#pragma unroll
-    for (int s = 0; s < PD2; ++s) issue_o(s);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < SPP; ++s) {
-      wait_vm_n(2 * min(PD2 - 1, SPP - 1 - s));
-      KD_BARRIER();
-      if (s + PD2 < SPP) issue_o(s + PD2);
-      const char* st = smem + (s % NSLOT) * WBLK;
-      bf16x8 wf[2][2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) wf[0][j] = *reinterpret_cast<const bf16x8*>(st + j * 32 * 128 + off4[0]);
-#pragma unroll
-      for (int c8 = 0; c8 < 8; ++c8) {
-        if (c8 + 1 < 8) {
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            wf[(c8 + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(st + ((c8 + 1) >> 2) * 8192 + j * 32 * 128 + off4[(c8 + 1) & 3]);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c8 & 1][j], a2[4 * (2 * s + (c8 >> 2)) + (c8 & 3)], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      float v[16], rr_[16];
-      block_from_raw(rraw[e], rr_);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = acc[e][r] + rr_[r];
-      store_block_bf16(xrow + 32 * e, v, lh, true);
-    }
-  }
   if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
   if (TS && wg_slot) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); wg_slot[1] = __builtin_amdgcn_s_memrealtime(); }
 }
@@ -588,7 +465,7 @@ extern "C" int kd_attn_block_bf16_supported(int tokens_per_sample, int width, in
   return tokens_per_sample == 256 && (width == 256 || width == 512) && n_heads * 64 == width && option("attn_block_bf16", 1) ? 1 : 0;
 }
 
-extern "C" int kd_attn_block_bf16(const KdGemm* dp, const KdGemm* op, int* sync, void* stream) {
+extern "C" int kd_attn_block_bf16(const KdGemm* dp, void* stream) {
   if (!dp) return fail(KD_EINVAL, "kd_attn_block_bf16: null descriptor");
   const KdGemm& d = *dp;
   if (!d.A || !d.Wp || !d.C || !d.scale || !d.qk_scale || !d.rope_pos || !d.rope_freq) return fail(KD_EINVAL, "kd_attn_block_bf16: null operand");
@@ -597,28 +474,18 @@ extern "C" int kd_attn_block_bf16(const KdGemm* dp, const KdGemm* op, int* sync,
   if (!kd_attn_block_bf16_supported(d.rows_per_sample, d.K, d.n_heads) || d.N != 3 * d.K || d.M <= 0 || d.M % 256)
     return fail(KD_EINVAL, "kd_attn_block_bf16: shape M=%d N=%d K=%d, %d tokens per sample, %d heads is not taken (256 tokens per sample, "
                 "K = 64 heads in {256, 512})", d.M, d.N, d.K, d.rows_per_sample, d.n_heads);
-  if (op) {
-    const KdGemm& o = *op;
-    if (o.epi != KD_EPI_RESIDUAL || o.norm || o.a_mode != KD_A_PLAIN || o.precision != KD_PREC_BF16 || !o.Wp || o.M != d.M || o.N != d.K || o.K != d.K)
-      return fail(KD_EINVAL, "kd_attn_block_bf16: the second descriptor must be the block's bf16 out projection + residual (M=%d, N=K=%d)", d.M, d.K);
-    if (o.A != d.C || o.C != d.A || o.R != d.A)
-      return fail(KD_EINVAL, "kd_attn_block_bf16: the out projection must read the attention output and update the residual stream in place");
-    if (!sync) return fail(KD_EINVAL, "kd_attn_block_bf16: the fused out projection needs the counter workspace (2 * batch + 1 ints, zeroed once)");
-  }
   BArgs a{reinterpret_cast<const u16*>(d.A), reinterpret_cast<const char*>(d.Wp), reinterpret_cast<u16*>(d.C), d.scale, d.scale_stride, d.eps,
-          d.M / 256, d.n_heads, d.qk_scale, d.rope_pos, d.rope_freq, option("code_warm", KD_CODE_WARM_DEFAULT), g_clk,
-          op ? reinterpret_cast<const char*>(op->Wp) : nullptr, op ? reinterpret_cast<u16*>(op->C) : nullptr, sync};
+          d.M / 256, d.n_heads, d.qk_scale, d.rope_pos, d.rope_freq, option("code_warm", KD_CODE_WARM_DEFAULT), g_clk};
   hipStream_t s = (hipStream_t)stream;
   constexpr int LDS = 8 * WBLK + 8 * 512 * 4;          // prologue: 8 wave-private staging slots + 8 scale vectors; later ring + K / V images
-  const double flops = 2.0 * d.M * 3.0 * d.K * d.K + 4.0 * (double)a.batch * a.nh * 256.0 * 256.0 * DH + (op ? 2.0 * d.M * (double)d.K * d.K : 0.0);
-  const double bytes = 2.0 * ((double)d.M * d.K * 2.0 + 3.0 * d.K * d.K) + (op ? 2.0 * ((double)d.M * d.K + (double)d.K * d.K) : 0.0);
+  const double flops = 2.0 * d.M * 3.0 * d.K * d.K + 4.0 * (double)a.batch * a.nh * 256.0 * 256.0 * DH;
+  const double bytes = 2.0 * ((double)d.M * d.K * 2.0 + 3.0 * d.K * d.K);
   char nm[96] = "attn_block_bf16";
-  if (prof_on()) snprintf(nm, sizeof(nm), "attn_block_bf16%s M=%d K=%d nh=%d", op ? "+out" : "", d.M, d.K, d.n_heads);
+  if (prof_on()) snprintf(nm, sizeof(nm), "attn_block_bf16 M=%d K=%d nh=%d", d.M, d.K, d.n_heads);
   LaunchScope prof(nm, flops, bytes, s);
-#define KD_BLK(NCV, OV, TSV) { static LdsAttr set; set.ensure(reinterpret_cast<const void*>(attn_block_bf16_kernel<NCV, OV, TSV>), LDS); \
-    hipLaunchKernelGGL((attn_block_bf16_kernel<NCV, OV, TSV>), dim3((unsigned)(a.batch * a.nh)), dim3(512), LDS, s, a); }
-#define KD_BLK2(NCV) { if (op) { if (a.clk) KD_BLK(NCV, true, true) else KD_BLK(NCV, true, false) } \
-                       else { if (a.clk) KD_BLK(NCV, false, true) else KD_BLK(NCV, false, false) } }
+#define KD_BLK(NCV, TSV) { static LdsAttr set; set.ensure(reinterpret_cast<const void*>(attn_block_bf16_kernel<NCV, TSV>), LDS); \
+    hipLaunchKernelGGL((attn_block_bf16_kernel<NCV, TSV>), dim3((unsigned)(a.batch * a.nh)), dim3(512), LDS, s, a); }
+#define KD_BLK2(NCV) { if (a.clk) KD_BLK(NCV, true) else KD_BLK(NCV, false) }
   if (d.K == 512) KD_BLK2(32) else KD_BLK2(16)
 #undef KD_BLK2
 #undef KD_BLK

@@ -55,8 +55,8 @@ __global__ __launch_bounds__(EW_BLOCK) void sampler_step_kernel(const float* __r
     f32x4 o;
 #pragma unroll
     for (int u = 0; u < 4; ++u) { float a = av[u]; o[u] = step_one<OP>(xv[u], dv[u], iv[u], a, c0, c1, c2, c3); av[u] = a; }
-    reinterpret_cast<f32x4*>(out)[i] = o;
-    if (AUX_W) reinterpret_cast<f32x4*>(aux)[i] = av;
+    st16(reinterpret_cast<f32x4*>(out) + i, o);
+    if (AUX_W) st16(reinterpret_cast<f32x4*>(aux) + i, av);
   }
   // tail (n % 4 elements)
   for (long i = (nv << 2) + (long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += stride) {

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x3_kernel(const FArgs3 p) {
       for (int it = 0; it < 2; ++it) {
         const int r16 = 16 * it + (lane >> 2), c = lane & 3;
         const f32x4 o = *reinterpret_cast<const f32x4*>(strip + r16 * 64 + ((c ^ ((r16 >> 2) & 1)) << 4));
-        if (st_ok[it]) *reinterpret_cast<f32x4*>(st_row[it] + 32 * ob + 16 * hb) = o + skip[it];
+        if (st_ok[it]) st16(st_row[it] + 32 * ob + 16 * hb, f32x4(o + skip[it]));
       }
     }
   });
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(256, 2) void ffn_x3h_kernel(const FArgs3 p) {
       for (int it = 0; it < 2; ++it) {
         const int r16 = 16 * it + (lane >> 2), c = lane & 3;
         const f32x4 o = *reinterpret_cast<const f32x4*>(strip + r16 * 64 + ((c ^ ((r16 >> 2) & 1)) << 4));
-        if (st_ok[it]) *reinterpret_cast<f32x4*>(st_row[it] + 32 * ob + 16 * hb) = o + skip[it];
+        if (st_ok[it]) st16(st_row[it] + 32 * ob + 16 * hb, f32x4(o + skip[it]));
       }
     }
   });

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
         for (int it = 0; it < 2; ++it) {
           const int r16 = 16 * it + (lane >> 2), c = lane & 3;
           const f32x4 o = *reinterpret_cast<const f32x4*>(strip + r16 * 64 + ((c ^ ((r16 >> 2) & 1)) << 4));
-          if (st_ok[it]) *reinterpret_cast<f32x4*>(st_row[it] + col + 16 * hb) = o;
+          if (st_ok[it]) st16(st_row[it] + col + 16 * hb, o);
         }
       }
     };
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, NC <= 8 ? 2 : 1) void gemm_x3_astat_kernel(con
             const size_t o = (((size_t)bb * p.chan + cch) * Himg + 4 * ty + py) * Wimg + 4 * tx;
             f32x4 v = f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]} * (rs * c_out);
             if (p.sigma) v = v + *reinterpret_cast<const f32x4*>(p.R + o) * c_skip;
-            *reinterpret_cast<f32x4*>(p.C + o) = v;
+            st16(p.C + o, v);
           }
         }
     } else {
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3h_kernel(const XArgs p) {
       for (int it = 0; it < 2; ++it) {
         const int r16 = 16 * it + (lane >> 2), c = lane & 3;
         const f32x4 o = *reinterpret_cast<const f32x4*>(strip + r16 * 64 + ((c ^ ((r16 >> 2) & 1)) << 4));
-        if (st_ok[it]) *reinterpret_cast<f32x4*>(st_row[it] + col + 16 * hb) = o;
+        if (st_ok[it]) st16(st_row[it] + col + 16 * hb, o);
       }
     }
   };

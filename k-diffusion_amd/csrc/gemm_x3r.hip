@@ -305,7 +305,7 @@ __global__ __launch_bounds__(LW ? 512 : 256, LW ? 2 : 1) void gemm_x3r_kernel(co
       for (int it = 0; it < 2; ++it) {
         const int r16 = 16 * it + (lane >> 2), cc = lane & 3;
         const f32x4 o = *reinterpret_cast<const f32x4*>(strip + r16 * 64 + ((cc ^ ((r16 >> 2) & 1)) << 4));
-        if (st_ok[it]) *reinterpret_cast<f32x4*>(st_row[it] + 32 * j + 16 * hb) = o;
+        if (st_ok[it]) st16(st_row[it] + 32 * j + 16 * hb, o);
       }
     }
   if (probe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.clk[14] = __builtin_amdgcn_s_memtime(); }      // stores out

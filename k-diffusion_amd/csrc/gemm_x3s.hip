@@ -305,7 +305,7 @@ __global__ __launch_bounds__(512) void gemm_x3s_kernel(const SArgs p) {
       for (int it = 0; it < 2; ++it) {
         const int r16 = 16 * it + (lane >> 2), c = lane & 3;
         const f32x4 o = *reinterpret_cast<const f32x4*>(strip + r16 * 64 + ((c ^ ((r16 >> 2) & 1)) << 4));
-        if (st_ok[it]) *reinterpret_cast<f32x4*>(st_row[it] + col + 16 * hb) = o;
+        if (st_ok[it]) st16(st_row[it] + col + 16 * hb, o);
       }
     }
   };

@@ -17,6 +17,21 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int WAVE = 64;
 
+// 16-byte store of a kernel's RESULT rows.  Build with -DKD_WT_STORES=1 for the write-through form (`sc1`): the bytes leave the XCD's L2 while
+// the kernel is still running, so the write-back at the kernel boundary -- which costs (dirty bytes) / ~6 TB/s before the next dependent launch
+// may start (MI355X_MICROARCH.md, "boundary") -- finds nothing left to do.  The consumer is always the NEXT launch, which does not find the
+// producer's lines in its L2 either way.  The asm form is not counted by hipcc's vmcnt bookkeeping: vector memory operations retire in order on
+// gfx9, so an uncounted store only makes the compiler's later waits conservative; `s_nop 1` keeps the data registers intact until read.
+template <class V>
+__device__ __forceinline__ void st16(void* p, const V& v) {
+  static_assert(sizeof(V) == 16, "st16: 16-byte vectors");
+#if KD_WT_STORES
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<V*>(p) = v;
+#endif
+}
+
 // the public descriptor plus what only the library sets (kept out of the ABI)
 struct GemmP : KdGemm {
   int warm;         // code warm-up workgroups (code_warm_begin below; option "code_warm")

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(PNW * 64) void unpatch4_kernel(const PArgs p) {
           v[e] = acc[gi >> 2][4 * (gi & 3) + e] * rs;
           if (p.sigma) v[e] = v[e] * c_out + skip[gi][e] * c_skip;
         }
-        if (ok) *reinterpret_cast<f32x4*>(p.Cimg + o[gi]) = v;
+        if (ok) st16(p.Cimg + o[gi], v);
       }
     }
   }

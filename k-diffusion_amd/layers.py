@@ -55,8 +55,10 @@ class Denoiser(nn.Module):
 
 
 class DenoiserWithVariance(Denoiser):
-    pass
+    """What ``make_denoiser_wrapper`` returns for ``has_variance`` configs (config.py:223-224; layers.py:93-101).  The reference's class
+    overrides ``loss`` only (the model's log-variance output is a training quantity): ``forward`` / ``get_scalings`` -- the sampling path --
+    are ``Denoiser``'s, as here."""
 
 
 class SimpleLossDenoiser(Denoiser):
-    pass
+    """``loss_config == 'simple'`` (config.py:229-230; layers.py:104-111): again only ``loss`` differs in the reference."""

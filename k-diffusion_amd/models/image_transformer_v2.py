@@ -39,15 +39,12 @@ from .. import ops
 from . import axial_rope
 
 D_HEAD = 64
-# KDIFF_GRAPH=1: replay the main and the per-step conditioning chain of a forward from captured hipGraphs (one host call per forward)
-# instead of issuing their launches.  Off by default: slower at every batch size (see _graph_policy).
 # Largest [steps, B, scale_width] scale table kept per sigma schedule (prefetch_schedule); longer schedules use the per-step chain.
 SCHEDULE_TABLE_MAX_BYTES = 1 << 30
 SCHEDULES_KEPT = 4            # a run of a two-stage solver hints two tables; older records (and their tensors) are dropped
 SCHEDULE_CHAINS_KEPT = 2      # conditioning workspaces kept per plan, by schedule length (least recently used dropped)
 # environment switches read while a plan is built (name, default): part of the plan key
-PLAN_SWITCHES = (("KDIFF_ATTN_BLOCK", "1"), ("KDIFF_PROJ_BLOCK", "1"), ("KDIFF_QKV_PACKED", "1"), ("KDIFF_GRAPH", "0"), ("KDIFF_FFN_X3", "1"), ("KDIFF_FFN_OUT", "all"), ("KDIFF_X3_PLANES", "1"),
-                 ("KDIFF_X3_DOWN", "0"), ("KDIFF_RUN_LIST", "1"))
+PLAN_SWITCHES = (("KDIFF_ATTN_BLOCK", "1"), ("KDIFF_PROJ_BLOCK", "1"), ("KDIFF_FFN_OUT", "all"), ("KDIFF_RUN_LIST", "1"))
 CLASS_IDS_KEPT = 4            # range-checked class_cond tensors remembered per plan (cond / uncond pairs of a guidance wrapper)
 
 
@@ -57,18 +54,6 @@ def _ver(t):
     """Version counter of a tensor, or a value that never repeats for tensors made under torch.inference_mode() (they carry no
     counter, so an in-place change cannot be seen: such a tensor is never recognised as 'the same data as last time')."""
     return next(_untracked) if t.is_inference() else t._version
-
-
-def _graph_policy():
-    """KDIFF_GRAPH: 0 (default) = issue the launch lists directly, 1 = replay them from captured hipGraphs.  Replay is 6 - 16 % slower than
-    direct issue at every batch size and in both modes (round 4, profiles/r04_small_batch.log: 0.59 against 0.51 ms per forward at batch 1
-    in the bf16 mode, 0.76 against 0.70 in the fp32-parity mode): the host needs ~0.2 ms to issue a forward's launches (kd_run_list, 3 us
-    each), well under what the kernels take even at batch 1.  (Earlier in round 4 replay looked 22 % FASTER for the bf16 mode at batch 1: the
-    host was then spending 0.3 - 0.4 ms per model call walking the module tree for its weights fingerprint -- see _weights_fingerprint.)"""
-    mode = os.environ.get("KDIFF_GRAPH", "0").lower()
-    if mode not in ("0", "1"):
-        raise ValueError(f"KDIFF_GRAPH={mode!r}: expected 0 or 1")
-    return mode == "1"
 
 
 # ---------------------------------------------------------------------------------- configuration
@@ -229,6 +214,9 @@ class _Plan:
         lib = nat.lib()
         m = model
         precision = nat.default_precision()
+        # fp8 mode: the bf16 plan with the norm -> qkv / norm -> GEGLU projections of the K = 256 / 512 levels on the fp8 matrix instruction
+        fp8 = precision == nat.PREC_FP8
+        precision = nat.PREC_BF16 if fp8 else precision
         bf = precision == nat.PREC_BF16
         cond_precision = nat.PREC_SPLIT3 if bf else precision      # the per-sample conditioning chain stays fp32 in every mode
         self.keep = []           # descriptors and tensors that must outlive the plan
@@ -248,11 +236,6 @@ class _Plan:
             grids.append((gh // 2, gw // 2))
         self.B, self.grids = B, grids
         self.out_shape = (B, m.out_channels, H, W)
-        self.use_graph = _graph_policy()
-        self.graphs, self.cond_graphs = {}, {}              # captured main chains / conditioning chains (see replay())
-        self.g_x = self.g_out = self.capture_stream = None   # their fixed input / output images
-        self.direct_runs = self.direct_cond_runs = 0
-        self.graph_epoch = nat.option_epoch
         self.class_checked = {}                             # identities of the range-checked class_cond tensors (_plan_for) -> the tensor
         mw, mdff = m.mapping_spec.width, m.mapping_spec.d_ff
 
@@ -268,7 +251,7 @@ class _Plan:
         # fp32) and the consumer GEMM moves them by LDS-DMA (csrc/gemm_x3t.hip).  Planes of the FF hidden activation live in `hid`
         # (hi in its first half, lo in the second); the normalised rows of the levels whose width exceeds the fused norm -> projection
         # kernel's register budget (> 256) get planes of their own (`xn`, written by kd_norm_split_f32).
-        planes = precision == nat.PREC_SPLIT3 and os.environ.get("KDIFF_X3_PLANES", "1") != "0"
+        planes = precision == nat.PREC_SPLIT3
         def prepass(width):                                  # widths the fused norm -> projection kernel (gemm_x3.hip) does not take
             return planes and width not in (128, 256, 512) and width > 256 and width % 128 == 0 and width <= 2048    # (tiles of 128 features)
         wide = [t * lv.width for t, lv in zip(toks, levels) if prepass(lv.width)]
@@ -288,18 +271,19 @@ class _Plan:
         self.main_entry = torch.cuda.Event()
         self.schedules, self.schedule_chains = [], {}       # conditioning of whole sigma schedules (prefetch_schedule); chains by length
         self.keep += [xs, qkv, att, hid, wcat]
-        self.block_sync = None                              # counters of kd_attn_block_bf16's fused out projection (zeroed once; the kernel leaves them zero)
         self.xs = xs
 
         def gemm(what, A, Wt, Cc, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, scale_ptr=None, scale_stride=0,
                  rows_per_sample=0, R=None, grid=(0, 0), patch=(0, 0, 0), out_add=0.0, sigma=None, fac=None, qk=None,
-                 a_planes=None, c_planes=None):
+                 a_planes=None, c_planes=None, mx8=False):
             d = nat.KdGemm()
             d.M, d.N, d.K, d.a_mode, d.epi = M, N, K, a_mode, epi
             main = target is self.launches
             d.precision = precision if main else cond_precision
             d.per_row = 0 if main else 1                    # conditioning products: one row per sample, see _CondChain
-            if d.precision == nat.PREC_BF16:
+            if mx8:
+                d.Wp = m._packed_image(Wt, N, K, epi == nat.EPI_GEGLU, bf16="mx8").data_ptr()
+            elif d.precision == nat.PREC_BF16:
                 d.Wp = m._packed_image(Wt, N, K, epi == nat.EPI_GEGLU, bf16=True).data_ptr()
             elif d.precision == nat.PREC_SPLIT3:
                 d.Wp = m._packed_image(Wt, N, K, epi == nat.EPI_GEGLU).data_ptr()
@@ -327,9 +311,13 @@ class _Plan:
                 if len(qk) >= 6:                                     # split3: positions / frequencies for the round-3 kernels (gemm_x3*.hip)
                     d.rope_pos, d.rope_freq = qk[4].data_ptr(), qk[5].data_ptr()
             (self.keep if main else chain.keep).append(d)
-            target.append(_Launch(lib.kd_gemm_bf16 if d.precision == nat.PREC_BF16 else lib.kd_gemm_f32, (C.byref(d),), what,
-                                  enc=("kd_gemm_bf16" if d.precision == nat.PREC_BF16 else "kd_gemm_f32", (d,))))
+            name = "kd_gemm_mx8" if mx8 else ("kd_gemm_bf16" if d.precision == nat.PREC_BF16 else "kd_gemm_f32")
+            target.append(_Launch(getattr(lib, name), (C.byref(d),), what + ("(mx8)" if mx8 else ""), enc=(name, (d,))))
             return d
+
+        def mx8_ok(M, N, K, epi):
+            """fp8 mode: this norm -> projection of the main chain goes to the block-scaled fp8 matrix instruction (kd_gemm_mx8)."""
+            return fp8 and target is self.launches and bool(lib.kd_gemm_mx8_supported(M, N, K, epi, 1))
 
         def call(what, fn, *args):
             target.append(_Launch(fn, args, what, enc=(fn.__name__, args)))
@@ -423,14 +411,13 @@ class _Plan:
                                   (), what + " (split)", enc=("kd_norm_split_f32", (xp, ref, total, rps_, hi_p, lo_p, T_, d_, 1e-6))))
             return (hi_p, lo_p)
 
-        packed_qkv = precision == nat.PREC_SPLIT3 and os.environ.get("KDIFF_QKV_PACKED", "1") != "0"
+        packed_qkv = precision == nat.PREC_SPLIT3
 
         def add_layer(li, prefix, mod, index):
             lv, (gh, gw), T = levels[li], grids[li], toks[li]
             d, x = lv.width, xs[li]
             rps = gh * gw
-            ffn_x3 = precision == nat.PREC_SPLIT3 and target is self.launches and lib.kd_ffn_f32_supported(T, d, lv.d_ff) \
-                and os.environ.get("KDIFF_FFN_X3", "1") != "0"
+            ffn_x3 = precision == nat.PREC_SPLIT3 and target is self.launches and lib.kd_ffn_f32_supported(T, d, lv.d_ff)     # (library option ffn_x3)
             # out projection fused into the FF kernel: width 128 (+3.5 % images/s in round 3) and, since round 5, width 256 too: in round 3
             # that measured level (176.1 vs 176.0: one wave per SIMD there); with the round-4 / 5 kernels around it the removed launch + the
             # attention rows' HBM round trip are worth +1.5 .. +3.0 % on two boxes (same box, back to back: 207.9 / 207.9 / 208.7 vs 214.3;
@@ -468,29 +455,15 @@ class _Plan:
                 # projection's, its C the attention output
                 # From 32 (sample, head) workgroups on: below that (batch 1 - 2 at level 2) the few-rows projection + the dense core are faster
                 # (0.514 against 0.543 ms per forward at batch 1; from batch 4 on the one-launch form wins: profiles/r05_attn_block.md)
-                fused_block = bf and isinstance(spec, GlobalAttentionSpec) and target is self.launches and T % 256 == 0 \
+                qkv_mx8 = mx8_ok(T, 3 * d, d, nat.EPI_QKV)
+                fused_block = bf and not qkv_mx8 and isinstance(spec, GlobalAttentionSpec) and target is self.launches and T % 256 == 0 \
                     and os.environ.get("KDIFF_ATTN_BLOCK", "1") != "0" and bool(lib.kd_attn_block_bf16_supported(rps, d, nh)) \
                     and (B * nh >= 32 or os.environ.get("KDIFF_ATTN_BLOCK", "1") == "force")
-                fused_out_proj = False
                 if fused_block:
                     dq = gemm(prefix + "attn_block", x, sa.qkv_proj.weight, att, T, 3 * d, d, epi=nat.EPI_QKV,
                               scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps, qk=qk)
                     target.pop()
-                    do = None
-                    if not fuse_out and os.environ.get("KDIFF_ATTN_BLOCK", "1") == "2":
-                        # KDIFF_ATTN_BLOCK=2 (on request): the block's out projection + residual in the same launch too -- the sample's
-                        # workgroups meet once its attention columns are stored.  Bit-identical, but measured LEVEL with the separate launch
-                        # (37.1 us against 25.8 + 14.6 at the level-2 shape; 440 against 442 images/s): the wait for the slowest sibling
-                        # (~5 us) and re-staging the 256 attention rows (~3.7 us) cost what the saved launch gave.  Default 1.
-                        do = gemm(prefix + "out_proj", att, sa.out_proj.weight, x, T, d, d, epi=nat.EPI_RESIDUAL, R=x)
-                        target.pop()
-                        if self.block_sync is None:
-                            self.block_sync = torch.zeros(2 * B + 1, device=device, dtype=torch.int32)
-                    sync_p = C.c_void_p(self.block_sync.data_ptr()) if do is not None else None
-                    target.append(_Launch(lib.kd_attn_block_bf16, (C.byref(dq), C.byref(do) if do is not None else None, sync_p),
-                                          prefix + ("attn_block+out" if do is not None else "attn_block"),
-                                          enc=("kd_attn_block_bf16", (dq, do, sync_p))))
-                    fused_out_proj = do is not None
+                    target.append(_Launch(lib.kd_attn_block_bf16, (C.byref(dq),), prefix + "attn_block", enc=("kd_attn_block_bf16", (dq,))))
                 elif xn is not None and prepass(d) and nh <= 16:
                     # AdaRMSNorm -> planes once, then a GEMM whose two operands both move by LDS-DMA
                     xn_planes = norm_split(prefix + "self_attn.norm", x, scale_ptr(prefix + "self_attn.norm")[1], T, d, rps)
@@ -498,10 +471,10 @@ class _Plan:
                               a_planes=xn_planes)
                 else:
                     dq = gemm(prefix + "qkv_proj", x, sa.qkv_proj.weight, qkv, T, 3 * d, d, epi=nat.EPI_QKV,
-                              scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps, qk=qk)
+                              scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps, qk=qk, mx8=qkv_mx8)
                     # bf16 mode, K = 256 / 512 with an attention core of its own (neighbourhood / window levels): the projection in the block
                     # form (kd_proj_block_bf16: a workgroup per (256-row group, 6 head vectors), rows normalised once) for one-round grids (192 .. 256)
-                    if bf and target is self.launches and os.environ.get("KDIFF_PROJ_BLOCK", "1") != "0" \
+                    if bf and not qkv_mx8 and target is self.launches and os.environ.get("KDIFF_PROJ_BLOCK", "1") != "0" \
                             and bool(lib.kd_proj_block_bf16_supported(rps, d, 3 * d, nat.EPI_QKV)) and 192 <= (T // 256) * (3 * d // 384) <= 256:
                         target[-1] = _Launch(lib.kd_proj_block_bf16, (C.byref(dq),), prefix + "qkv_proj(block)", enc=("kd_proj_block_bf16", (dq,)))
                 dq.qkv_packed = 1 if packed_qkv else 0
@@ -523,7 +496,7 @@ class _Plan:
                     call(prefix + "attn_na2d", lib.kd_attn_na2d_f32, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.kernel_size, *prep)
                 else:
                     call(prefix + "attn_window", lib.kd_attn_window_f32, _ptr(qkv), _ptr(att), B, gh, gw, nh, spec.window_size, shift, *prep)
-                if not fuse_out and not fused_out_proj:
+                if not fuse_out:
                     gemm(prefix + "out_proj", att, sa.out_proj.weight, x, T, d, d, epi=nat.EPI_RESIDUAL, R=x)
             if ffn_x3:
                 # fp32-parity mode: the whole FeedForwardBlock in one kernel (csrc/ffn_x3.hip), hidden activation on the chip; at widths 128 / 256
@@ -556,31 +529,22 @@ class _Plan:
                 self.keep.append(fd)
                 target.append(_Launch(lib.kd_ffn_bf16, (C.byref(fd),), prefix + "ff", enc=("kd_ffn_bf16", (fd,))))
             else:
-                # hidden activation as planes when the down projection's tiled form fills the chip (256-row x 128-feature tiles)
-                hid_planes = None
-                if planes and target is self.launches and d % 128 == 0 and lv.d_ff % 64 == 0 and d in (128, 256, 512) \
-                        and -(-T // 256) * (d // 128) >= 192 and os.environ.get("KDIFF_X3_DOWN", "0") == "1":     # measured level with the fp32 form: on request
-                    hid_planes = (hid.data_ptr(), hid.data_ptr() + 2 * T * lv.d_ff)
                 if xn is not None and target is self.launches and prepass(d) and lv.d_ff % 64 == 0:
                     xn_planes = norm_split(prefix + "ff.norm", x, scale_ptr(prefix + "ff.norm")[1], T, d, rps)
-                    gemm(prefix + "up_proj", None, mod.ff.up_proj.weight, hid, T, lv.d_ff, d, epi=nat.EPI_GEGLU, a_planes=xn_planes,
-                         c_planes=hid_planes)
+                    gemm(prefix + "up_proj", None, mod.ff.up_proj.weight, hid, T, lv.d_ff, d, epi=nat.EPI_GEGLU, a_planes=xn_planes)
                 else:
+                    up_mx8 = mx8_ok(T, lv.d_ff, d, nat.EPI_GEGLU)
                     du = gemm(prefix + "up_proj", x, mod.ff.up_proj.weight, hid, T, lv.d_ff, d, epi=nat.EPI_GEGLU,
-                              scale_ptr=scale_ptr(prefix + "ff.norm"), scale_stride=total, rows_per_sample=rps,
-                              c_planes=hid_planes if (d in (128, 256) and T >= 512) else None)
+                              scale_ptr=scale_ptr(prefix + "ff.norm"), scale_stride=total, rows_per_sample=rps, mx8=up_mx8)
                     # bf16 mode, rows per sample a multiple of 256: the projection in the attention block's form (a workgroup per (256-row group,
                     # 192-output slice), rows normalised once; csrc/block_bf16.hip: proj_block_bf16_kernel) for grids that fill ONE round of the
                     # chip's 256 CUs (192 .. 256 workgroups): two rounds measured level with the A-stationary kernel (42.3 against 41.5 us at
                     # level 1), and a workgroup's six passes are a serial chain -- at 32 - 128 workgroups the A-stationary kernel, which splits
                     # the same work over up to 512 slots, is faster (batch 4: 0.645 against 0.759 ms per forward; batch 16: level); same bits
-                    if bf and target is self.launches and os.environ.get("KDIFF_PROJ_BLOCK", "1") != "0" \
+                    if bf and not up_mx8 and target is self.launches and os.environ.get("KDIFF_PROJ_BLOCK", "1") != "0" \
                             and bool(lib.kd_proj_block_bf16_supported(rps, d, lv.d_ff, nat.EPI_GEGLU)) and 192 <= (T // 256) * (lv.d_ff // 192) <= 256:
                         target[-1] = _Launch(lib.kd_proj_block_bf16, (C.byref(du),), prefix + "up_proj(block)", enc=("kd_proj_block_bf16", (du,)))
-                    if not (d in (128, 256) and T >= 512):
-                        hid_planes = None
-                gemm(prefix + "down_proj", None if hid_planes else hid, mod.ff.down_proj.weight, x, T, d, lv.d_ff, epi=nat.EPI_RESIDUAL, R=x,
-                     a_planes=hid_planes)
+                gemm(prefix + "down_proj", hid, mod.ff.down_proj.weight, x, T, d, lv.d_ff, epi=nat.EPI_RESIDUAL, R=x)
 
         for li in range(n_lv - 1):
             for i, mod in enumerate(m.down_levels[li]):
@@ -643,60 +607,16 @@ class _Plan:
                 return
         self.calls = calls
 
-    # ---- hipGraph replay (launch-bound batch sizes only: ``use_graph``) ---------------------------------------------------
-    def _capture(self, issue):
-        # capture_begin / capture_end rather than the torch.cuda.graph context: that one synchronises the device, runs the
-        # garbage collector and empties the allocator cache first, none of which a capture of pure kernel launches needs
-        # (the library allocates nothing and never syncs; nothing executes during capture)
-        g = torch.cuda.CUDAGraph()
-        if self.capture_stream is None:
-            self.capture_stream = torch.cuda.Stream(device=self.sigma.device)
-        with torch.cuda.stream(self.capture_stream):
-            g.capture_begin(capture_error_mode="thread_local")
-            try:
-                issue()
-            finally:
-                g.capture_end()
-        return g
 
-    def _graph_epoch(self):
-        """Kernel selection inside the library follows its options (kd_set_option): graphs captured under other settings are dropped."""
-        if self.graph_epoch != nat.option_epoch:
-            self.graphs, self.cond_graphs, self.graph_epoch = {}, {}, nat.option_epoch
-            self.direct_runs = self.direct_cond_runs = 0          # another kernel family may see its first launch now
+def _weak_epoch_bump(model):
+    """load_state_dict post-hook that bumps ``model``'s weights epoch without holding the model alive."""
+    ref = weakref.ref(model)
 
-    def replay(self, x, sigma_data, base):
-        """``run`` through a captured graph.  Kernel arguments are frozen at capture, so the chain reads a fixed input image
-        and writes a fixed output image (two small copies per forward at these sizes) and there is one graph per
-        (scale table, preconditioning) combination.  The first forward of a plan is issued directly (one-time kernel
-        attribute set-up must not happen under capture)."""
-        if self.g_x is None:
-            self.g_x = torch.empty_like(x)
-            self.g_out = torch.empty(self.out_shape, device=x.device, dtype=torch.float32)
-        self.g_x.copy_(x, non_blocking=True)
-        self._graph_epoch()
-        key = (base, None if sigma_data is None else float(sigma_data))
-        g = self.graphs.get(key)
-        if g is None and self.direct_runs == 0:
-            self.direct_runs += 1
-            self.run(self.g_x, self.g_out, sigma_data, base)
-        else:
-            if g is None:
-                g = self.graphs[key] = self._capture(lambda: self.run(self.g_x, self.g_out, sigma_data, base))
-            g.replay()
-        return self.g_out.clone()
-
-    def replay_cond(self, buf):
-        """``run_cond`` on the current stream, replayed from a graph after the first direct pass."""
-        self._graph_epoch()
-        g = self.cond_graphs.get(buf)
-        if g is None and self.direct_cond_runs == 0:
-            self.direct_cond_runs += 1
-            self.run_cond(buf, C.c_void_p(torch.cuda.current_stream().cuda_stream))
-            return
-        if g is None:
-            g = self.cond_graphs[buf] = self._capture(lambda: self.run_cond(buf, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        g.replay()
+    def hook(*_args):
+        m = ref()
+        if m is not None:
+            m._fp_epoch += 1
+    return hook
 
 
 # ---------------------------------------------------------------------------------- the model
@@ -749,6 +669,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         self._plans, self._fingerprint, self._packed, self._plans_epoch = {}, None, {}, None
         self._fp_dicts, self._fp_names, self._fp_objs, self._fp_tensors, self._fp_tracked, self._fp_epoch = (), (), (), (), (), 0
         self._fp_hooked = weakref.WeakSet()
+        self._fp_sized, self._fp_sizes = (), ()
 
     # ---- bookkeeping ---------------------------------------------------------------------------
     def _ada_norm_modules(self):
@@ -783,9 +704,6 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         freq = sa.pos_emb.freqs.detach().to(torch.float32).cpu() / (2.0 * math.pi)
         return pos.reshape(-1, 2).to(torch.float32).contiguous().to(device), freq.contiguous().to(device)
 
-    def _note_weights_rewritten(self, *_args):
-        self._fp_epoch += 1
-
     def invalidate(self):
         """Drop the plans and packed weight images at the next call.  Needed only after an IN-PLACE edit of weights that were created
         under torch.inference_mode() outside load_state_dict / .to(): such tensors carry no version counter, so the edit leaves no trace
@@ -804,7 +722,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         """Packed image of a weight (split-bf16, or plain bf16 for the bf16 mode), shared by all plans of this model.  The
         entry keeps the source tensor alive, so its address cannot be recycled under the cached image; the dict is dropped
         with the plans whenever the weights change (``_weights_fingerprint``)."""
-        key = (id(W), N, K, int(geglu), bool(bf16))
+        key = (id(W), N, K, int(geglu), bf16 if bf16 == "mx8" else bool(bf16))
         ent = self._packed.get(key)
         if ent is None:
             ent = self._packed[key] = (W, ops.pack_weight(W, N, K, geglu, cache=False, bf16=bf16))
@@ -815,19 +733,22 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         weight images.  Read on every model call, so the LIST of tensors is kept -- torch's module traversal (parameters() / buffers() over
         ~90 sub-modules) took 0.3 - 0.4 ms per call, more than the launches of a batch-1 forward.  What makes the kept list safe is a
         per-call identity check of every SLOT the tree has -- each (module._parameters | _buffers | _modules dict, name) still holds the
-        object it held when the list was built -- which is ~200 dict reads in C (a few microseconds), needs no traversal and sees every
-        way a tensor can be swapped: attribute assignment, register_*, del + re-register, a replaced sub-module, and direct writes into
+        object it held when the list was built, and each of those dicts still has the size it had (a parameter / buffer / sub-module ADDED
+        to an existing module) -- which is ~300 dict reads in C (a few microseconds), needs no traversal and sees the ways a tensor can be
+        swapped: attribute assignment, register_*, del + re-register, a replaced sub-module, and direct writes into
         ``module._parameters[name]`` (torch.func.functional_call / stateless._reparametrize_module swap parameters that way, past every
         registration hook).  In-place edits move the tensors' version counters; .to() moves their addresses; load_state_dict / _apply /
         invalidate() bump the epoch (which also covers inference-mode tensors, whose edits leave no version trace).  No process-wide
         hooks: only this model's own tree is looked at."""
-        if not (self._fp_objs and all(map(operator.is_, map(dict.get, self._fp_dicts, self._fp_names), self._fp_objs))):
-            dicts, names, objs, ts = [], [], [], []
+        if not (self._fp_objs and all(map(operator.is_, map(dict.get, self._fp_dicts, self._fp_names), self._fp_objs))
+                and tuple(map(len, self._fp_sized)) == self._fp_sizes):      # (sizes: a slot ADDED to a recorded dict is no recorded slot)
+            dicts, names, objs, ts, sized = [], [], [], [], []
             for mod in self.modules():
                 if mod not in self._fp_hooked:       # a (sub-)module's load_state_dict rewrites weights in place: bump the epoch (inference-mode tensors)
                     self._fp_hooked.add(mod)
-                    mod.register_load_state_dict_post_hook(self._note_weights_rewritten)
+                    mod.register_load_state_dict_post_hook(_weak_epoch_bump(self))      # (weak: a sub-module shared with another model does not pin this one)
                 for d, is_tensor in ((mod._parameters, True), (mod._buffers, True), (mod._modules, False)):
+                    sized.append(d)
                     for name, obj in d.items():
                         dicts.append(d), names.append(name), objs.append(obj)
                         if is_tensor and obj is not None:
@@ -838,6 +759,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
                     seen.add(id(t))
                     uniq.append(t)
             self._fp_dicts, self._fp_names, self._fp_objs = tuple(dicts), tuple(names), tuple(objs)
+            self._fp_sized, self._fp_sizes = tuple(sized), tuple(map(len, sized))
             self._fp_tensors, self._fp_tracked = tuple(uniq), tuple(not t.is_inference() for t in uniq)
         return (self._fp_epoch, *[(t.data_ptr(), t._version if tr else 0) for t, tr in zip(self._fp_tensors, self._fp_tracked)])
 
@@ -871,7 +793,6 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         B, _, H, W = x.shape
         plan = self._plan_for(x, aug_cond, class_cond, create=True)
         cur = torch.cuda.current_stream()
-        graphed = plan.use_graph and not nat.prof_active and not torch.cuda.is_current_stream_capturing()
         ident = self._cond_identity(sigma, aug_cond, class_cond, mapping_cond)
         table = None
         for sch in plan.schedules:                # this call's scales were computed with its whole sigma schedule
@@ -890,21 +811,16 @@ class ImageTransformerDenoiserModelV2(nn.Module):
                 if pre is not None:
                     cur.wait_event(pre[2])        # an unused prefetch still owns the conditioning workspace: order behind it
                 plan.step_chain.fill(sigma, aug_cond, class_cond, mapping_cond)
-                if graphed:
-                    plan.replay_cond(buf)
-                else:
-                    plan.run_cond(buf, C.c_void_p(cur.cuda_stream))
+                plan.run_cond(buf, C.c_void_p(cur.cuda_stream))
             plan.last_buf = buf
             table = plan.scales[buf].data_ptr()
         if sigma_data is not None:                # per-sample sigma of the preconditioning folded into patch-in / patch-out
-            if graphed or sigma.numel() != B or sigma.dtype != torch.float32 or not sigma.is_contiguous() or sigma.device != x.device:
+            if sigma.numel() != B or sigma.dtype != torch.float32 or not sigma.is_contiguous() or sigma.device != x.device:
                 plan.sigma.copy_(sigma.reshape(-1).expand(B) if sigma.numel() == 1 else sigma.reshape(B), non_blocking=True)
                 plan.sigma_ptr = plan.sigma.data_ptr()
             else:
                 plan.sigma_ptr = sigma.data_ptr()  # read in place: freed storage is not reused before this stream's work is done
         plan.main_entry.record(cur)               # everything before this step's main chain (incl. an inline conditioning chain)
-        if graphed:
-            return plan.replay(x, sigma_data, table)
         out = torch.empty(B, self.out_channels, H, W, device=x.device, dtype=torch.float32)
         plan.run(x, out, sigma_data, table)
         return out
@@ -976,8 +892,8 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         if B != x_like.shape[0] or n == 0 or sigma_table.dtype != torch.float32 or not sigma_table.is_contiguous():
             return False
         plan = self._plan_for(x_like, aug_cond, class_cond, create=True)
-        if plan.use_graph or n * B * plan.scale_width * 4 > SCHEDULE_TABLE_MAX_BYTES:
-            return False                          # (a captured main chain is bound to the address of its scale table)
+        if n * B * plan.scale_width * 4 > SCHEDULE_TABLE_MAX_BYTES:
+            return False
         chain = plan.schedule_chains.pop(n, None)
         if chain is None:
             with torch.inference_mode(False):
@@ -1027,10 +943,7 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         side.wait_event(plan.main_entry)          # table `buf` and the conditioning workspace are free once the main chain of
         with torch.cuda.stream(side):             # the step in flight has started (its predecessors are complete in stream order)
             plan.step_chain.fill(sigma, aug_cond, class_cond, mapping_cond)
-            if plan.use_graph and not nat.prof_active:
-                plan.replay_cond(buf)
-            else:
-                plan.run_cond(buf, C.c_void_p(side.cuda_stream))
+            plan.run_cond(buf, C.c_void_p(side.cuda_stream))
             done = torch.cuda.Event()
             done.record(side)
         # the record keeps the hinted tensors alive: while it is pending their storage cannot be freed and handed to another

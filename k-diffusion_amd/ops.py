@@ -47,11 +47,11 @@ _packed = {}
 
 def pack_weight(W, N, K, geglu, cache=True, bf16=False):
     """Packed image of a weight (uint8 tensor): the split-bf16 image of KD_PREC_SPLIT3, or with ``bf16=True`` the plain bf16
-    image of KD_PREC_BF16.  ``geglu``: 0 / False plain, 1 / True GEGLU rows, 2 the k order of the fused FF block's down projection.  Weights are static while sampling, so the image is cached per tensor OBJECT (weak reference +
+    image of KD_PREC_BF16, or with ``bf16="mx8"`` the e4m3 image + channel scales of kd_gemm_mx8 (``geglu`` 0 / 1 only).  ``geglu``: 0 / False plain, 1 / True GEGLU rows, 2 the k order of the fused FF block's down projection.  Weights are static while sampling, so the image is cached per tensor OBJECT (weak reference +
     version counter: a new tensor that happens to reuse the address of a freed one never hits a stale image)."""
     geglu = int(geglu)
     cache = cache and not W.is_inference()        # (no version counter to tell a rewritten tensor by: never cached)
-    key = (id(W), bool(bf16), geglu)
+    key = (id(W), bf16 if bf16 == "mx8" else bool(bf16), geglu)
     ent = _packed.get(key) if cache else None
     if ent is not None:
         ref, version, meta, img = ent
@@ -59,7 +59,13 @@ def pack_weight(W, N, K, geglu, cache=True, bf16=False):
             return img
     _chk(W, "W")
     lib = nat.lib()
-    if bf16:
+    if bf16 == "mx8":
+        size = lib.kd_packed_weight_bytes_mx8(N, K, int(geglu))
+        if size <= 0:
+            raise ValueError(f"kd_pack_weight_mx8: N={N} K={K} is not taken (K must be a multiple of 128)")
+        img = torch.empty(size, device=W.device, dtype=torch.uint8)
+        nat.check(lib.kd_pack_weight_mx8(_p(W), _p(img), N, K, int(geglu), _stream()), "kd_pack_weight_mx8")
+    elif bf16:
         img = torch.empty(lib.kd_packed_weight_bytes_bf16(N, K, int(geglu)), device=W.device, dtype=torch.uint8)
         nat.check(lib.kd_pack_weight_bf16(_p(W), _p(img), N, K, int(geglu), _stream()), "kd_pack_weight_bf16")
     else:
@@ -78,7 +84,7 @@ def pack_weight(W, N, K, geglu, cache=True, bf16=False):
 def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scale=None, scale_stride=0,
          rows_per_sample=0, residual=None, grid=(0, 0), patch=(0, 0, 0), eps=1e-6, out_add=0.0,
          sigma=None, sigma_data=1.0, fac=None, scale_ptr=None, precision=None, qk=None, qkv_packed=False, per_row=False,
-         a_planes=None, c_planes=None, launch=True):
+         a_planes=None, c_planes=None, launch=True, mx8=False):
     """Fused GEMM (see KdGemm in include/kdiff_hip.h).  ``norm_scale`` may be a tensor or, with
     ``scale_ptr``, a raw device address inside a larger scale table.  ``precision``: nat.PREC_EXACT /
     nat.PREC_SPLIT3 / nat.PREC_BF16 (default: KDIFF_GEMM env, split3).  In bf16 mode A, out and residual are bf16 tensors
@@ -86,15 +92,20 @@ def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scal
     ``per_row`` (fp32 modes): the per-row FMA kernel of the conditioning chain whatever M (KdGemm.per_row).
     ``a_planes`` / ``c_planes`` (split3): (hi, lo) bf16 tensors instead of the fp32 ``A`` / ``out`` (KdGemm.a_split / c_split; ``A`` / ``out``
     are then ignored and may be None).  ``launch=False``: only build and return the descriptor (for entry points that take one, e.g.
-    kd_attn_block_bf16)."""
+    kd_attn_block_bf16).  ``mx8`` (bf16 tensors, norm -> store / qkv / GEGLU at K = 256 / 512): the product on the block-scaled fp8 matrix
+    instruction (kd_gemm_mx8: e4m3 weights with power-of-two channel scales, activations quantised per 32-k block)."""
     d = nat.KdGemm()
     d.per_row = 1 if per_row else 0
-    d.precision = nat.default_precision() if precision is None else precision
+    d.precision = nat.kernel_precision() if precision is None else precision
     bf = d.precision == nat.PREC_BF16
     act = torch.bfloat16 if bf else torch.float32
     a_dt = torch.float32 if a_mode == nat.A_PATCH_NCHW else act
     c_dt = torch.float32 if epi == nat.EPI_UNPATCH_NCHW else act
-    if bf:
+    if mx8:
+        if not bf:
+            raise TypeError("mx8: bf16 activations only (precision=PREC_BF16)")
+        d.Wp = pack_weight(W, N, K, epi == nat.EPI_GEGLU, bf16="mx8").data_ptr()
+    elif bf:
         d.Wp = pack_weight(W, N, K, epi == nat.EPI_GEGLU, bf16=True).data_ptr()
     elif d.precision == nat.PREC_SPLIT3:
         d.Wp = pack_weight(W, N, K, epi == nat.EPI_GEGLU).data_ptr()
@@ -130,7 +141,9 @@ def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scal
         d.qkv_packed = 1 if qkv_packed else 0      # q, k, v stored as split-bf16 chunks for the attention cores (prep="packed")
     if not launch:
         return d
-    if bf:
+    if mx8:
+        nat.check(nat.lib().kd_gemm_mx8(C.byref(d), _stream()), "kd_gemm_mx8")
+    elif bf:
         nat.check(nat.lib().kd_gemm_bf16(C.byref(d), _stream()), "kd_gemm_bf16")
     else:
         nat.check(nat.lib().kd_gemm_f32(C.byref(d), _stream()), "kd_gemm_f32")
@@ -141,7 +154,7 @@ def _prec_of(x):
     """Arithmetic mode implied by an activation tensor: bf16 tensors run the bf16 kernels, fp32 ones the KDIFF_GEMM fp32 mode."""
     if x.dtype == torch.bfloat16:
         return nat.PREC_BF16
-    p = nat.default_precision()
+    p = nat.kernel_precision()
     return nat.PREC_SPLIT3 if p == nat.PREC_BF16 else p
 
 
@@ -185,7 +198,7 @@ def rms_norm(x, scale, eps=1e-6, out=None):
     return out
 
 
-def norm_linear(x, scale, weight, *, rows_per_sample, epi=nat.EPI_STORE, out=None, eps=1e-6, qk=None, qkv_packed=False):
+def norm_linear(x, scale, weight, *, rows_per_sample, epi=nat.EPI_STORE, out=None, eps=1e-6, qk=None, qkv_packed=False, mx8=False):
     """AdaRMSNorm/RMSNorm (:155-166) fused into the following Linear / LinearGEGLU.
     ``scale``: [B, K] per-sample scales (AdaRMSNorm: Linear(cond) + 1) or [K] shared gain.
     ``epi=EPI_QKV`` with ``qk=(scale_h, cos, sin, nh)``: qkv projection whose q, k come out prepared
@@ -195,33 +208,20 @@ def norm_linear(x, scale, weight, *, rows_per_sample, epi=nat.EPI_STORE, out=Non
     Nn = weight.shape[0] // (2 if epi == nat.EPI_GEGLU else 1)
     out = torch.empty(*x.shape[:-1], Nn, device=x.device, dtype=x.dtype) if out is None else out
     return gemm(x, weight, out, M=M, N=Nn, K=K, epi=epi, norm_scale=scale, scale_stride=K if scale.dim() == 2 else 0,
-                rows_per_sample=rows_per_sample, eps=eps, qk=qk, qkv_packed=qkv_packed, precision=_prec_of(x))
+                rows_per_sample=rows_per_sample, eps=eps, qk=qk, qkv_packed=qkv_packed, precision=_prec_of(x), mx8=mx8)
 
 
-_attn_block_sync = {}
-
-
-def attn_block(x, scale, weight, *, rows_per_sample, qk, out=None, eps=1e-6, w_out=None):
-    """The global-attention block as one launch (kd_attn_block_bf16; image_transformer_v2.py:370-396): x [B, T, K] bf16, ``scale`` [B, K]
+def attn_block(x, scale, weight, *, rows_per_sample, qk, out=None, eps=1e-6):
+    """The global-attention block as one launch (kd_attn_block_bf16; image_transformer_v2.py:370-392): x [B, T, K] bf16, ``scale`` [B, K]
     AdaRMSNorm scales, ``weight`` the qkv projection [3 K, K], ``qk`` = (scale_h [nh], rope_pos [T, 2], rope_freq [nh, 8] in revolutions, nh)
-    -> attention output [B, T, K] bf16 (``out``).  With ``w_out`` [K, K] the out projection + residual runs in the same launch and ``x`` is
-    updated IN PLACE (x += att w_out^T); returns (attention output, x).  256 tokens per sample, K = 64 nh in {256, 512}."""
+    -> attention output [B, T, K] bf16 (``out``).  256 tokens per sample, K = 64 nh in {256, 512}."""
     K = x.shape[-1]
     M = x.numel() // K
     out = torch.empty_like(x) if out is None else out
     d = gemm(x, weight, out, M=M, N=3 * K, K=K, epi=nat.EPI_QKV, norm_scale=scale, scale_stride=K, rows_per_sample=rows_per_sample, eps=eps,
              qk=qk, precision=nat.PREC_BF16, launch=False)
-    if w_out is None:
-        nat.check(nat.lib().kd_attn_block_bf16(C.byref(d), None, None, _stream()), "kd_attn_block_bf16")
-        return out
-    do = gemm(out, w_out, x, M=M, N=K, K=K, epi=nat.EPI_RESIDUAL, residual=x, precision=nat.PREC_BF16, launch=False)
-    B = M // max(rows_per_sample, 1)
-    key = (x.device, B)
-    sync = _attn_block_sync.get(key)
-    if sync is None:
-        sync = _attn_block_sync[key] = torch.zeros(2 * B + 1, device=x.device, dtype=torch.int32)
-    nat.check(nat.lib().kd_attn_block_bf16(C.byref(d), C.byref(do), _p(sync), _stream()), "kd_attn_block_bf16")
-    return out, x, sync
+    nat.check(nat.lib().kd_attn_block_bf16(C.byref(d), _stream()), "kd_attn_block_bf16")
+    return out
 
 
 def proj_block(x, scale, weight, *, rows_per_sample, epi=nat.EPI_GEGLU, qk=None, out=None, eps=1e-6):
@@ -263,7 +263,7 @@ def patch_in(image, weight, patch, sigma=None, sigma_data=1.0, out=None, precisi
     ph, pw = patch
     h, w = H // ph, W // pw
     Nn = weight.shape[0]
-    precision = nat.default_precision() if precision is None else precision
+    precision = nat.kernel_precision() if precision is None else precision
     act = torch.bfloat16 if precision == nat.PREC_BF16 else torch.float32
     out = torch.empty(B, h, w, Nn, device=image.device, dtype=act) if out is None else out
     return gemm(image, weight, out, M=B * h * w, N=Nn, K=Cc * ph * pw, a_mode=nat.A_PATCH_NCHW, grid=(h, w),

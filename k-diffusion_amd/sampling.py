@@ -43,23 +43,20 @@ def _to_device_with_host_copy(sig, device):
     device->host transfer -- in a multi-batch job it would hold the host until the previous batch's GPU pass has drained."""
     dev = sig.to(device)
     if dev is not sig:
-        try:
+        if not dev.is_inference():        # (inference-mode tensors carry no version counter: no shortcut for them)
             dev._kd_host = (sig, dev._version)
-        except Exception:                 # inference-mode tensors carry no version counter: no shortcut for them
-            pass
     return dev
 
 
 def _host_values(sigmas):
     """fp32 CPU copy of a schedule: the remembered one when the tensor still is what ``get_sigmas_*`` returned (same version: no
-    in-place edit since), else one device->host transfer."""
+    in-place edit since), else one device->host transfer.  LIMIT: the version counter is what tells an edit.  Writes that bypass it --
+    ``sigmas.data[i] = v``, a custom kernel or any write through the raw pointer -- are not seen, and the sampler would step with the
+    schedule as ``get_sigmas_*`` returned it; edit schedules with ordinary tensor ops (or pass a fresh tensor)."""
     kept = getattr(sigmas, '_kd_host', None)
-    if kept is not None:
-        try:
-            if kept[1] == sigmas._version and kept[0].shape == sigmas.shape and kept[0].dtype == torch.float32:
-                return kept[0]
-        except Exception:
-            pass
+    if kept is not None and not sigmas.is_inference() and kept[1] == sigmas._version and kept[0].shape == sigmas.shape \
+            and kept[0].dtype == torch.float32:
+        return kept[0]
     return sigmas.detach().to('cpu', torch.float32)
 
 

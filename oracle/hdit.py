@@ -10,6 +10,7 @@ All attention variants use the heads-last layout ``[n, h, w, nh, e]``
 (image_transformer_v2.py:422); q/k/v are views of the qkv projection output whose feature index
 is ``t*(nh*e) + head*e + e_idx`` (``:386, :422, :431, :467``).
 """
+import contextlib
 import math
 
 import torch
@@ -207,6 +208,58 @@ def attn_shifted_window(q, k, v, window_size, shift, scale=1.0):
     return out.view(n, h, w, nh, e)
 
 
+# ----------------------------------------------------------------------------- fp8 arithmetic mode (no reference counterpart)
+# Restates the arithmetic csrc/gemm_mx8.hip defines (kd_gemm_mx8 / kd_pack_weight_mx8): OCP e4m3 values with power-of-two scales -- one per
+# output channel for weights (checkpoint.quantize_fp8's rule), one per (row, 32-k block) for activations (OCP microscaling, E8M0 scale byte).
+
+FP8_MAX = 448.0
+MX8_WIDTHS = (256, 512)     # K of the norm -> projection products the fp8 mode takes
+
+
+def mx8_scale(amax):
+    """Smallest power of two >= amax / 448 (exponent byte clamped to [1, 253]), from the bits of the fp32 quotient like the kernel."""
+    r = (amax.to(torch.float32) / FP8_MAX).contiguous()
+    byte = ((r.view(torch.int32) + 0x7FFFFF) >> 23).clamp(1, 253)
+    return torch.ldexp(torch.ones_like(r), byte - 127)
+
+
+def mx8_quantize_rows(u):
+    """u [..., K] fp32, K % 32 == 0 -> the fp32 value of its microscaled e4m3 storage: per 32-k block, scale = mx8_scale(max |u|)."""
+    shape = u.shape
+    b = u.to(torch.float32).reshape(*shape[:-1], shape[-1] // 32, 32)
+    s = mx8_scale(b.abs().amax(dim=-1, keepdim=True))
+    return ((b / s).to(torch.float8_e4m3fn).to(torch.float32) * s).reshape(shape)
+
+
+def mx8_quantize_weight(w):
+    """W [N, K] fp32 -> the fp32 value of its e4m3 storage with one power-of-two scale per output channel."""
+    s = mx8_scale(w.abs().amax(dim=1, keepdim=True))
+    return (w.to(torch.float32) / s).to(torch.float8_e4m3fn).to(torch.float32) * s
+
+
+MX8 = False     # inside ``with mx8_arithmetic():`` the norm -> qkv / norm -> GEGLU products of the MX8_WIDTHS levels use the arithmetic above
+
+
+@contextlib.contextmanager
+def mx8_arithmetic(on=True):
+    global MX8
+    saved, MX8 = MX8, bool(on)
+    try:
+        yield
+    finally:
+        MX8 = saved
+
+
+def norm_linear(x, cond, w_norm, w):
+    """AdaRMSNorm -> Linear (:370-372, :487-489).  With MX8 on and the width taken by the fp8 mode: the kernel's order of operations --
+    u = x * scale quantised per block, exact products with the quantised weight, the RMS row factor of the UNQUANTISED row afterwards."""
+    if not (MX8 and x.shape[-1] in MX8_WIDTHS):
+        return ada_rms_norm(x, cond, w_norm) @ w.T
+    scale = (cond @ w_norm.T)[:, None, None, :] + 1
+    rs = torch.rsqrt(x.float().square().mean(dim=-1, keepdim=True) + EPS)
+    return (mx8_quantize_rows(x * scale) @ mx8_quantize_weight(w).T) * rs
+
+
 # ----------------------------------------------------------------------------- blocks
 
 def self_attention_block(sd, prefix, spec, layer_index, x, pos, cond):
@@ -214,8 +267,7 @@ def self_attention_block(sd, prefix, spec, layer_index, x, pos, cond):
     attention(scale=1.0) -> out_proj -> + skip."""
     skip = x
     n_heads = x.shape[-1] // spec.get("d_head", 64)
-    x = ada_rms_norm(x, cond, sd[prefix + "norm.linear.weight"])
-    qkv = x @ sd[prefix + "qkv_proj.weight"].T
+    qkv = norm_linear(x, cond, sd[prefix + "norm.linear.weight"], sd[prefix + "qkv_proj.weight"])
     q, k, v = split_qkv(qkv, n_heads)
     q, k = cosine_sim_scale(q, k, sd[prefix + "scale"])
     theta = rope_theta(pos, sd[prefix + "pos_emb.freqs"])
@@ -236,8 +288,9 @@ def self_attention_block(sd, prefix, spec, layer_index, x, pos, cond):
 
 def feed_forward_block(sd, prefix, x, cond):
     """:487-493."""
-    h = ada_rms_norm(x, cond, sd[prefix + "norm.linear.weight"])
-    h = linear_geglu(h, sd[prefix + "up_proj.weight"])
+    h = norm_linear(x, cond, sd[prefix + "norm.linear.weight"], sd[prefix + "up_proj.weight"])
+    d = h.shape[-1] // 2
+    h = h[..., :d] * F.gelu(h[..., d:])                       # linear_geglu (:89-95) on the projection above
     return h @ sd[prefix + "down_proj.weight"].T + x
 
 

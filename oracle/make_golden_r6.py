@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Round-6 additions to the golden vectors, recorded from the REAL reference (build container only):
+
+    python -m oracle.make_golden_r6 [demo] [headline] [headline_bf16] [fp8]
+
+  tests/golden/samples_r6_demo.safetensors   (part "demo")
+      demo_tiny_sw_cfg3_2msde_heun8 /     the SECOND caller of the hot path, exactly as /root/reference/train.py:333-369 runs it on a
+      demo_cifar_cfg3_2msde_heun50        class-conditional model: ``sample_dpmpp_2m_sde(make_cfg_model_fn(model), x, sigmas,
+                                          extra_args={'class_cond': c}, eta=0.0, solver_type='heun')`` with cfg_scale 3.  The guidance
+                                          wrapper is a closure inside train.py's main() and cannot be imported: its FunctionDef is cut out
+                                          of /root/reference/train.py with ``ast`` at generation time and executed over (torch,
+                                          num_classes, cfg_scale) -- the reference's own statements, not a transcription.  With eta = 0 no
+                                          noise is drawn; the sampler still constructs its default BrownianTreeNoiseSampler, for which
+                                          ``torchsde.BrownianTree`` (absent) is replaced by oracle.brownian.OracleBrownianTree as in round 3.
+      demo_tiny_sw_cfg3_fwd               one call of the wrapped denoiser (sigma 2.0 / 0.3): pins the wrapper alone.
+  tests/golden/samples_r6.safetensors        (parts "headline", "headline_bf16")
+      smp32_flowers_na_2m50               THE HEADLINE at its own size: config_oxford_flowers.json, sample_dpmpp_2m x 50, batch 32, fp32,
+                                          images cases.B32_KEEP kept.  The file's metadata records the reference's own wall time for this
+                                          run (seconds, threads, torch version, host CPU): bench.py quotes it as the CPU reference figure.
+      smp32_flowers_na_2m50_bf16          the same run with the reference's denoiser under torch.autocast("cpu", bfloat16).
+  tests/golden/forward_fp8.safetensors       (part "fp8")
+      fwd_cifar.denoised / fwd_flowers_na.denoised /      the fp8 ARITHMETIC mode's golden (BASELINE configs[4] "fp8 MFMA weights"; no reference
+      smp_cifar_heun50 / smp_flowers_na_sde50_fp8         counterpart: convert_for_inference.py:23): the REFERENCE's own modules with a quantising hook --
+                                                          every qkv_proj / up_proj Linear whose input width the mode takes (256, 512) gets its weight
+                                                          replaced by its e4m3 / power-of-two-per-channel value (checkpoint.quantize_fp8's rule) and a
+                                                          forward pre-hook that rounds its input to e4m3 with one power-of-two scale per 32-k block
+                                                          (oracle.hdit.mx8_quantize_rows) -- fp32 arithmetic everywhere else.  Same inputs as the fp32
+                                                          cases of the same names (cases.FORWARD_CASES / SAMPLE_CASES / SDE_FULL_CASE); the SDE run on
+                                                          the fp8-stored weights of round 3 (checkpoint.fp8_state_dict) with the oracle's Brownian tree.
+Parts not named on the command line keep what the existing files hold.  The earlier files are not touched.
+"""
+import ast
+import os
+import platform
+import sys
+import time
+
+import torch
+from safetensors import safe_open
+from safetensors.torch import load_file, save_file
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+from oracle import make_golden as mg  # noqa: E402  (imports the reference)
+from oracle import brownian as obrown  # noqa: E402
+from oracle import ref_import  # noqa: E402
+from tests.golden import cases  # noqa: E402
+
+K = mg.K
+S = K.sampling
+
+
+def reference_cfg_wrapper(num_classes, cfg_scale):
+    """``make_cfg_model_fn`` of /root/reference/train.py:333-344, cut out of the reference's source and executed as written."""
+    path = os.path.join(ref_import.REFERENCE_ROOT, "train.py")
+    tree = ast.parse(open(path).read())
+    fn = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "make_cfg_model_fn")
+    ns = {"torch": torch, "num_classes": num_classes, "cfg_scale": cfg_scale}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    return ns["make_cfg_model_fn"]
+
+
+def demo_cases():
+    out = {}
+    S.torchsde.BrownianTree = obrown.OracleBrownianTree        # constructed by sample_dpmpp_2m_sde, never queried at eta = 0
+    for case, cfgname, steps, batch in cases.DEMO_CASES:
+        t0 = time.time()
+        cfg, model = mg.build_reference_model(cfgname)
+        mc = cfg["model"]
+        nc = cases.num_classes_of(cfg)
+        den = K.Denoiser(model, sigma_data=mc["sigma_data"])
+        fn = reference_cfg_wrapper(nc, cases.DEMO_CFG_SCALE)(den)
+        assert fn is not den
+        x, cls = cases.sample_inputs(cfg, batch)
+        sigmas = S.get_sigmas_karras(steps, mc["sigma_min"], mc["sigma_max"], rho=7.)
+        y = S.sample_dpmpp_2m_sde(fn, x, sigmas, extra_args={"class_cond": cls}, eta=0.0, solver_type="heun", disable=True)   # train.py:362
+        out[case] = y
+        print(f"{case}: |y|max {y.abs().max():.4f}  {time.time() - t0:.1f}s", flush=True)
+        if cfgname == "tiny_sw":
+            sig = torch.tensor(cases.DEMO_FWD_SIGMAS[:batch])
+            out["demo_tiny_sw_cfg3_fwd"] = fn(x, sig, class_cond=cls)
+    return out
+
+
+def install_mx8_hooks(model):
+    """The quantising hook of the fp8 golden: weights fake-quantised in place, inputs of the taken Linears rounded per 32-k block."""
+    from oracle import hdit
+    n = 0
+    for name, mod in model.named_modules():
+        # (the mapping network's own up_proj is part of the per-sample conditioning chain, which stays fp32 in every mode)
+        if name.endswith((".qkv_proj", ".up_proj")) and not name.startswith("mapping.") and getattr(mod, "weight", None) is not None \
+                and mod.weight.shape[1] in hdit.MX8_WIDTHS:
+            mod.weight.data = hdit.mx8_quantize_weight(mod.weight.data)
+            mod.register_forward_pre_hook(lambda m, args: (hdit.mx8_quantize_rows(args[0]),) + tuple(args[1:]))
+            n += 1
+    return n
+
+
+def fp8_cases():
+    out = {}
+    for case, cfgname, batch, sigmas in cases.FORWARD_CASES:
+        if case not in cases.FP8_FORWARD_CASES:
+            continue
+        t0 = time.time()
+        cfg, model = mg.build_reference_model(cfgname)
+        n = install_mx8_hooks(model)
+        den = K.Denoiser(model, sigma_data=cfg["model"]["sigma_data"])
+        x, sigma, cls = cases.forward_inputs(cfg, batch, sigmas)
+        kw = {"class_cond": cls} if cls is not None else {}
+        with torch.no_grad():
+            out[case + ".denoised"] = den(x, sigma, **kw)
+        print(f"{case} [fp8 hooks on {n} projections]: {time.time() - t0:.1f}s", flush=True)
+    for case, cfgname, sampler, steps, batch in cases.SAMPLE_CASES:
+        if case not in cases.FP8_SAMPLE_CASES:
+            continue
+        t0 = time.time()
+        cfg, model = mg.build_reference_model(cfgname)
+        install_mx8_hooks(model)
+        mc = cfg["model"]
+        den = K.Denoiser(model, sigma_data=mc["sigma_data"])
+        x, cls = cases.sample_inputs(cfg, batch)
+        extra = {"class_cond": cls} if cls is not None else {}
+        sigmas = S.get_sigmas_karras(steps, mc["sigma_min"], mc["sigma_max"], rho=7.)
+        out[case] = getattr(S, sampler)(den, x, sigmas, extra_args=extra, disable=True)
+        print(f"{case} [fp8]: |y|max {out[case].abs().max():.4f}  {time.time() - t0:.1f}s", flush=True)
+    if cases.FP8_SDE:
+        case, cfgname, sampler, steps, batch = cases.SDE_FULL_CASE
+        t0 = time.time()
+        cfg, model = mg.build_reference_model(cfgname)
+        checkpoint = __import__("importlib").import_module("k-diffusion_amd.checkpoint")
+        model.load_state_dict(checkpoint.fp8_state_dict(model.state_dict()))
+        install_mx8_hooks(model)
+        mc = cfg["model"]
+        den = K.Denoiser(model, sigma_data=mc["sigma_data"])
+        x, cls = cases.sample_inputs(cfg, batch)
+        sigmas = S.get_sigmas_karras(steps, mc["sigma_min"], mc["sigma_max"], rho=7.)
+        S.torchsde.BrownianTree = obrown.OracleBrownianTree
+        ns = S.BrownianTreeNoiseSampler(x, sigmas[sigmas > 0].min(), sigmas.max(), seed=cases.sde_brownian_seeds(batch))
+        out[case + "_fp8"] = getattr(S, sampler)(den, x, sigmas, disable=True, noise_sampler=ns)
+        print(f"{case}_fp8: |y|max {out[case + '_fp8'].abs().max():.4f}  {time.time() - t0:.1f}s", flush=True)
+    return out
+
+
+def headline(bf16):
+    case, cfgname, sampler, steps, batch = cases.HEADLINE_CASE
+    cfg, model = mg.build_reference_model(cfgname)
+    mc = cfg["model"]
+    den = K.Denoiser(model, sigma_data=mc["sigma_data"])
+    x, cls = cases.sample_inputs(cfg, batch)
+    extra = {"class_cond": cls} if cls is not None else {}
+    sigmas = S.get_sigmas_karras(steps, mc["sigma_min"], mc["sigma_max"], rho=7.)
+
+    def den_bf16(xx, ss, **kw):
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            return den(xx, ss, **kw).float()
+    t0 = time.time()
+    y = getattr(S, sampler)(den_bf16 if bf16 else den, x, sigmas, extra_args=extra, disable=True)
+    dt = time.time() - t0
+    tag = "_bf16" if bf16 else ""
+    print(f"{case}{tag}: |y|max {y.abs().max():.4f}  {dt:.1f}s  ({batch / dt:.4f} images/s on {torch.get_num_threads()} threads)", flush=True)
+    return {case + tag: y[cases.B32_KEEP]}, {f"reference_seconds{tag}": f"{dt:.2f}", f"reference_images_per_s{tag}": f"{batch / dt:.5f}"}
+
+
+def cpu_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def merge_save(path, new, meta_new):
+    old, meta = {}, {}
+    if os.path.exists(path):
+        old = load_file(path)
+        with safe_open(path, "pt") as f:
+            meta = dict(f.metadata() or {})
+    old.update({k: v.detach().contiguous() for k, v in new.items()})
+    meta.update(meta_new)
+    save_file(old, path, metadata=meta)
+
+
+def main(argv):
+    parts = argv or ["demo", "headline", "headline_bf16", "fp8"]
+    torch.set_num_threads(os.cpu_count())
+    gd = cases.GOLDEN_DIR
+    meta = {"generator": "oracle/make_golden_r6.py", "torch": torch.__version__,
+            "reference": "crowsonkb/k-diffusion @ /root/reference (v0.2.0.dev0)"}
+    if "demo" in parts:
+        merge_save(os.path.join(gd, "samples_r6_demo.safetensors"), demo_cases(), meta)
+    if "fp8" in parts:
+        merge_save(os.path.join(gd, "forward_fp8.safetensors"), fp8_cases(), meta)
+    host = {"threads": str(torch.get_num_threads()), "cpu_count": str(os.cpu_count()), "cpu": cpu_name(),
+            "workload": "config_oxford_flowers.json 256x256, k_diffusion.sampling.sample_dpmpp_2m x 50, batch 32, fp32, the reference's own "
+                        "modules on the CPU (neighbourhood attention through the restated na2d: NATTEN is absent)"}
+    for part, bf16 in (("headline", False), ("headline_bf16", True)):
+        if part in parts:
+            out, timing = headline(bf16)
+            merge_save(os.path.join(gd, "samples_r6.safetensors"), out, {**meta, **host, **timing})
+    for f in sorted(os.listdir(gd)):
+        print(f, os.path.getsize(os.path.join(gd, f)))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -14,11 +14,12 @@ sample.py:59-60, and therefore cannot run its own class-conditional configs):
   --class-cond C       class id for every image (-1: image index mod num_classes) for class-conditional configs
   --random-weights     no checkpoint: synthetic weights (K.synth), for smoke runs and benchmarking
   --no-png             skip PNG encoding (timing runs)
-  --noise device|host  where --seed's per-image noise is drawn.  device (default): the keyed Philox generator of the HIP library
-                       (kd_randn_f32; seed, global index, draw number -> values), no host work at all -- also for the ancestral samplers'
-                       per-step noise; host: one CPU torch.Generator per global image index (K.synth.synth_noise: the recipe of the
-                       committed fixtures), drawn by worker threads AHEAD of the sampler and handed over as an asynchronous pinned copy on a
-                       side stream, so the draw runs beside the previous batch's GPU pass
+  --noise host|device  where --seed's per-image noise is drawn.  host (default: what --seed S has always produced, and the recipe of the
+                       committed fixtures): one CPU torch.Generator per global image index (K.synth.synth_noise), drawn by worker threads
+                       AHEAD of the sampler and handed over as an asynchronous pinned copy on a side stream, so the draw runs beside the
+                       previous batch's GPU pass (job rate = loop rate, bench.py --job); device: the keyed Philox generator of the HIP
+                       library (kd_randn_f32; seed, global index, draw number -> values), no host work at all -- also for the ancestral
+                       samplers' per-step noise; other images than host, reproducible to ~1e-5 across GPU generations (hardware log2 / cos)
   --gather-uint8       8-bit conversion on the GPU before the all-gather of finished images (same PNG bytes, 4x less xGMI traffic).
                        The DEFAULT whenever there is a gather (more than one process) and PNG files are written -- the writer needs
                        nothing else; --gather-fp32 keeps the reference's fp32 gather (main() then returns fp32 images)
@@ -52,8 +53,9 @@ def parse(argv=None):
     p.add_argument('--class-cond', type=int, default=None, help='class id for all images; -1 = index mod num_classes')
     p.add_argument('--random-weights', action='store_true', help='synthetic weights instead of a checkpoint')
     p.add_argument('--no-png', action='store_true', help='do not write PNG files')
-    p.add_argument('--noise', choices=['device', 'host'], default='device',
-                   help="where --seed's per-image noise is drawn: the library's keyed device generator (default) or per-image CPU generators ahead of the sampler")
+    p.add_argument('--noise', choices=['device', 'host'], default='host',
+                   help="where --seed's per-image noise is drawn: per-image CPU generators ahead of the sampler (default: the recipe of every earlier "
+                        "round and of the committed fixtures) or the library's keyed device generator")
     p.add_argument('--gather-uint8', action='store_true',
                    help='convert finished images to uint8 on the GPU before the all-gather (what the PNG writer needs; 4x less xGMI traffic)')
     p.add_argument('--gather-fp32', action='store_true', help='all-gather the finished images as fp32 even when only PNG files are wanted')

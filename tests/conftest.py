@@ -21,7 +21,7 @@ def golden():
     gd = cases.GOLDEN_DIR
     out = {"kat": json.load(open(os.path.join(gd, "kat.json")))}
     out["kat2"] = json.load(open(os.path.join(gd, "kat2.json")))
-    for name in ("ops", "forward", "samples", "forward_b32", "forward_b32_bf16", "forward_bf16", "samples_bf16", "samples_r3", "samples_r4", "samples_r5"):
+    for name in ("ops", "forward", "samples", "forward_b32", "forward_b32_bf16", "forward_bf16", "samples_bf16", "samples_r3", "samples_r4", "samples_r5", "samples_r6", "samples_r6_demo", "forward_fp8"):
         out[name] = load_file(os.path.join(gd, name + ".safetensors"))
     return out
 

@@ -109,6 +109,25 @@ SAMPLE_B64_CASE = ("smp64_cifar_heun50", "cifar", "sample_heun", 50, 64)
 B64_KEEP = [0, 13, 37, 63]
 
 
+# round 6 ------------------------------------------------------------------------------------------------
+# The headline at its own size: config_oxford_flowers.json, sample_dpmpp_2m x 50, batch 32 (fp32 and autocast(bfloat16)); images B32_KEEP kept.
+# Recorded by oracle/make_golden_r6.py (samples_r6.safetensors; its metadata holds the reference's own wall time on the build container's cores).
+HEADLINE_CASE = ("smp32_flowers_na_2m50", "flowers_na", "sample_dpmpp_2m", 50, 32)
+# The second caller of the path (train.py:333-369): sample_dpmpp_2m_sde(make_cfg_model_fn(model), ..., eta=0, solver_type='heun') with
+# classifier-free guidance on class-conditional models: (case, config, steps, batch).  samples_r6_demo.safetensors.
+DEMO_CFG_SCALE = 3.0
+DEMO_CASES = [
+    ("demo_tiny_sw_cfg3_2msde_heun8", "tiny_sw", 8, 2),
+    ("demo_cifar_cfg3_2msde_heun50", "cifar", 50, 4),
+]
+DEMO_FWD_SIGMAS = [2.0, 0.3]
+# The fp8 arithmetic mode's goldens (forward_fp8.safetensors): the reference with the quantising hook of oracle/make_golden_r6.py on the inputs /
+# weights of the projections the mode takes.  Same inputs as the fp32 cases of the same names.
+FP8_FORWARD_CASES = ["fwd_cifar", "fwd_flowers_na"]
+FP8_SAMPLE_CASES = ["smp_cifar_heun50"]
+FP8_SDE = True            # + SDE_FULL_CASE (configs[4]) on the fp8-stored weights: "smp_flowers_na_sde50_fp8"
+
+
 def sde_brownian_seeds(batch, seed=SDE_SEED):
     """One Brownian-tree seed per global image index: the rule of sample.py --seed (sample.brownian_seeds), restated here so that
     the golden script and the tests do not import the CLI."""

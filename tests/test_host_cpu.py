@@ -497,9 +497,9 @@ def test_option_sync_is_incremental():
         "nat.set_option('ffn_fused', 0)\n"
         "os.environ['KDIFF_OPTIONS'] = 'tiled_bm=128'\n"          # wstat disappears: default again; ffn_fused (programmatic) untouched
         "assert get('wstat', 1) == 1 and get('wstat', 5) == 5 and get('tiled_bm', 0) == 128 and get('ffn_fused', 1) == 0\n"
-        "os.environ['KDIFF_SKINNY'] = '0'\n"
+        "os.environ['KDIFF_OPTIONS'] = 'tiled_bm=128,skinny=0'\n"
         "assert get('skinny', 1) == 0 and get('ffn_fused', 1) == 0 and get('tiled_bm', 0) == 128\n"
-        "del os.environ['KDIFF_SKINNY']\n"
+        "os.environ['KDIFF_OPTIONS'] = 'tiled_bm=128'\n"
         "assert get('skinny', 1) == 1\n"
         "os.environ['KDIFF_OPTIONS'] = 'ffn_fused=1'\n"          # the environment names it anew: it wins again
         "assert get('ffn_fused', 0) == 1 and get('tiled_bm', 7) == 7\n"
@@ -666,6 +666,8 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
+    # what the driver reads: the line is the LAST thing on stdout, short enough for any tail, strict JSON; stderr stays quiet
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096 and len(r.stderr) < 2000, (len(lines[0]), r.stderr[-2000:])
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["data"] == "stub"
     assert line["config"]["nranks"] == 2 and line["config"]["backend"] == "gloo" and line["config"]["ranks_in_gather"] == [0, 1]
@@ -742,6 +744,37 @@ def test_oracle_index_addressed_normals():
     assert np.allclose(ob.randn_indexed([5], 64, scale=160.0)[0], 160.0 * z[0][:64], rtol=1e-6)
 
 
+def test_product_host_functions_bit_equal_the_reference_hex(KD, golden):
+    """The PRODUCT's host-side functions of the path -- K.sampling.get_sigmas_karras / _exponential / _polyexponential / _vp (sampling.py:17-43),
+    get_ancestral_step (:51-58), Denoiser.get_scalings (layers.py:70-74), make_axial_pos (axial_rope.py:60-68), the AxialRoPE frequency ladder
+    (image_transformer_v2.py:234-240) -- against the hex the REFERENCE produced (tests/golden/kat.json, oracle/make_golden.py): bit for bit,
+    directly (not through the oracle), no GPU."""
+    import struct
+    kat = golden["kat"]
+    unhex = lambda lst: torch.tensor([struct.unpack(">f", bytes.fromhex(h))[0] for h in lst], dtype=torch.float32)
+    bits = lambda t: torch.as_tensor(t, dtype=torch.float32).detach().contiguous().view(torch.int32).reshape(-1)
+    S = KD.sampling
+    for key, hx in kat["sigmas_karras"].items():
+        n, lo, hi, rho = key.split(",")
+        assert torch.equal(bits(S.get_sigmas_karras(int(n), float(lo), float(hi), float(rho))), bits(unhex(hx))), key
+    assert torch.equal(bits(S.get_sigmas_exponential(12, 0.01, 80)), bits(unhex(kat["sigmas_exponential"]["12,0.01,80"])))
+    assert torch.equal(bits(S.get_sigmas_polyexponential(12, 0.01, 80, 2.0)), bits(unhex(kat["sigmas_polyexponential"]["12,0.01,80,2.0"])))
+    assert torch.equal(bits(S.get_sigmas_vp(12)), bits(unhex(kat["sigmas_vp"]["12"])))
+    assert [f"{v & 0xffffffff:08x}" for v in bits(S.get_sigmas_karras(50, 1e-2, 80))[:3].tolist()] == ["429ffffe", "42902fec", "4281bbba"]     # SURVEY 8(a) a1
+    for key, hx in kat["ancestral_step"].items():
+        a, b, eta = (float(v) for v in key.split(","))
+        sd, su = S.get_ancestral_step(torch.tensor(a), torch.tensor(b), eta)
+        assert torch.equal(bits(torch.stack([torch.as_tensor(sd), torch.as_tensor(su)])), bits(unhex(hx))), key
+    den = KD.Denoiser(None, sigma_data=0.5)
+    for s, hx in kat["scalings_sd0.5"].items():
+        assert torch.equal(bits(torch.stack(den.get_scalings(torch.tensor(float(s))))), bits(unhex(hx))), s
+    for key, hx in kat["axial_pos"].items():
+        h, w = (int(v) for v in key.split("x"))
+        assert torch.equal(bits(KD.models.axial_rope.make_axial_pos(h, w)), bits(unhex(hx))), key
+    for nh, hx in kat["rope_freqs"].items():
+        assert torch.equal(bits(KD.models.axial_rope.rope_freqs(64, int(nh))), bits(unhex(hx))), nh
+
+
 def _load_bench():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(REPO, "bench.py"))
@@ -782,11 +815,12 @@ def test_bench_global_attention_block_figure_from_a_recorded_kernel_table(KD):
 
 
 def test_bench_throttle_accumulators_and_the_reading(monkeypatch):
-    """bench.py's `power` object: amd-smi's throttle accumulators are parsed from its JSON whatever the nesting, a missing tool gives None, and
+    """benchmarks/power_report.py (`bench.py --power`): amd-smi's throttle accumulators are parsed from its JSON whatever the nesting, a missing tool gives None, and
     the sentence it prints grades the power limiter's share of the ticks instead of asserting a cause."""
     import json
     import subprocess
-    bench = _load_bench()
+    sys.path.insert(0, os.path.join(REPO, "benchmarks"))
+    import power_report as bench                                   # (moved out of bench.py in round 6: opt-in `bench.py --power`)
     sample = {"gpu_data": [{"gpu": 0, "throttle": {"accumulation_counter": 1000, "prochot_accumulated": 0, "ppt_accumulated": {"value": 250, "unit": "ticks"},
                                                     "socket_thermal_accumulated": 0, "vr_thermal_accumulated": 0, "hbm_thermal_accumulated": 0,
                                                     "gfx_clk_below_host_limit_accumulated": "N/A"}}]}
@@ -805,6 +839,45 @@ def test_bench_throttle_accumulators_and_the_reading(monkeypatch):
         raise FileNotFoundError("amd-smi")
     monkeypatch.setattr(subprocess, "run", boom)
     assert bench.throttle_accumulators() is None and bench._smi("--showpower") == ""
+
+
+def test_bench_line_is_compact_and_the_long_form_goes_to_the_detail_file(tmp_path, capsys):
+    """The round-5 line was 21 KB with the contract's keys at the front, and the driver's tails cut them off (BENCH_r05.parsed == null).
+    bench.compact_line() turns that very result (profiles/r05_bench_line.json) into a line under 4 KiB that still carries every key the
+    contract names plus roofline / cpu_baseline / parity / mode_values; emit() prints it alone on stdout and writes the long form beside it."""
+    import json
+    bench = _load_bench()
+    big = json.load(open(os.path.join(REPO, "profiles", "r05_bench_line.json")))
+    assert len(json.dumps(big)) > 15000
+    detail = tmp_path / "bench_detail.json"
+    bench.emit(big, str(detail))
+    out = capsys.readouterr()
+    assert out.err == "" and out.out.count("\n") == 1
+    text = out.out.strip()
+    assert len(text) <= bench.LINE_LIMIT < 4096
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "parity", "mode_values"):
+        assert k in line, k
+    assert line["value"] == big["value"] and line["dtype"] == "f32" and "workload" in line["config"]
+    for k in ("bound", "kernel", "avg_launch_ms", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    assert line["roofline"]["frac"] == big["roofline"]["frac"] and line["roofline"]["traffic"] == big["roofline"]["traffic"]
+    assert {"split3", "bf16"} <= set(line["roofline"]["global_attention_block"])
+    assert line["roofline"]["global_attention_block"]["bf16"]["frac_of_bf16_mfma_peak"] == big["modes"]["bf16"]["roofline"]["global_attention_block"]["frac_of_bf16_mfma_peak"]
+    assert {"value", "unit", "cores", "kind"} <= set(line["cpu_baseline"]) and line["parity"]["pass"] is True
+    assert line["detail_file"] == "bench_detail.json" and json.load(open(detail)) == big
+    # however long the strings of a result get, the line stays under the limit (optional parts go first, never the contract's keys)
+    fat = json.loads(json.dumps(big))
+    fat["config"]["workload"] = "w" * 5000
+    fat["cpu_baseline"]["sample"] = "s" * 5000
+    fat["parity"]["case"] = "c" * 5000
+    fat["mode_values"] = {f"mode{i}": 1.0 for i in range(400)}
+    slim = bench.compact_line(fat, str(detail))
+    assert len(json.dumps(slim)) <= bench.LINE_LIMIT and slim["value"] == big["value"] and "roofline" in slim and "cpu_baseline" in slim
+    # an unwritable detail file costs nothing but the file
+    bench.emit(big, str(tmp_path / "no" / "such" / "dir" / "d.json"))
+    assert "detail_file" not in json.loads(capsys.readouterr().out)
 
 
 def test_bench_optional_blocks_never_cost_the_line(monkeypatch):
