@@ -7,7 +7,7 @@
 //                channel -- exactly checkpoint.quantize_fp8, so an fp8 checkpoint's weights enter the instruction bit for bit;
 //   activations  u = x * s (x the bf16 residual row, s the sample's fp32 AdaRMSNorm scale vector) is quantised per (row, 32-k block):
 //                u[b] = 2^E_b * q_b, E_b = ceil(log2(max|u[b]| / 448)) from the fp32 quotient's bits (no saturation: |q| <= 448), q OCP e4m3
-//                (RNE) -- the OCP microscaling layout the instruction takes natively: one E8M0 scale byte per lane's 32 values;
+//                (RNE) -- OCP microscaling, which the instruction takes natively: one E8M0 scale byte per (row, 32-k block);
 //   products     exact in the instruction, fp32 accumulation; the RMS row factor rsqrt(mean(x^2) + eps) (fp32 statistics of the UNQUANTISED
 //                row) multiplies the accumulators in the epilogue, which is gemm_bf16.hip's (cosine-sim norm, RoPE, GELU in fp32).
 //
@@ -17,8 +17,8 @@
 // k-step of 64 is ONE instruction per 32-feature group (8 per block, 64 cycles each) fed by two ds_read_b128.
 //
 // Packed image (kd_pack_weight_mx8): blocks [n-tile][k / 128] of 16 KiB, inside a block the 16-byte piece (feature group j of 32, k-step ks
-// of 64, half h of a lane's 32 bytes, lane half lh = 32-k block, feature l31) at ((((j * 2 + ks) * 2 + h) * 2 + lh) * 32 + l31) * 16: every
-// ds_read_b128 of a W fragment half covers one contiguous KiB.  Behind the blocks: one E8M0 byte per tile row, [n-tile][l31][j].
+// of 64, 32-k block h of the step = half h of a lane's 32 bytes, lane half lh = which 16 k of that block, feature l31) at
+// ((((j * 2 + ks) * 2 + h) * 2 + lh) * 32 + l31) * 16: every ds_read_b128 of a W fragment half covers one contiguous KiB.  Behind the blocks: one E8M0 byte per tile row, [n-tile][l31][j].
 // GEGLU tiles interleave 32 value rows with their 32 gate rows like the bf16 image (bf16_common.h: w_row_of_tile).
 #include "bf16_common.h"
 
@@ -95,8 +95,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_astat_kernel(const MArgs p) {
   const int row = m0 + wid * 32 + l31;
   const bool ok = row < p.M;
   const int rowc = ok ? row : p.M - 1;
-  i32x8 a[NK64];                                       // this lane's row, 32-k block 2 ks + lh of every 64-wide k-step: 32 e4m3 bytes each
-  int asc[NK64];                                       // ... and the block's E8M0 byte in all four byte lanes (any op_sel reads it)
+  // The instruction's operand layout, found by experiment (benchmarks/probe/mx8_probe.cpp, profiles/r06_mx8_probe.log): lane (row, lh) holds,
+  // of a 64-wide k-step, bytes 0-15 = k 16 lh .. 16 lh + 15 of the step's FIRST 32-k block and bytes 16-31 = the same k of its SECOND block;
+  // block b's E8M0 byte is read from the scale register of lane (row, lh = b); op_sel picks the byte of that register.
+  i32x8 a[NK64];                                       // this lane's 2 x 16 e4m3 values of every 64-wide k-step
+  int asc[NK64];                                       // ... and the E8M0 byte of block lh of the step, in all four byte lanes (any op_sel reads it)
   float rs;
   {
     // rows: HBM -> the ring slot this wave borrows (whole rows by LDS-DMA) -> this lane's 64-byte pieces; the sample's scale vector -> LDS
@@ -134,7 +137,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_astat_kernel(const MArgs p) {
 #pragma unroll
         for (int ks = 0; ks < NK64; ++ks)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) raw[ks][u] = *reinterpret_cast<const u32x4*>(rowp + (((8 * ks + 4 * lh + u) ^ (rr & 15)) << 4));
+          for (int u = 0; u < 4; ++u)       // u = 2 * block + piece: 8 k of block (u >> 1), k = 16 lh + 8 (u & 1) .. inside it
+            raw[ks][u] = *reinterpret_cast<const u32x4*>(rowp + (((8 * ks + 4 * (u >> 1) + 2 * lh + (u & 1)) ^ (rr & 15)) << 4));
       }
       if (NR > 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -143,10 +147,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_astat_kernel(const MArgs p) {
 #pragma unroll
     for (int ks = 0; ks < NK64; ++ks) {
       float y[32];
-      float amax = 0.f;
+      float amax[2] = {0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int k0 = 64 * ks + 32 * lh + 8 * u;
+        const int k0 = 64 * ks + 32 * (u >> 1) + 16 * lh + 8 * (u & 1);
         const f32x4 s0 = *reinterpret_cast<const f32x4*>((uni ? spl : sp) + k0), s1 = *reinterpret_cast<const f32x4*>((uni ? spl : sp) + k0 + 4);
         float x[8];
 #pragma unroll
@@ -156,22 +160,29 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_astat_kernel(const MArgs p) {
           ssq = fmaf(x[e], x[e], ssq);
           const float v = x[e] * (e < 4 ? s0[e] : s1[e - 4]);
           y[8 * u + e] = v;
-          amax = fmaxf(amax, fabsf(v));
+          amax[u >> 1] = fmaxf(amax[u >> 1], fabsf(v));
         }
       }
-      const unsigned sb = mx_scale_byte(amax);
-      const float inv = mx_inv_scale(sb);
+      // a 32-k block lives in BOTH lanes of a row (16 values each): its maximum is the larger of the two halves'
+      unsigned sb[2];
+      float inv[2];
+#pragma unroll
+      for (int bk = 0; bk < 2; ++bk) {
+        amax[bk] = fmaxf(amax[bk], __shfl_xor(amax[bk], 32, 64));
+        sb[bk] = mx_scale_byte(amax[bk]);
+        inv[bk] = mx_inv_scale(sb[bk]);
+      }
       i32x8 f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) {
         int pk = 0;
-        pk = __builtin_amdgcn_cvt_pk_fp8_f32(y[4 * w] * inv, y[4 * w + 1] * inv, pk, false);
-        pk = __builtin_amdgcn_cvt_pk_fp8_f32(y[4 * w + 2] * inv, y[4 * w + 3] * inv, pk, true);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(y[4 * w] * inv[w >> 2], y[4 * w + 1] * inv[w >> 2], pk, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(y[4 * w + 2] * inv[w >> 2], y[4 * w + 3] * inv[w >> 2], pk, true);
         f[w] = pk;
       }
       asm volatile("" : "+v"(f));                      // materialise the fragment here (see gemm_astat_kernel)
       a[ks] = f;
-      asc[ks] = (int)(sb * 0x01010101u);
+      asc[ks] = (int)((lh ? sb[1] : sb[0]) * 0x01010101u);      // block b's byte is read from the lane half b of the row
       __builtin_amdgcn_sched_barrier(0);
     }
     ssq += __shfl_xor(ssq, 32, 64);
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(64) void pack_weight_mx8_kernel(const float* __rest
     int pk = 0;
     pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], pk, false);
     pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
-    const int kb = k4 >> 7, ks = (k4 >> 6) & 1, lh = (k4 >> 5) & 1, h = (k4 >> 4) & 1, byte = k4 & 15;
+    const int kb = k4 >> 7, ks = (k4 >> 6) & 1, h = (k4 >> 5) & 1, lh = (k4 >> 4) & 1, byte = k4 & 15;      // h = 32-k block of the step, lh = its half
     const size_t off = ((size_t)nt * nkb + kb) * WBLK + ((((j * 2 + ks) * 2 + h) * 2 + lh) * 32 + l31) * 16 + byte;
     *reinterpret_cast<int*>(out + off) = pk;
   }

@@ -17,19 +17,16 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int WAVE = 64;
 
-// 16-byte store of a kernel's RESULT rows.  Build with -DKD_WT_STORES=1 for the write-through form (`sc1`): the bytes leave the XCD's L2 while
-// the kernel is still running, so the write-back at the kernel boundary -- which costs (dirty bytes) / ~6 TB/s before the next dependent launch
-// may start (MI355X_MICROARCH.md, "boundary") -- finds nothing left to do.  The consumer is always the NEXT launch, which does not find the
-// producer's lines in its L2 either way.  The asm form is not counted by hipcc's vmcnt bookkeeping: vector memory operations retire in order on
-// gfx9, so an uncounted store only makes the compiler's later waits conservative; `s_nop 1` keeps the data registers intact until read.
+// 16-byte store of a kernel's RESULT rows.  Round 6 tried the write-through form here (`global_store_dwordx4 ... sc1`: the bytes leave the
+// XCD's L2 while the kernel runs, so that the write-back at the kernel boundary -- (dirty bytes) / ~6 TB/s before the next dependent launch
+// starts, MI355X_MICROARCH.md "boundary" -- finds nothing to do).  Same box, interleaved with the plain build: fp32-parity 212.1 / 213.1 ->
+// 208.7 / 210.7 images/s, bf16 429.0 / 430.0 -> 367.8 / 366.9 (-14.5 %): a write-through store DROPS the line from the L2, and the next launch
+// of a layer re-reads most of what its predecessor wrote on the same XCD (the panel / tile placements are XCD-aware for exactly that reason).
+// The boundary's write-back is the cheaper side of that trade.  Plain stores it is (profiles/r06_wt_stores.md).
 template <class V>
 __device__ __forceinline__ void st16(void* p, const V& v) {
   static_assert(sizeof(V) == 16, "st16: 16-byte vectors");
-#if KD_WT_STORES
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#else
   *reinterpret_cast<V*>(p) = v;
-#endif
 }
 
 // the public descriptor plus what only the library sets (kept out of the ABI)

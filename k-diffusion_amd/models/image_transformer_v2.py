@@ -455,10 +455,12 @@ class _Plan:
                 # projection's, its C the attention output
                 # From 32 (sample, head) workgroups on: below that (batch 1 - 2 at level 2) the few-rows projection + the dense core are faster
                 # (0.514 against 0.543 ms per forward at batch 1; from batch 4 on the one-launch form wins: profiles/r05_attn_block.md)
-                qkv_mx8 = mx8_ok(T, 3 * d, d, nat.EPI_QKV)
-                fused_block = bf and not qkv_mx8 and isinstance(spec, GlobalAttentionSpec) and target is self.launches and T % 256 == 0 \
+                fused_block = bf and isinstance(spec, GlobalAttentionSpec) and target is self.launches and T % 256 == 0 \
                     and os.environ.get("KDIFF_ATTN_BLOCK", "1") != "0" and bool(lib.kd_attn_block_bf16_supported(rps, d, nh)) \
                     and (B * nh >= 32 or os.environ.get("KDIFF_ATTN_BLOCK", "1") == "force")
+                # fp8 mode: the qkv projection on the fp8 matrix instruction -- except where the one-launch bf16 attention block takes the layer
+                # (level 2 of the 256 x 256 configs: 25.5 us against 25.6 + 13.6 us for fp8 projection + dense core, profiles/r06_fp8_mode.md)
+                qkv_mx8 = not fused_block and mx8_ok(T, 3 * d, d, nat.EPI_QKV)
                 if fused_block:
                     dq = gemm(prefix + "attn_block", x, sa.qkv_proj.weight, att, T, 3 * d, d, epi=nat.EPI_QKV,
                               scale_ptr=scale_ptr(prefix + "self_attn.norm"), scale_stride=total, rows_per_sample=rps, qk=qk)
