@@ -230,18 +230,22 @@ struct NaGeo {
   static constexpr int PW = (8 + KS - 1 <= 16) ? 16 : 32;                    // patch width (keys per patch row)
   static constexpr int NKT = (PR * PW + 31) / 32;                            // key tiles per wave
   // image rows: a wave's patch may poke past the halo's last key -- the highest row any fragment read touches is
-  // (HR - 1) HC + (HC - (8 + KS - 1)) + 15 = HR HC - KS + 8.  Kept tight: at KS = 7 the two images take 78 KiB, TWO workgroups per CU
+  // (HR - 1) HC + (HC - (8 + KS - 1)) + 15 = HR HC - KS + 8.  Kept tight: at KS = 7 the image takes 39 KiB (round 6: one image for K, then V), THREE workgroups per CU
   static constexpr int ROWS = ((HR * HC - KS + 9 + 7) / 8) * 8;
-  static constexpr int LDS = 2 * ROWS * 128;
+  static constexpr int LDS = ROWS * 128;                                     // ONE image: K, then V
 };
 
+// Round 6: K and V go through ONE image -- the V rows are requested behind the barrier that ends the score MFMAs and land behind the
+// softmax -- so a workgroup holds 39 KiB instead of 78 (KS = 7) and THREE of them fit a CU (150 registers): a workgroup is a serial chain
+// "wait for the halo -> scores -> softmax -> PV -> stores" whose wait nobody but the CU's other workgroups can cover.  Same box, same
+// run: level 0 33.5 -> 30.95 us, level 1 20.5 -> 18.7 us, bf16 mode 443.4 -> 447.4 images/s (two images, two workgroups per CU before).
 template <int KS>
-__global__ __launch_bounds__(256, (NaGeo<KS>::LDS <= 80 * 1024) ? 2 : 1) void attn_na2d_bf16_kernel(const NArgs a) {
+__global__ __launch_bounds__(256, NaGeo<KS>::LDS <= 53 * 1024 ? 3 : 2) void attn_na2d_bf16_kernel(const NArgs a) {
   using G = NaGeo<KS>;
   constexpr int HR = G::HR, HC = G::HC, PR = G::PR, PW = G::PW, NKT = G::NKT, ROWS = G::ROWS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kimg = smem;
-  char* Vimg = smem + ROWS * 128;
+  char* Vimg = smem;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, h2 = lane >> 5;
   const auto warm = code_warm_begin<7168>((int)blockIdx.x < a.warm && tid < 64);
   const int wy_ = wid >> 1, wx_ = wid & 1;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256, (NaGeo<KS>::LDS <= 80 * 1024) ? 2 : 1) void at
 
   // ---- halo rows -> K / V images: image row 8 pc + (lane >> 3) = halo position (y, x), walked 32 rows at a time ----------------
   static_assert(PW == 16, "kernel sizes up to 9: 16-key patch rows");
-  {
+  auto stage = [&](bool want_k, bool want_v) {
     int row = 8 * wid + (lane >> 3);
     int y = row / HC, x = row % HC;
     constexpr int DY = 32 / HC, DX = 32 % HC;
@@ -271,12 +275,13 @@ __global__ __launch_bounds__(256, (NaGeo<KS>::LDS <= 80 * 1024) ? 2 : 1) void at
       // rows past the halo's last key (a patch may poke there) take any real token: they are outside every window
       const int ky = min(hy0 + y, a.H - 1), kx = min(hx0 + x, a.W - 1);
       const char* src = base + (size_t)(unsigned)((ky * a.W + kx) * (int)row_bytes + (((lane & 7) ^ asw(row)) << 4));
-      glds16(src + a.nh * DH * 2, Kimg + pc * 1024);
-      glds16(src + 2 * a.nh * DH * 2, Vimg + pc * 1024);
+      if (want_k) glds16(src + a.nh * DH * 2, Kimg + pc * 1024);
+      if (want_v) glds16(src + 2 * a.nh * DH * 2, Vimg + pc * 1024);
       row += 32; x += DX; y += DY;
       if (x >= HC) { x -= HC; ++y; }
     }
-  }
+  };
+  stage(true, false);
   // ---- this lane's query ------------------------------------------------------------------------------------------------------------
   const int qy_raw = ty0 + 4 * wy_ + (l31 >> 3), qx_raw = tx0 + 8 * wx_ + (l31 & 7);
   const bool q_ok = qy_raw < a.H && qx_raw < a.W;
@@ -331,6 +336,14 @@ __global__ __launch_bounds__(256, (NaGeo<KS>::LDS <= 80 * 1024) ? 2 : 1) void at
       S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], S[t], 0, 0, 0);
     }
   }
+  {
+    // every K fragment of this wave has been read (the MFMAs above consumed them): once all four waves are here the image takes the V rows,
+    // which land while the softmax below runs
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    KD_BARRIER();
+    stage(false, true);
+  }
   // ---- window mask + softmax -------------------------------------------------------------------------------------------------------
 #pragma unroll
   for (int t = 0; t < NKT; ++t)
@@ -339,6 +352,8 @@ __global__ __launch_bounds__(256, (NaGeo<KS>::LDS <= 80 * 1024) ? 2 : 1) void at
   const float m = score_max<NKT>(S);
   float l = score_exp<NKT>(S, m);
   l += __shfl_xor(l, 32, 64);
+  KD_WAIT_VM(0);
+  KD_BARRIER();
 
   // ---- O^T = V^T P^T: k-slots of lane-half h2 at step (t, u) are patch row 2 t + u, columns 4 h2 + {0..3} and + 8 ----------------
   f32x16 O[2];
@@ -501,12 +516,13 @@ template <int KS>
 static int launch_na(const NArgs& a, hipStream_t s) {
   auto k = attn_na2d_bf16_kernel<KS>;
   static LdsAttr set;
-  set.ensure(reinterpret_cast<const void*>(k), NaGeo<KS>::LDS);
+  constexpr int LDS = NaGeo<KS>::LDS;
+  set.ensure(reinterpret_cast<const void*>(k), LDS);
   const long nb = (long)a.batch * a.nh * ((a.H + NA_TH - 1) / NA_TH) * ((a.W + NA_TW - 1) / NA_TW);
   char nm[64] = "attn_na2d_bf16";
   if (prof_on()) snprintf(nm, sizeof(nm), "attn_na2d_bf16 k%d %dx%d nh=%d", KS, a.H, a.W, a.nh);
   LaunchScope prof(nm, 4.0 * a.batch * (double)a.H * a.W * a.nh * DH * KS * KS, 8.0 * a.batch * (double)a.H * a.W * a.nh * DH, s);
-  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(256), NaGeo<KS>::LDS, s, a);
+  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(256), LDS, s, a);
   return check_launch("kd_attn_na2d_bf16");
 }
 

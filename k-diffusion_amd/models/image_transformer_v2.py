@@ -194,6 +194,7 @@ class _Schedule:
     def __init__(self, sigma_table, others, ident_others, tables, done):
         self.base, self.version, self.n, self.B = sigma_table.data_ptr(), _ver(sigma_table), sigma_table.shape[0], sigma_table.shape[1]
         self.ident_others, self.tables, self.done = ident_others, tables, done
+        self.waited = set()       # streams (handles) that have waited for ``done`` once: everything they run later is ordered behind it
         # the record keeps the hinted tensors alive, so their addresses cannot be handed to other tensors while it exists
         self.keep = (sigma_table, others)
 
@@ -796,12 +797,17 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         plan = self._plan_for(x, aug_cond, class_cond, create=True)
         cur = torch.cuda.current_stream()
         ident = self._cond_identity(sigma, aug_cond, class_cond, mapping_cond)
-        table = None
+        table, from_schedule = None, False
         for sch in plan.schedules:                # this call's scales were computed with its whole sigma schedule
             i = sch.row_of(sigma) if sch.ident_others == ident[1:] else None
             if i is not None:
-                cur.wait_event(sch.done)
+                # the table was computed once, ahead of the loop, on the side stream: ONE wait per (schedule, stream) orders every later
+                # forward on that stream behind it (a wait packet per forward cost ~3 us of idle queue each: profiles/r06_launch_gaps_*.txt)
+                if cur.cuda_stream not in sch.waited:
+                    cur.wait_event(sch.done)
+                    sch.waited.add(cur.cuda_stream)
                 table = sch.tables[i].data_ptr()
+                from_schedule = True
                 break
         if table is None:
             pre, plan.prefetched = plan.prefetched, None
@@ -822,7 +828,8 @@ class ImageTransformerDenoiserModelV2(nn.Module):
                 plan.sigma_ptr = plan.sigma.data_ptr()
             else:
                 plan.sigma_ptr = sigma.data_ptr()  # read in place: freed storage is not reused before this stream's work is done
-        plan.main_entry.record(cur)               # everything before this step's main chain (incl. an inline conditioning chain)
+        if not from_schedule:                     # (only the per-step side-stream chain of prefetch_conditioning waits on this event)
+            plan.main_entry.record(cur)           # everything before this step's main chain (incl. an inline conditioning chain)
         out = torch.empty(B, self.out_channels, H, W, device=x.device, dtype=torch.float32)
         plan.run(x, out, sigma_data, table)
         return out
