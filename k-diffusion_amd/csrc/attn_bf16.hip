@@ -369,6 +369,12 @@ __global__ __launch_bounds__(256, NaGeo<KS>::LDS <= 53 * 1024 ? 3 : 2) void attn
   store_o(a.out + ((size_t)b * T + q_tok) * (a.nh * DH) + head * DH, O, 1.0f / l, h2, q_ok);
 }
 
+// (Round 6 also built a PERSISTENT form of this kernel -- a workgroup walking several tiles with the next tile's K and queries requested behind
+// the scores and the current tile's V behind the barrier in front of them, two images, two workgroups per CU, V^T reads as inline asm so that
+// hipcc's vmcnt(0) in front of its own ds_read_b64_tr_b16 would not drain the prefetch -- bit-identical, and SLOWER: 33.9 against 32.4 us at
+// level 0, 19.0 against 19.2 at level 1, same box, interleaved.  With three workgroups per CU the one-tile form already moves its 134 MB in
+// ~27 us of a 31 us launch, ~5 TB/s: the halo waits are covered, what is left is the memory system.  Removed; profiles/r06_na_core.md.)
+
 // ---- neighbourhood core, kernel sizes 11 and 13 ------------------------------------------------------------------------------------
 // The 4x8 query block of a wave now needs a patch of (4 + KS - 1) rows x (8 + KS - 1) = 18 / 20 columns: no longer a power-of-two
 // width, so the patch is walked DENSELY: local key kl = 20 r + c (columns padded to 20, a multiple of 4 so that the 4-key groups of
@@ -514,11 +520,11 @@ static int launch_dense(const DArgs& a, long nproblems, const char* name, hipStr
 
 template <int KS>
 static int launch_na(const NArgs& a, hipStream_t s) {
+  const long nb = (long)a.batch * a.nh * ((a.H + NA_TH - 1) / NA_TH) * ((a.W + NA_TW - 1) / NA_TW);
   auto k = attn_na2d_bf16_kernel<KS>;
   static LdsAttr set;
   constexpr int LDS = NaGeo<KS>::LDS;
   set.ensure(reinterpret_cast<const void*>(k), LDS);
-  const long nb = (long)a.batch * a.nh * ((a.H + NA_TH - 1) / NA_TH) * ((a.W + NA_TW - 1) / NA_TW);
   char nm[64] = "attn_na2d_bf16";
   if (prof_on()) snprintf(nm, sizeof(nm), "attn_na2d_bf16 k%d %dx%d nh=%d", KS, a.H, a.W, a.nh);
   LaunchScope prof(nm, 4.0 * a.batch * (double)a.H * a.W * a.nh * DH * KS * KS, 8.0 * a.batch * (double)a.H * a.W * a.nh * DH, s);
