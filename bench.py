@@ -20,11 +20,13 @@ cpu_baseline -- plus ``parity`` (distance of this build on this box to the refer
 
 Arithmetic mode (``--mode``, default split3): ``value`` / ``dtype`` / ``roofline`` belong to that mode.  The default is the
 fp32-PARITY mode -- the reference samples in fp32 (sample.py:39-47, no mixed precision) and north_star asks for images within
-1e-3 of it, which only the fp32 modes meet.  At N = 1 the bf16 mode is measured right after it on the same box with the SAME
---steps / --warmup and its own HIP-event pass (``mode_values``; full entry in the detail file):
+1e-3 of it, which only the fp32 modes meet.  At N = 1 the bf16 and fp8 modes are measured right after it on the same box with the SAME
+--steps / --warmup and their own HIP-event pass (``mode_values``; full entries in the detail file):
   split3  fp32 activations, 3 split-bf16 MFMA terms per product: the fp32-parity mode (< 5e-4 from the fp32 reference end to end)
   bf16    bf16 activations, one bf16 MFMA per product, fp32 accumulate / statistics (the reference under autocast(bfloat16);
           1.1e-2 from the fp32 reference after 50 steps: NOT parity-grade, reported for what it is)
+  fp8     the bf16 mode with the norm -> qkv / norm -> GEGLU projections of the width-256 / 512 levels as e4m3 x e4m3 products on the block-scaled
+          fp8 matrix instruction (BASELINE configs[4]'s arithmetic; NOT parity-grade)
   exact   fp32 activations, fp32-input MFMA, bit-for-bit an fmaf chain (``--detail`` or ``--modes split3,bf16,exact``)
 Opt-in blocks (``--detail`` = all of them; they lengthen the run from ~1 to ~3 minutes and only ever write to the detail file):
 ``--other-configs`` (all five BASELINE configurations with their parity), ``--small-batch`` (batch 1 / 4 latency), ``--job`` (the
@@ -64,7 +66,7 @@ def parse(argv=None):
     p.add_argument("--sampler-steps", type=int, default=50)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--mode", default=os.environ.get("KDIFF_GEMM", "split3"), choices=["bf16", "split3", "exact", "fp8"], help="arithmetic mode of `value`")
-    p.add_argument("--modes", default=None, help="modes measured at N = 1 (same steps / warm-up, own roofline); default: split3,bf16 (+ exact with --detail)")
+    p.add_argument("--modes", default=None, help="modes measured at N = 1 (same steps / warm-up, own roofline); default: split3,bf16,fp8 (+ exact with --detail)")
     p.add_argument("--no-other-modes", action="store_true", help="measure --mode only")
     p.add_argument("--gather", default="uint8", choices=["uint8", "fp32"],
                    help="what the N > 1 exchange step moves: uint8 images (what sample.py gathers when it writes PNGs) or the reference's fp32")
@@ -91,7 +93,7 @@ def parse(argv=None):
     if args.detail:
         args.other_configs = args.small_batch = args.job = True
     if args.modes is None:
-        args.modes = "split3,bf16,exact" if args.detail else "split3,bf16"
+        args.modes = "split3,bf16,fp8,exact" if args.detail else "split3,bf16,fp8"
     return args
 
 
@@ -179,7 +181,7 @@ def pmc_traffic(kernel_family):
     passes, gfx950 FETCH x2 correction: profiles/summarize_pmc.py); None when the summary has no matching entry."""
     if not kernel_family:
         return None
-    for name in ("r05_pmc_traffic.json", "r05_pmc_traffic_bf16.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):        # newest committed summary that knows the kernel
+    for name in ("r06_pmc_traffic.json", "r06_pmc_traffic_bf16.json", "r06_pmc_traffic_fp8.json", "r05_pmc_traffic.json", "r05_pmc_traffic_bf16.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):        # newest committed summary that knows the kernel
         path = os.path.join(REPO, "profiles", name)
         try:
             table = json.load(open(path))

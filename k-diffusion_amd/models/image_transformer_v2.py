@@ -318,7 +318,8 @@ class _Plan:
 
         def mx8_ok(M, N, K, epi):
             """fp8 mode: this norm -> projection of the main chain goes to the block-scaled fp8 matrix instruction (kd_gemm_mx8)."""
-            return fp8 and target is self.launches and bool(lib.kd_gemm_mx8_supported(M, N, K, epi, 1))
+            # (from 4 096 rows on: below that the few-rows bf16 kernels are ahead -- batch 1: 0.512 against 0.552 ms per forward, profiles/r06_bench_detail_full.json)
+            return fp8 and target is self.launches and M >= 4096 and bool(lib.kd_gemm_mx8_supported(M, N, K, epi, 1))
 
         def call(what, fn, *args):
             target.append(_Launch(fn, args, what, enc=(fn.__name__, args)))
