@@ -291,6 +291,10 @@ int kd_proj_block_bf16(const KdGemm* d, void* stream);
  * and the epilogues as in kd_gemm_bf16.  `d` is the projection's descriptor as kd_gemm_bf16 takes it (bf16 A / C, norm = 1, epi = KD_EPI_STORE /
  * KD_EPI_QKV / KD_EPI_GEGLU, precision = KD_PREC_BF16, rows_per_sample set) except that Wp points at the kd_pack_weight_mx8 image.
  * Shapes: K in {256, 512}, N a multiple of 128 (GEGLU: d_ff a multiple of 64), M >= 128 (kd_gemm_mx8_supported tells); else KD_EINVAL.
+ * With c_split = 1 (KD_EPI_GEGLU only) the result leaves as the NEXT fp8 product's operand: C = e4m3 rows [M, N] (bytes), C_lo = one E8M0
+ * byte per (row, 32 features) [M, N / 32], the activations' rule.
+ * Second form, norm = 0 and a_split = 1 (:492 down_proj + the skip add; epi = KD_EPI_STORE / KD_EPI_RESIDUAL): A = such e4m3 rows [M, K],
+ * A_lo = their scale bytes [M, K / 32] (4-byte aligned), both operands by LDS-DMA; K in {256, 512, 768, 1536}, N a multiple of 128; C / R bf16.
  * The arithmetic is restated in oracle/hdit.py (mx8_quantize_rows / mx8_quantize_weight). */
 long long kd_packed_weight_bytes_mx8(int N, int K, int geglu);
 int kd_pack_weight_mx8(const float* W, void* out, int N, int K, int geglu, void* stream);

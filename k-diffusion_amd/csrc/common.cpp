@@ -74,7 +74,7 @@ Opt g_opts[] = {{"skinny", {0}, {false}}, {"astat", {0}, {false}}, {"ksplit", {0
                 {"wstat_waves", {0}, {false}}, {"wstat_max_slices", {0}, {false}}, {"wstat_prefetch", {0}, {false}}, {"astat_bf16", {0}, {false}},
                 {"astat_splits", {0}, {false}}, {"tiled_bm", {0}, {false}}, {"attn_global_qw", {0}, {false}},
                 {"patch_fast", {0}, {false}}, {"ffn_fused", {0}, {false}}, {"ffn_fused_256", {0}, {false}}, {"astat_rows", {0}, {false}}, {"tiled_deep", {0}, {false}}, {"code_warm", {0}, {false}}, {"ffn_variant", {0}, {false}},
-                {"x3", {0}, {false}}, {"x3_splits", {0}, {false}}, {"ffn_x3", {0}, {false}}, {"ffn_x3_half", {0}, {false}}, {"x3_res", {0}, {false}}, {"attn_x3", {0}, {false}}, {"x3_half", {0}, {false}}, {"x3r", {0}, {false}}, {"x3_unpatch", {0}, {false}}, {"x3r_lw", {0}, {false}}, {"x3r_split", {0}, {false}}, {"tiled_lw", {0}, {false}}, {"x3_min_rows", {0}, {false}}, {"x3r_min_rows", {0}, {false}}, {"ffn_x3_min_panels_256", {0}, {false}}, {"x3s_max_rows", {0}, {false}}, {"x3s_max_wgs", {0}, {false}}, {"x3s_scale_lds", {0}, {false}}, {"b16s_max_rows", {0}, {false}}, {"b16s_max_wgs", {0}, {false}}, {"ffn_bf16_min_rows", {0}, {false}}, {"x3s_trace", {0}, {false}}, {"attn_block_bf16", {0}, {false}}, {"proj_block_bf16", {0}, {false}}, {"mx8", {0}, {false}}, {"mx8_splits", {0}, {false}}};
+                {"x3", {0}, {false}}, {"x3_splits", {0}, {false}}, {"ffn_x3", {0}, {false}}, {"ffn_x3_half", {0}, {false}}, {"x3_res", {0}, {false}}, {"attn_x3", {0}, {false}}, {"x3_half", {0}, {false}}, {"x3r", {0}, {false}}, {"x3_unpatch", {0}, {false}}, {"x3r_lw", {0}, {false}}, {"x3r_split", {0}, {false}}, {"tiled_lw", {0}, {false}}, {"x3_min_rows", {0}, {false}}, {"x3r_min_rows", {0}, {false}}, {"ffn_x3_min_panels_256", {0}, {false}}, {"x3s_max_rows", {0}, {false}}, {"x3s_max_wgs", {0}, {false}}, {"x3s_scale_lds", {0}, {false}}, {"b16s_max_rows", {0}, {false}}, {"b16s_max_wgs", {0}, {false}}, {"ffn_bf16_min_rows", {0}, {false}}, {"x3s_trace", {0}, {false}}, {"attn_block_bf16", {0}, {false}}, {"proj_block_bf16", {0}, {false}}, {"mx8", {0}, {false}}, {"mx8_splits", {0}, {false}}, {"mx8_min_rows", {0}, {false}}};
 constexpr int N_OPTS = sizeof(g_opts) / sizeof(g_opts[0]);
 }  // namespace
 int option_index(const char* name) {

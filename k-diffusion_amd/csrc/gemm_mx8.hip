@@ -33,6 +33,7 @@ using i32x8 = __attribute__((ext_vector_type(8))) int;
 
 struct MArgs {
   const u16* A; const char* Wp; const unsigned* Ws; u16* C;
+  unsigned char* C8; unsigned char* Cs;        // C8OUT (GEGLU): the result as e4m3 [M, N] + one E8M0 byte per (row, 32 features) [M, N / 32]
   const float* scale; int scale_stride, rows_per_sample; float eps;
   int M, N, n_tiles, n_splits;
   int n_heads; const float* qk_scale; const float* pos; const float* freq;
@@ -48,6 +49,10 @@ __device__ __host__ __forceinline__ unsigned mx_scale_byte(float amax) {
 }
 __device__ __forceinline__ float mx_inv_scale(unsigned byte) { return __uint_as_float((254u - byte) << 23); }
 
+__device__ __forceinline__ void glds16(const void* src, void* dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
 __device__ __forceinline__ void wait_vm_dyn8(int n) {
   switch (n) {
 #define KD_C(v) case v: asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); break;
@@ -59,8 +64,11 @@ __device__ __forceinline__ void wait_vm_dyn8(int n) {
 }
 
 // NK64 = K / 64 (4 or 8).  128-row panels (4 waves), two workgroups per CU, n-splits of a panel on one XCD: gemm_astat_kernel's schedule.
-template <int NK64, int EPI>
+// C8OUT (EPI_GEGLU): the hidden activation leaves as the NEXT fp8 product's A operand -- e4m3 rows + one power-of-two scale per (row, 32
+// features), the same rule as the activations above -- instead of bf16: kd_gemm_mx8's tiled form (down projection) takes it by LDS-DMA.
+template <int NK64, int EPI, bool C8OUT = false>
 __global__ __launch_bounds__(256, 2) void gemm_mx8_astat_kernel(const MArgs p) {
+  static_assert(!C8OUT || EPI == KD_EPI_GEGLU, "e4m3 output: the GEGLU epilogue");
   constexpr int K = NK64 * 64, NKB = K / 128, NSTG = 4, PDIST = NSTG - 1, NWV = 4, PB = 4;
   constexpr bool GEGLU = EPI == KD_EPI_GEGLU;
   constexpr int NCOL = GEGLU ? 64 : 128;
@@ -263,7 +271,32 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_astat_kernel(const MArgs p) {
           v[r] = o.x;
           v[r + 1] = o.y;
         }
-        store_block_bf16(crow + n0 + 32 * jj, v, lh, ok);
+        if constexpr (C8OUT) {
+          // v[4 g + e] = feature 8 g + 4 lh + e of the block: the block's maximum over both lanes of the row, then 16 e4m3 bytes per lane --
+          // after the half-wave exchange lane half 0 holds features 0..15, lane half 1 features 16..31: one 16-byte store each
+          float amax = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(v[r]));
+          amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+          const unsigned sb = mx_scale_byte(amax);
+          const float inv = mx_inv_scale(sb);
+          unsigned w[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            int pk = 0;
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * g] * inv, v[4 * g + 1] * inv, pk, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * g + 2] * inv, v[4 * g + 3] * inv, pk, true);
+            w[g] = (unsigned)pk;
+          }
+          half_swap(w[0], w[2]);
+          half_swap(w[1], w[3]);
+          if (ok) {
+            st16(p.C8 + (size_t)rowc * p.N + n0 + 32 * jj + 16 * lh, u32x4{w[0], w[2], w[1], w[3]});
+            if (lh == 0) p.Cs[(size_t)rowc * (p.N >> 5) + ((n0 + 32 * jj) >> 5)] = (unsigned char)sb;
+          }
+        } else {
+          store_block_bf16(crow + n0 + 32 * jj, v, lh, ok);
+        }
       }
     } else if (EPI == KD_EPI_QKV) {
 #pragma unroll
@@ -305,6 +338,145 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_astat_kernel(const MArgs p) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  }
+}
+
+// ---- tiled form: BOTH operands e4m3 through LDS (down projection + residual of the fp8 mode) ------------------------------------------------
+// gemm_bf16.hip's tiled kernel (128 x 128 tile per workgroup, 2 x 2 blocks per wave, both operands by LDS-DMA, K loop = ds_read + matrix
+// instruction) with A = the e4m3 rows + E8M0 block scales a C8OUT launch above wrote and W = a kd_pack_weight_mx8 image.  A ring slot covers
+// 128 k: A image [128 rows][128 bytes] (16-byte chunk q of row r at q ^ ((r >> 1) & 7), permuted on the source side: bf16_common.h swz128)
+// + one 16 KiB W block = 32 KiB, 8 instructions per wave.  The row's scale bytes (K / 32) are read once into registers; the byte of the
+// block a lane feeds (block lh of the k-step) is spread over the register's byte lanes by one v_perm_b32.
+struct TArgs8 {
+  const unsigned char* A8; const unsigned* As; const char* Wp; const unsigned* Ws; u16* C; const u16* R;
+  int M, N, K, n_tiles_n;
+  int warm;
+};
+
+template <int NKB /* K / 128 */, int EPI, bool DEEP>
+__global__ __launch_bounds__(256, DEEP ? 1 : 2) void gemm_mx8_tiled_kernel(const TArgs8 p) {
+  constexpr int SLOT = 2 * WBLK, NSTG = DEEP ? 4 : 2, K = NKB * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, lh = lane >> 5;
+  const auto warm = code_warm_begin<8192>((int)blockIdx.x < p.warm && tid < 64);
+  const int wc = wid & 1, wr = wid >> 1;
+  int tile;
+  {   // XCD-aware order, n fastest: the n-tiles of one row panel run back to back on ONE L2
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int nt = tile % p.n_tiles_n, mt = tile / p.n_tiles_n;
+  const int m0 = mt * 128, n0 = nt * 128;
+  const char* aptr[4];
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) {
+    const int row = 8 * (4 * wid + ii) + (lane >> 3);
+    const int q = (lane & 7) ^ ((row >> 1) & 7);
+    aptr[ii] = reinterpret_cast<const char*>(p.A8) + (size_t)min(m0 + row, p.M - 1) * K + q * 16;
+  }
+  const char* wsrc = p.Wp + (size_t)nt * NKB * WBLK + (wid * 4) * 1024 + lane * 16;
+  auto issue = [&](int kt) {
+    char* st = smem + (kt % NSTG) * SLOT;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) glds16(aptr[ii] + kt * 128, st + (4 * wid + ii) * 1024);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(wsrc + (size_t)kt * WBLK + j * 1024, st + WBLK + (wid * 4 + j) * 1024);
+  };
+#pragma unroll
+  for (int kt = 0; kt < NSTG - 1; ++kt)
+    if (kt < NKB) issue(kt);
+  // this lane's rows of the two row blocks: their scale bytes (4 per 128 k), and the channel-scale bytes of the wave's two feature groups
+  unsigned asw[2][NKB];
+  int wsc[2];
+  {
+    const unsigned wsw = p.Ws[(size_t)nt * 32 + l31];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wsc[i] = (int)(((wsw >> (8 * (2 * wc + i))) & 0xFFu) * 0x01010101u);
+#pragma unroll
+    for (int jr = 0; jr < 2; ++jr) {
+      const unsigned* sp = p.As + (size_t)min(m0 + wr * 64 + 32 * jr + l31, p.M - 1) * NKB;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) asw[jr][kb] = sp[kb];
+    }
+  }
+  const unsigned sel0 = (unsigned)lh * 0x01010101u, sel1 = (unsigned)(2 + lh) * 0x01010101u;      // v_perm_b32 selectors: byte lh / 2 + lh of a dword to all four lanes
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  constexpr bool HAS_R = EPI == KD_EPI_RESIDUAL;
+  u32x4 rraw[2][2][2];
+  size_t roff[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      roff[i][j] = (size_t)min(m0 + wr * 64 + 32 * j + l31, p.M - 1) * p.N + min(n0 + wc * 64 + 32 * i, p.N - 32);
+  code_warm_end(warm);
+#pragma unroll
+  for (int kt = 0; kt < NKB; ++kt) {
+    // the steps requested after kt may stay in flight (8 LDS-DMA requests per wave and step); the scale loads above were consumed by the compiler's own wait
+    if (NSTG == 2 || kt + 1 >= NKB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (kt + 2 >= NKB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (kt + NSTG - 1 < NKB) issue(kt + NSTG - 1);
+    if (HAS_R && kt == (NKB >= 2 ? NKB - 2 : 0)) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) load_block_raw(p.R + roff[i][j], rraw[i][j], lh);
+    }
+    const char* st = smem + (kt % NSTG) * SLOT;
+    const char* wb = st + WBLK + lh * 512 + l31 * 16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      i32x8 af[2], wf[2];
+#pragma unroll
+      for (int jr = 0; jr < 2; ++jr) {
+        const int row = wr * 64 + 32 * jr + l31;
+        const u32x4 h0 = *reinterpret_cast<const u32x4*>(st + swz128(row, 4 * ks + lh));
+        const u32x4 h1 = *reinterpret_cast<const u32x4*>(st + swz128(row, 4 * ks + 2 + lh));
+        af[jr] = i32x8{(int)h0[0], (int)h0[1], (int)h0[2], (int)h0[3], (int)h1[0], (int)h1[1], (int)h1[2], (int)h1[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int j = 2 * wc + i;
+        const u32x4 h0 = *reinterpret_cast<const u32x4*>(wb + ((j * 2 + ks) * 2 + 0) * 1024);
+        const u32x4 h1 = *reinterpret_cast<const u32x4*>(wb + ((j * 2 + ks) * 2 + 1) * 1024);
+        wf[i] = i32x8{(int)h0[0], (int)h0[1], (int)h0[2], (int)h0[3], (int)h1[0], (int)h1[1], (int)h1[2], (int)h1[3]};
+      }
+#pragma unroll
+      for (int jr = 0; jr < 2; ++jr) {
+        const int sc = (int)__builtin_amdgcn_perm(asw[jr][kt], asw[jr][kt], ks ? sel1 : sel0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i][jr] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[i], af[jr], acc[i][jr], 0, 0, 0, wsc[i], 0, sc);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int gm = m0 + wr * 64 + 32 * j + l31;
+    const bool ok = gm < p.M;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int nb = n0 + wc * 64 + 32 * i;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+      if (HAS_R) {
+        float rr_[16];
+        block_from_raw(rraw[i][j], rr_);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += rr_[r];
+      }
+      store_block_bf16(p.C + roff[i][j], v, lh, ok && nb < p.N);
+    }
   }
 }
 
@@ -360,31 +532,70 @@ extern "C" int kd_pack_weight_mx8(const float* W, void* out, int N, int K, int g
   return check_launch("kd_pack_weight_mx8");
 }
 
-// AdaRMSNorm -> projection on the block-scaled fp8 matrix instruction.  `d` is the projection's descriptor as kd_gemm_bf16 takes it (bf16
-// activations in and out, norm = 1, epi = KD_EPI_STORE / KD_EPI_QKV / KD_EPI_GEGLU, precision = KD_PREC_BF16) except that Wp points at the
-// kd_pack_weight_mx8 image.  K in {256, 512}, N a multiple of the tile (128; GEGLU: 64), M >= 128.
+// Products on the block-scaled fp8 matrix instruction.  `d` is the projection's descriptor as kd_gemm_bf16 takes it (bf16 activations,
+// precision = KD_PREC_BF16) except that Wp points at the kd_pack_weight_mx8 image.  Two forms:
+//   norm = 1 (AdaRMSNorm -> projection; epi = KD_EPI_STORE / KD_EPI_QKV / KD_EPI_GEGLU; K in {256, 512}, N a multiple of the tile (128; GEGLU:
+//            64), M >= 128): the A-stationary kernel; the activations are quantised in the kernel.  With c_split = 1 (GEGLU only) the
+//            result leaves as e4m3 rows in C ([M, N] bytes) + one E8M0 byte per (row, 32 features) in C_lo ([M, N / 32] bytes);
+//   norm = 0, a_split = 1 (epi = KD_EPI_STORE / KD_EPI_RESIDUAL; K in {256, 512, 768, 1536}, N a multiple of 128): A is such an e4m3 tensor
+//            (A = [M, K] bytes, A_lo = [M, K / 32] scale bytes): the tiled kernel, both operands by LDS-DMA (the fp8 mode's down projection).
 extern "C" int kd_gemm_mx8_supported(int M, int N, int K, int epi, int norm) {
-  if (!norm || (K != 256 && K != 512) || M < 128 || !option("mx8", 1)) return 0;
+  if (M < 128 || !option("mx8", 1)) return 0;
+  if (!norm) return (epi == KD_EPI_STORE || epi == KD_EPI_RESIDUAL) && (K == 256 || K == 512 || K == 768 || K == 1536) && N > 0 && N % 128 == 0;
+  if (K != 256 && K != 512) return 0;
   if (epi == KD_EPI_GEGLU) return N > 0 && N % 64 == 0;
   if (epi == KD_EPI_QKV) return N == 3 * K;
   if (epi == KD_EPI_STORE) return N > 0 && N % 128 == 0;
   return 0;
 }
 
+static int mx8_tiled(const KdGemm& d, hipStream_t s) {
+  if (!d.A || !d.A_lo || !d.Wp || !d.C || (d.epi == KD_EPI_RESIDUAL && !d.R)) return fail(KD_EINVAL, "kd_gemm_mx8: null operand");
+  if (d.epi == KD_EPI_STORE && d.out_add != 0.f) return fail(KD_EINVAL, "kd_gemm_mx8: out_add is not taken");
+  const int n_tiles_n = d.N / 128, nkb = d.K / 128;
+  TArgs8 a{reinterpret_cast<const unsigned char*>(d.A), reinterpret_cast<const unsigned*>(d.A_lo), reinterpret_cast<const char*>(d.Wp),
+           reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(d.Wp) + (size_t)n_tiles_n * nkb * WBLK), reinterpret_cast<u16*>(d.C),
+           reinterpret_cast<const u16*>(d.R), d.M, d.N, d.K, n_tiles_n, option("code_warm", KD_CODE_WARM_DEFAULT)};
+  const long tiles = (long)((d.M + 127) / 128) * n_tiles_n;
+  const bool deep = tiles <= cu_count();              // at most one tile per CU: a 4-slot ring instead of two workgroups per CU
+  const double flops = 2.0 * d.M * (double)d.N * d.K;
+  const double bytes = (double)d.M * d.K * (1.0 + 1.0 / 32) + (double)d.N * d.K + 2.0 * d.M * d.N * (d.epi == KD_EPI_RESIDUAL ? 2.0 : 1.0);
+  char nm[96] = "gemm_mx8_tiled";
+  if (prof_on()) snprintf(nm, sizeof(nm), "gemm_mx8_tiled<e%d> M=%d N=%d K=%d", d.epi, d.M, d.N, d.K);
+  LaunchScope prof(nm, flops, bytes, s);
+#define KD_MT(NKBV, EP, DP) { constexpr int LDS = (DP ? 4 : 2) * 2 * WBLK; static LdsAttr set;                                \
+    set.ensure(reinterpret_cast<const void*>(gemm_mx8_tiled_kernel<NKBV, EP, DP>), LDS);                                          \
+    hipLaunchKernelGGL((gemm_mx8_tiled_kernel<NKBV, EP, DP>), dim3((unsigned)tiles), dim3(256), LDS, s, a); }
+#define KD_MT2(NKBV) { if (d.epi == KD_EPI_RESIDUAL) { if (deep) KD_MT(NKBV, KD_EPI_RESIDUAL, true) else KD_MT(NKBV, KD_EPI_RESIDUAL, false) } \
+                       else { if (deep) KD_MT(NKBV, KD_EPI_STORE, true) else KD_MT(NKBV, KD_EPI_STORE, false) } }
+  if (nkb == 2) KD_MT2(2) else if (nkb == 4) KD_MT2(4) else if (nkb == 6) KD_MT2(6) else KD_MT2(12)
+#undef KD_MT2
+#undef KD_MT
+  return check_launch("kd_gemm_mx8(tiled)");
+}
+
 extern "C" int kd_gemm_mx8(const KdGemm* dp, void* stream) {
   if (!dp) return fail(KD_EINVAL, "kd_gemm_mx8: null descriptor");
   const KdGemm& d = *dp;
-  if (!d.A || !d.Wp || !d.C || !d.scale) return fail(KD_EINVAL, "kd_gemm_mx8: null operand");
-  if (d.a_mode != KD_A_PLAIN || d.precision != KD_PREC_BF16 || d.rows_per_sample <= 0 || (d.epi == KD_EPI_STORE && d.out_add != 0.f))
-    return fail(KD_EINVAL, "kd_gemm_mx8: the descriptor must be a bf16 norm -> projection (plain A, rows_per_sample set)");
+  if (d.a_mode != KD_A_PLAIN || d.precision != KD_PREC_BF16)
+    return fail(KD_EINVAL, "kd_gemm_mx8: the descriptor must be a bf16-mode projection with a plain A operand");
   if (!kd_gemm_mx8_supported(d.M, d.N, d.K, d.epi, d.norm))
-    return fail(KD_EINVAL, "kd_gemm_mx8: shape M=%d N=%d K=%d epi=%d norm=%d is not taken (norm -> store / qkv / GEGLU, K in {256, 512})", d.M, d.N, d.K, d.epi, d.norm);
+    return fail(KD_EINVAL, "kd_gemm_mx8: shape M=%d N=%d K=%d epi=%d norm=%d is not taken", d.M, d.N, d.K, d.epi, d.norm);
+  if (!d.norm) {
+    if (!d.a_split) return fail(KD_EINVAL, "kd_gemm_mx8: without a norm the A operand must be e4m3 rows + block scales (a_split = 1, A_lo = the scale bytes)");
+    return mx8_tiled(d, (hipStream_t)stream);
+  }
+  if (!d.A || !d.Wp || !d.C || !d.scale) return fail(KD_EINVAL, "kd_gemm_mx8: null operand");
+  if (d.a_split || d.rows_per_sample <= 0 || (d.epi == KD_EPI_STORE && d.out_add != 0.f))
+    return fail(KD_EINVAL, "kd_gemm_mx8: the descriptor must be a bf16 norm -> projection (bf16 A, rows_per_sample set)");
+  if (d.c_split && (d.epi != KD_EPI_GEGLU || !d.C_lo)) return fail(KD_EINVAL, "kd_gemm_mx8: the e4m3 output (c_split) is the GEGLU epilogue's, with C_lo = the scale bytes");
   if (d.epi == KD_EPI_QKV && (!d.qk_scale || !d.rope_pos || !d.rope_freq || d.n_heads * 64 != d.K))
     return fail(KD_EINVAL, "kd_gemm_mx8: the qkv projection needs qk_scale, rope_pos, rope_freq and n_heads * 64 == K");
   const bool geglu = d.epi == KD_EPI_GEGLU;
   const int n_tiles = mx8_tiles(d.N, geglu), nkb = d.K / 128;
   MArgs a{reinterpret_cast<const u16*>(d.A), reinterpret_cast<const char*>(d.Wp),
           reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(d.Wp) + (size_t)n_tiles * nkb * WBLK), reinterpret_cast<u16*>(d.C),
+          reinterpret_cast<unsigned char*>(d.C), reinterpret_cast<unsigned char*>(d.C_lo),
           d.scale, d.scale_stride, d.rows_per_sample, d.eps, d.M, d.N, n_tiles, 1,
           d.n_heads, d.qk_scale, d.rope_pos, d.rope_freq, option("code_warm", KD_CODE_WARM_DEFAULT)};
   // n-splits of a panel: gemm_astat's cost model (rounds x (row prologue + tiles per split)), two workgroups per CU
@@ -403,18 +614,20 @@ extern "C" int kd_gemm_mx8(const KdGemm* dp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const double n_eff = geglu ? 2.0 * d.N : (double)d.N;
   const double flops = 2.0 * d.M * n_eff * d.K;
-  const double bytes = 2.0 * ((double)d.M * d.K + (double)d.M * d.N) + n_eff * d.K;
+  const double bytes = 2.0 * (double)d.M * d.K + (d.c_split ? (1.0 + 1.0 / 32) : 2.0) * (double)d.M * d.N + n_eff * d.K;
   char nm[96] = "gemm_mx8_astat";
-  if (prof_on()) snprintf(nm, sizeof(nm), "gemm_mx8_astat<e%d> M=%d N=%d K=%d", d.epi, d.M, d.N, d.K);
+  if (prof_on()) snprintf(nm, sizeof(nm), "gemm_mx8_astat<e%d%s> M=%d N=%d K=%d", d.epi, d.c_split ? ",c8" : "", d.M, d.N, d.K);
   LaunchScope prof(nm, flops, bytes, s);
   // ring + one scale vector (K floats) per wave + the channel-scale bytes of a split's n-tiles (<= 64 tiles)
-#define KD_MX(NKV, EP) { constexpr int LDS = 4 * WBLK + 4 * NKV * 64 * 4 + 64 * 128; static LdsAttr set;               \
-    set.ensure(reinterpret_cast<const void*>(gemm_mx8_astat_kernel<NKV, EP>), LDS);                                      \
-    hipLaunchKernelGGL((gemm_mx8_astat_kernel<NKV, EP>), dim3((unsigned)(panels * a.n_splits)), dim3(256), LDS, s, a); }
+#define KD_MX(NKV, EP, C8) { constexpr int LDS = 4 * WBLK + 4 * NKV * 64 * 4 + 64 * 128; static LdsAttr set;           \
+    set.ensure(reinterpret_cast<const void*>(gemm_mx8_astat_kernel<NKV, EP, C8>), LDS);                                  \
+    hipLaunchKernelGGL((gemm_mx8_astat_kernel<NKV, EP, C8>), dim3((unsigned)(panels * a.n_splits)), dim3(256), LDS, s, a); }
   if (d.K == 512) {
-    if (d.epi == KD_EPI_GEGLU) KD_MX(8, KD_EPI_GEGLU) else if (d.epi == KD_EPI_QKV) KD_MX(8, KD_EPI_QKV) else KD_MX(8, KD_EPI_STORE)
+    if (d.epi == KD_EPI_GEGLU) { if (d.c_split) KD_MX(8, KD_EPI_GEGLU, true) else KD_MX(8, KD_EPI_GEGLU, false) }
+    else if (d.epi == KD_EPI_QKV) KD_MX(8, KD_EPI_QKV, false) else KD_MX(8, KD_EPI_STORE, false)
   } else {
-    if (d.epi == KD_EPI_GEGLU) KD_MX(4, KD_EPI_GEGLU) else if (d.epi == KD_EPI_QKV) KD_MX(4, KD_EPI_QKV) else KD_MX(4, KD_EPI_STORE)
+    if (d.epi == KD_EPI_GEGLU) { if (d.c_split) KD_MX(4, KD_EPI_GEGLU, true) else KD_MX(4, KD_EPI_GEGLU, false) }
+    else if (d.epi == KD_EPI_QKV) KD_MX(4, KD_EPI_QKV, false) else KD_MX(4, KD_EPI_STORE, false)
   }
 #undef KD_MX
   return check_launch("kd_gemm_mx8");

@@ -318,8 +318,9 @@ class _Plan:
 
         def mx8_ok(M, N, K, epi):
             """fp8 mode: this norm -> projection of the main chain goes to the block-scaled fp8 matrix instruction (kd_gemm_mx8)."""
-            # (from 4 096 rows on: below that the few-rows bf16 kernels are ahead -- batch 1: 0.512 against 0.552 ms per forward, profiles/r06_bench_detail_full.json)
-            return fp8 and target is self.launches and M >= 4096 and bool(lib.kd_gemm_mx8_supported(M, N, K, epi, 1))
+            # (from 4 096 rows on -- library option mx8_min_rows: below that the few-rows bf16 kernels are ahead -- batch 1: 0.512 against 0.552 ms
+            # per forward, profiles/r06_bench_detail_full.json)
+            return fp8 and target is self.launches and M >= lib.kd_get_option(b"mx8_min_rows", 4096) and bool(lib.kd_gemm_mx8_supported(M, N, K, epi, 1))
 
         def call(what, fn, *args):
             target.append(_Launch(fn, args, what, enc=(fn.__name__, args)))
@@ -533,13 +534,18 @@ class _Plan:
                 self.keep.append(fd)
                 target.append(_Launch(lib.kd_ffn_bf16, (C.byref(fd),), prefix + "ff", enc=("kd_ffn_bf16", (fd,))))
             else:
+                hid8 = None
                 if xn is not None and target is self.launches and prepass(d) and lv.d_ff % 64 == 0:
                     xn_planes = norm_split(prefix + "ff.norm", x, scale_ptr(prefix + "ff.norm")[1], T, d, rps)
                     gemm(prefix + "up_proj", None, mod.ff.up_proj.weight, hid, T, lv.d_ff, d, epi=nat.EPI_GEGLU, a_planes=xn_planes)
                 else:
                     up_mx8 = mx8_ok(T, lv.d_ff, d, nat.EPI_GEGLU)
+                    # fp8 mode: the hidden activation leaves the GEGLU epilogue as e4m3 rows + one power-of-two scale per (row, 32 features) -- in
+                    # the first half of `hid`, the scale bytes behind them -- and the down projection takes both operands as e4m3 by LDS-DMA
+                    down_mx8 = up_mx8 and lv.d_ff % 128 == 0 and bool(lib.kd_gemm_mx8_supported(T, d, lv.d_ff, nat.EPI_RESIDUAL, 0))
+                    hid8 = (hid.data_ptr(), hid.data_ptr() + T * lv.d_ff) if down_mx8 else None
                     du = gemm(prefix + "up_proj", x, mod.ff.up_proj.weight, hid, T, lv.d_ff, d, epi=nat.EPI_GEGLU,
-                              scale_ptr=scale_ptr(prefix + "ff.norm"), scale_stride=total, rows_per_sample=rps, mx8=up_mx8)
+                              scale_ptr=scale_ptr(prefix + "ff.norm"), scale_stride=total, rows_per_sample=rps, mx8=up_mx8, c_planes=hid8)
                     # bf16 mode, rows per sample a multiple of 256: the projection in the attention block's form (a workgroup per (256-row group,
                     # 192-output slice), rows normalised once; csrc/block_bf16.hip: proj_block_bf16_kernel) for grids that fill ONE round of the
                     # chip's 256 CUs (192 .. 256 workgroups): two rounds measured level with the A-stationary kernel (42.3 against 41.5 us at
@@ -548,7 +554,10 @@ class _Plan:
                     if bf and not up_mx8 and target is self.launches and os.environ.get("KDIFF_PROJ_BLOCK", "1") != "0" \
                             and bool(lib.kd_proj_block_bf16_supported(rps, d, lv.d_ff, nat.EPI_GEGLU)) and 192 <= (T // 256) * (lv.d_ff // 192) <= 256:
                         target[-1] = _Launch(lib.kd_proj_block_bf16, (C.byref(du),), prefix + "up_proj(block)", enc=("kd_proj_block_bf16", (du,)))
-                gemm(prefix + "down_proj", hid, mod.ff.down_proj.weight, x, T, d, lv.d_ff, epi=nat.EPI_RESIDUAL, R=x)
+                if hid8 is not None:
+                    gemm(prefix + "down_proj", None, mod.ff.down_proj.weight, x, T, d, lv.d_ff, epi=nat.EPI_RESIDUAL, R=x, a_planes=hid8, mx8=True)
+                else:
+                    gemm(prefix + "down_proj", hid, mod.ff.down_proj.weight, x, T, d, lv.d_ff, epi=nat.EPI_RESIDUAL, R=x)
 
         for li in range(n_lv - 1):
             for i, mod in enumerate(m.down_levels[li]):

@@ -117,11 +117,16 @@ def gemm(A, W, out, *, M, N, K, a_mode=nat.A_PLAIN, epi=nat.EPI_STORE, norm_scal
     d.ph, d.pw, d.chan = patch
     d.eps, d.out_add, d.sigma_data = eps, out_add, sigma_data
     d.W = _chk(W, "W").data_ptr()
-    if a_planes is not None:
+    if a_planes is not None and mx8:          # (e4m3 rows [M, K], E8M0 block-scale bytes [M, K / 32]): kd_gemm_mx8's tiled form
+        d.a_split, d.A, d.A_lo = 1, _chk(a_planes[0], "A e4m3", torch.uint8).data_ptr(), _chk(a_planes[1], "A scales", torch.uint8).data_ptr()
+    elif a_planes is not None:
         d.a_split, d.A, d.A_lo = 1, _chk(a_planes[0], "A hi", torch.bfloat16).data_ptr(), _chk(a_planes[1], "A lo", torch.bfloat16).data_ptr()
     else:
         d.A = _chk(A, "A", a_dt).data_ptr()
-    if c_planes is not None:
+    if c_planes is not None and mx8:          # the GEGLU result as (e4m3 rows [M, N], scale bytes [M, N / 32])
+        d.c_split, d.C, d.C_lo = 1, _chk(c_planes[0], "C e4m3", torch.uint8).data_ptr(), _chk(c_planes[1], "C scales", torch.uint8).data_ptr()
+        out = c_planes
+    elif c_planes is not None:
         d.c_split, d.C, d.C_lo = 1, _chk(c_planes[0], "C hi", torch.bfloat16).data_ptr(), _chk(c_planes[1], "C lo", torch.bfloat16).data_ptr()
         out = c_planes
     else:
@@ -198,7 +203,7 @@ def rms_norm(x, scale, eps=1e-6, out=None):
     return out
 
 
-def norm_linear(x, scale, weight, *, rows_per_sample, epi=nat.EPI_STORE, out=None, eps=1e-6, qk=None, qkv_packed=False, mx8=False):
+def norm_linear(x, scale, weight, *, rows_per_sample, epi=nat.EPI_STORE, out=None, eps=1e-6, qk=None, qkv_packed=False, mx8=False, c_fp8=False):
     """AdaRMSNorm/RMSNorm (:155-166) fused into the following Linear / LinearGEGLU.
     ``scale``: [B, K] per-sample scales (AdaRMSNorm: Linear(cond) + 1) or [K] shared gain.
     ``epi=EPI_QKV`` with ``qk=(scale_h, cos, sin, nh)``: qkv projection whose q, k come out prepared
@@ -206,9 +211,24 @@ def norm_linear(x, scale, weight, *, rows_per_sample, epi=nat.EPI_STORE, out=Non
     K = x.shape[-1]
     M = x.numel() // K
     Nn = weight.shape[0] // (2 if epi == nat.EPI_GEGLU else 1)
+    if c_fp8:            # mx8 + GEGLU: the result as (e4m3 rows [..., N] uint8, E8M0 scale bytes [..., N / 32] uint8) -- linear_mx8's A operand
+        planes = (torch.empty(*x.shape[:-1], Nn, device=x.device, dtype=torch.uint8), torch.empty(*x.shape[:-1], Nn // 32, device=x.device, dtype=torch.uint8))
+        return gemm(x, weight, None, M=M, N=Nn, K=K, epi=epi, norm_scale=scale, scale_stride=K if scale.dim() == 2 else 0,
+                    rows_per_sample=rows_per_sample, eps=eps, precision=_prec_of(x), mx8=True, c_planes=planes)
     out = torch.empty(*x.shape[:-1], Nn, device=x.device, dtype=x.dtype) if out is None else out
     return gemm(x, weight, out, M=M, N=Nn, K=K, epi=epi, norm_scale=scale, scale_stride=K if scale.dim() == 2 else 0,
                 rows_per_sample=rows_per_sample, eps=eps, qk=qk, qkv_packed=qkv_packed, precision=_prec_of(x), mx8=mx8)
+
+
+def linear_mx8(a8, a_scales, weight, residual=None, out=None):
+    """(e4m3 rows [..., K] uint8, E8M0 block-scale bytes [..., K / 32] uint8) @ e4m3(weight[N, K])^T (+ residual, bf16) -> bf16 [..., N]:
+    kd_gemm_mx8's tiled form (the fp8 mode's down projection; both operands e4m3 on the block-scaled matrix instruction)."""
+    K = a8.shape[-1]
+    M = a8.numel() // K
+    Nn = weight.shape[0]
+    out = torch.empty(*a8.shape[:-1], Nn, device=a8.device, dtype=torch.bfloat16) if out is None else out
+    return gemm(None, weight, out, M=M, N=Nn, K=K, epi=nat.EPI_RESIDUAL if residual is not None else nat.EPI_STORE, residual=residual,
+                precision=nat.PREC_BF16, mx8=True, a_planes=(a8, a_scales))
 
 
 def attn_block(x, scale, weight, *, rows_per_sample, qk, out=None, eps=1e-6):

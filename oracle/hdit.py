@@ -291,6 +291,8 @@ def feed_forward_block(sd, prefix, x, cond):
     h = norm_linear(x, cond, sd[prefix + "norm.linear.weight"], sd[prefix + "up_proj.weight"])
     d = h.shape[-1] // 2
     h = h[..., :d] * F.gelu(h[..., d:])                       # linear_geglu (:89-95) on the projection above
+    if MX8 and x.shape[-1] in MX8_WIDTHS and d % 128 == 0:     # fp8 mode: the hidden activation and the down projection's weight are e4m3 too
+        return mx8_quantize_rows(h) @ mx8_quantize_weight(sd[prefix + "down_proj.weight"]).T + x
     return h @ sd[prefix + "down_proj.weight"].T + x
 
 

@@ -21,7 +21,7 @@
   tests/golden/forward_fp8.safetensors       (part "fp8")
       fwd_cifar.denoised / fwd_flowers_na.denoised /      the fp8 ARITHMETIC mode's golden (BASELINE configs[4] "fp8 MFMA weights"; no reference
       smp_cifar_heun50 / smp_flowers_na_sde50_fp8         counterpart: convert_for_inference.py:23): the REFERENCE's own modules with a quantising hook --
-                                                          every qkv_proj / up_proj Linear whose input width the mode takes (256, 512) gets its weight
+                                                          every qkv_proj / up_proj Linear whose input width the mode takes (256, 512), and the down_proj behind such an up_proj, gets its weight
                                                           replaced by its e4m3 / power-of-two-per-channel value (checkpoint.quantize_fp8's rule) and a
                                                           forward pre-hook that rounds its input to e4m3 with one power-of-two scale per 32-k block
                                                           (oracle.hdit.mx8_quantize_rows) -- fp32 arithmetic everywhere else.  Same inputs as the fp32
@@ -89,8 +89,13 @@ def install_mx8_hooks(model):
     n = 0
     for name, mod in model.named_modules():
         # (the mapping network's own up_proj is part of the per-sample conditioning chain, which stays fp32 in every mode)
-        if name.endswith((".qkv_proj", ".up_proj")) and not name.startswith("mapping.") and getattr(mod, "weight", None) is not None \
-                and mod.weight.shape[1] in hdit.MX8_WIDTHS:
+        w = getattr(mod, "weight", None)
+        if w is None or name.startswith("mapping."):
+            continue
+        # norm -> qkv / norm -> up projections of the taken widths, and the down projection behind such an up projection (d_ff a multiple of 128)
+        taken = (name.endswith((".qkv_proj", ".up_proj")) and w.shape[1] in hdit.MX8_WIDTHS) or \
+                (name.endswith(".ff.down_proj") and w.shape[0] in hdit.MX8_WIDTHS and w.shape[1] % 128 == 0)
+        if taken:
             mod.weight.data = hdit.mx8_quantize_weight(mod.weight.data)
             mod.register_forward_pre_hook(lambda m, args: (hdit.mx8_quantize_rows(args[0]),) + tuple(args[1:]))
             n += 1

@@ -914,6 +914,25 @@ def test_gemm_mx8_vs_the_restated_arithmetic(KD, ops, B, T, K, d_ff):
     e = max(relerr(got[..., 0, :, :], q_ref), relerr(got[..., 1, :, :], k_ref), relerr(got[..., 2, :, :], r[..., 2, :, :]))
     print(f"mx8 qkv: vs restated arithmetic {e:.3e}")
     assert e < 8e-3
+    # the hidden activation as the next product's operand (c_split): e4m3 rows + E8M0 scale bytes must be EXACTLY the restated quantiser applied
+    # to the kernel's own fp32 GEGLU values -- checked through the values they decode to, against the bf16 result of the same launch shape --
+    # and the tiled form (both operands e4m3, down projection + residual) against exact products of those decoded operands
+    h8, hs = ops.norm_linear(xb, sc, g(wg), rows_per_sample=T, epi=nat.EPI_GEGLU, mx8=True, c_fp8=True)
+    assert h8.dtype == torch.uint8 and h8.shape == (B, T, d_ff) and hs.shape == (B, T, d_ff // 32)
+    dec = h8.cpu().view(torch.float8_e4m3fn).float().view(B, T, d_ff // 32, 32) * torch.ldexp(torch.ones(()), hs.cpu().to(torch.int32) - 127)[..., None]
+    dec = dec.view(B, T, d_ff)
+    e = relerr(dec, hdit.mx8_quantize_rows(ref))
+    print(f"mx8 GEGLU -> e4m3 hidden: decoded vs the restated quantiser on the restated hidden {e:.3e}")
+    assert e < 7e-2 and relerr(dec, ref) < 7e-2                   # (a last-bit difference of a hidden value moves its e4m3 code by one step: 2^-3 of the block maximum at worst)
+    assert torch.equal(hdit.mx8_quantize_rows(dec), dec)          # what was stored IS a point of the quantiser's grid (block scale minimal, values representable)
+    if lib.kd_gemm_mx8_supported(M, K, d_ff, nat.EPI_RESIDUAL, 0):          # down-projection lengths the tiled form takes: 256, 512, 768, 1536
+        wdn = rn(K, d_ff, seed=13, scale=d_ff ** -0.5)
+        got = ops.linear_mx8(h8, hs, g(wdn), residual=xb)
+        refd = dec @ hdit.mx8_quantize_weight(wdn).T + xr
+        e = relerr(got.float().cpu(), refd)
+        print(f"mx8 tiled down projection K={d_ff} N={K}: vs exact products of the decoded operands {e:.3e}")
+        assert got.dtype == BF and got.shape == (B, T, K) and e < 6e-3
+        assert relerr(ops.linear_mx8(h8, hs, g(wdn)).float().cpu(), dec @ hdit.mx8_quantize_weight(wdn).T) < 6e-3
     # an fp8 checkpoint's weight (already e4m3 x power-of-two channel scale: checkpoint.quantize_fp8) enters bit for bit: the packed image of W
     # and of its fp8-stored value are the same image
     wq8 = KD.checkpoint.fake_quantize_fp8(w)
