@@ -551,6 +551,8 @@ extern "C" int kd_gemm_mx8_supported(int M, int N, int K, int epi, int norm) {
 
 static int mx8_tiled(const KdGemm& d, hipStream_t s) {
   if (!d.A || !d.A_lo || !d.Wp || !d.C || (d.epi == KD_EPI_RESIDUAL && !d.R)) return fail(KD_EINVAL, "kd_gemm_mx8: null operand");
+  if ((reinterpret_cast<size_t>(d.A) & 15) || (reinterpret_cast<size_t>(d.A_lo) & 3))
+    return fail(KD_EINVAL, "kd_gemm_mx8: the e4m3 rows must be 16-byte aligned and their scale bytes 4-byte aligned");
   if (d.epi == KD_EPI_STORE && d.out_add != 0.f) return fail(KD_EINVAL, "kd_gemm_mx8: out_add is not taken");
   const int n_tiles_n = d.N / 128, nkb = d.K / 128;
   TArgs8 a{reinterpret_cast<const unsigned char*>(d.A), reinterpret_cast<const unsigned*>(d.A_lo), reinterpret_cast<const char*>(d.Wp),

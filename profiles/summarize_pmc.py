@@ -39,7 +39,7 @@ def family_of(symbol):
                          ("b16::ffn_kernel", "ffn_bf16"), ("b16::unpatch4_kernel", "gemm_bf16_unpatch4"), ("b16::patchin4_kernel", "gemm_bf16_patchin4"),
                          ("b16::gemm_wstat_kernel", "gemm_bf16_wstat"), ("b16::gemm_astat_kernel", "gemm_bf16_astat"), ("b16::gemm_tiled_kernel", "gemm_bf16_tiled"),
                          ("b16::gemm_generic_bf16_kernel", "gemm_bf16_generic"), ("b16::attn_na2d_bf16_kernel", "attn_na2d_bf16"),
-                         ("b16::attn_block_bf16_kernel", "attn_block_bf16"), ("mx8::gemm_mx8_astat_kernel", "gemm_mx8_astat"), ("b16::proj_block_bf16_kernel", "proj_block_bf16"), ("b16::attn_dense_bf16_kernel<0", "attn_global_bf16"), ("b16::attn_dense_bf16_kernel", "attn_window_bf16"),
+                         ("b16::attn_block_bf16_kernel", "attn_block_bf16"), ("mx8::gemm_mx8_astat_kernel", "gemm_mx8_astat"), ("mx8::gemm_mx8_tiled_kernel", "gemm_mx8_tiled"), ("b16::proj_block_bf16_kernel", "proj_block_bf16"), ("b16::attn_dense_bf16_kernel<0", "attn_global_bf16"), ("b16::attn_dense_bf16_kernel", "attn_window_bf16"),
                          ("b16::attn_long_bf16_kernel", "attn_global_bf16"), ("gemm_astat_kernel", "gemm_astat"), ("attn_na2d_kernel", "attn_na2d"), ("attn_global_split_kernel", "attn_global_bf16x3"), ("attn_dense_kernel<0", "attn_global_f32"),
                          ("attn_dense_kernel<1", "attn_window_f32"), ("sampler_step_kernel", "sampler_step_f32")):
         if needle in symbol:
