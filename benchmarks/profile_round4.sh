@@ -27,8 +27,8 @@ python $R/benchmarks/x3r_bench.py > $OUT/x3r_bench.log 2>&1
 python $R/benchmarks/wg_timeline.py > $OUT/wg_timeline.log 2>&1
 python $R/benchmarks/tiled_bf16_bench.py > $OUT/tiled_bf16_bench.log 2>&1
 python $R/benchmarks/attn_x3_bench.py 30 > $OUT/attn_x3_bench.log 2>&1
-python $R/benchmarks/small_batch.py configs/config_oxford_flowers.json 1 sample_dpmpp_2m 50 configs/config_oxford_flowers.json 4 sample_dpmpp_2m 50 > $OUT/small_batch_bf16.log 2>&1
-KDIFF_GEMM=split3 python $R/benchmarks/small_batch.py configs/config_oxford_flowers.json 1 sample_dpmpp_2m 50 configs/config_oxford_flowers.json 4 sample_dpmpp_2m 50 > $OUT/small_batch_split3.log 2>&1
+# (removed in round 6 with hipGraph replay; bench.py --small-batch) python $R/benchmarks/small_batch.py configs/config_oxford_flowers.json 1 sample_dpmpp_2m 50 configs/config_oxford_flowers.json 4 sample_dpmpp_2m 50 > $OUT/small_batch_bf16.log 2>&1
+# (removed) KDIFF_GEMM=split3 python $R/benchmarks/small_batch.py configs/config_oxford_flowers.json 1 sample_dpmpp_2m 50 configs/config_oxford_flowers.json 4 sample_dpmpp_2m 50 > $OUT/small_batch_split3.log 2>&1
 # 6. socket power / shader clock while the path runs (is it power-limited?)
 for m in split3 bf16 exact; do $R/benchmarks/power_watch.sh $m $([ $m = exact ] && echo 15 || echo 60) > $OUT/power_$m.log 2>&1; done
 # keep what travels back small: the per-dispatch traces of the stats runs are large, the stats tables are not

@@ -19,7 +19,7 @@ for MODE in split3 bf16; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$MODE -o f -- python $R/bench.py --mode $MODE $TINY > $OUT/pmc_fetch_$MODE.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$MODE -o w -- python $R/bench.py --mode $MODE $TINY > $OUT/pmc_write_$MODE.log 2>&1
 done
-python $R/benchmarks/attn_block_bench.py > $OUT/attn_block_bench.log 2>&1
+# (benchmarks/attn_block_bench.py: removed in round 6 with the rendezvous form it compared; its log is profiles/r05_attn_block_bench.log)
 # power management while the headline pass runs: a background loop of passes, the tools beside it
 ( python $R/bench.py --mode split3 --steps 400 --warmup 2 --no-cpu-baseline --no-kernel-events --no-other-configs --no-other-modes --no-power --no-parity --no-small-batch --no-job > /dev/null 2>&1 ) &
 LOAD=$!

@@ -38,6 +38,7 @@ struct MArgs {
   int M, N, n_tiles, n_splits;
   int n_heads; const float* qk_scale; const float* pos; const float* freq;
   int warm;
+  unsigned long long* clk;  // kd_prof_clock_buffer: workgroup 0's time line (s_memtime): [0] entry, [4] rows quantised, [5] / [6] first tile's K loop / epilogue done, [2] exit
 };
 
 // E8M0 exponent byte of the power-of-two block scale 2^(E - 127) >= amax / 448 (smallest such), clamped to [1, 253]
@@ -89,6 +90,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_astat_kernel(const MArgs p) {
   const int nt_begin = (int)((long)p.n_tiles * split / n_splits), nt_end = (int)((long)p.n_tiles * (split + 1) / n_splits);
   const int n_tiles = nt_end - nt_begin, total = n_tiles * NKB;
   const int m0 = panel * 128;
+  const bool probe = p.clk && blockIdx.x == 0 && tid == 0;
+  if (probe) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
 
   const char* wp = p.Wp + (size_t)nt_begin * NKB * WBLK + wid * (PB * 1024) + lane * 16;
   auto issue = [&](int s) {
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_astat_kernel(const MArgs p) {
   for (int s = 0; s < PDIST; ++s)
     if (s < total) issue(s);
   const bool full_panel = m0 + 128 <= p.M;
+  if (probe) p.clk[4] = __builtin_amdgcn_s_memtime();
   u16* crow = p.C + (size_t)rowc * p.N;
   const int rd = lh * 512 + l31 * 16;                  // this lane's 16 bytes inside a (j, ks, h) KiB of a block
 
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_astat_kernel(const MArgs p) {
       }
     }
     const int n0 = (nt_begin + nt) * NCOL;
+    if (probe && nt == 0) p.clk[5] = __builtin_amdgcn_s_memtime();
     if (GEGLU) {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
@@ -334,11 +339,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_astat_kernel(const MArgs p) {
         store_block_bf16(crow + n0 + 32 * j, v, lh, ok);
       }
     }
+    if (probe && nt == 0) p.clk[6] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   }
+  if (probe) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); p.clk[7] = (unsigned long long)n_tiles; }
 }
 
 // ---- tiled form: BOTH operands e4m3 through LDS (down projection + residual of the fp8 mode) ------------------------------------------------
@@ -599,7 +606,7 @@ extern "C" int kd_gemm_mx8(const KdGemm* dp, void* stream) {
           reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(d.Wp) + (size_t)n_tiles * nkb * WBLK), reinterpret_cast<u16*>(d.C),
           reinterpret_cast<unsigned char*>(d.C), reinterpret_cast<unsigned char*>(d.C_lo),
           d.scale, d.scale_stride, d.rows_per_sample, d.eps, d.M, d.N, n_tiles, 1,
-          d.n_heads, d.qk_scale, d.rope_pos, d.rope_freq, option("code_warm", KD_CODE_WARM_DEFAULT)};
+          d.n_heads, d.qk_scale, d.rope_pos, d.rope_freq, option("code_warm", KD_CODE_WARM_DEFAULT), g_clk};
   // n-splits of a panel: gemm_astat's cost model (rounds x (row prologue + tiles per split)), two workgroups per CU
   const int panels = (d.M + 127) / 128, slots = 2 * cu_count();
   int best = 1;
