@@ -943,6 +943,35 @@ def test_gemm_mx8_vs_the_restated_arithmetic(KD, ops, B, T, K, d_ff):
         ops.norm_linear(_bf(rn(1, 64, K, seed=1)), g(scale[:1]), g(w), rows_per_sample=64, mx8=True)
 
 
+@pytest.mark.parametrize("M,K,N", [(8192, 1536, 512), (32768, 768, 256), (40000, 256, 256), (300, 512, 512), (4111, 768, 384), (128, 1536, 128)])
+def test_gemm_mx8_tiled_form(KD, ops, M, K, N):
+    """kd_gemm_mx8's second form (norm = 0, a_split = 1: e4m3 rows + E8M0 block scales x a kd_pack_weight_mx8 image, both operands by LDS-DMA;
+    the fp8 mode's down projection) on operands quantised by the oracle's own quantiser on the host: every K it takes (256, 512, 768, 1536),
+    grids of at most one tile per CU (the 4-slot ring) and larger ones (two workgroups per CU), ragged last row tile, with and without the
+    residual.  The products of e4m3 values are exact and sums are fp32: what remains is summation order + the bf16 rounding of the output."""
+    from k_diffusion_amd import _native as nat
+    assert nat.lib().kd_gemm_mx8_supported(M, N, K, nat.EPI_RESIDUAL, 0) == 1 and nat.lib().kd_gemm_mx8_supported(M, N, 384, nat.EPI_RESIDUAL, 0) == 0
+    u = rn(M, K, seed=4) * torch.logspace(-2, 2, K // 32).repeat_interleave(32)[None, :]       # block maxima over four decades
+    u[5, 64:96] = 0.0
+    blocks = u.view(M, K // 32, 32)
+    s = hdit.mx8_scale(blocks.abs().amax(-1, keepdim=True))
+    q8 = (blocks / s).to(torch.float8_e4m3fn)
+    a8 = q8.view(torch.uint8).reshape(M, K).contiguous()
+    sb = (torch.log2(s).round().to(torch.int32) + 127).to(torch.uint8).reshape(M, K // 32).contiguous()
+    dec = (q8.float() * s).reshape(M, K)
+    assert torch.equal(dec, hdit.mx8_quantize_rows(u))
+    w = rn(N, K, seed=6, scale=K ** -0.5)
+    res = rn(M, N, seed=2)
+    ref = dec.double() @ hdit.mx8_quantize_weight(w).double().T
+    got = ops.linear_mx8(g(a8), g(sb), g(w))
+    got_r = ops.linear_mx8(g(a8), g(sb), g(w), residual=_bf(res))
+    e0, e1 = relerr(got.float().cpu(), ref.float()), relerr(got_r.float().cpu(), (ref + _rt(res).double()).float())
+    print(f"mx8 tiled M={M} K={K} N={N}: store {e0:.3e}, + residual {e1:.3e}")
+    assert got.dtype == BF and got.shape == (M, N) and e0 < 6e-3 and e1 < 6e-3
+    with pytest.raises(RuntimeError):                                # bf16 rows are not this form's operand
+        ops.gemm(_bf(u), g(w), torch.empty(M, N, device=DEV, dtype=BF), M=M, N=N, K=K, precision=nat.PREC_BF16, mx8=True)
+
+
 @pytest.mark.parametrize("nh,B,K", [(8, 32, 512), (8, 3, 512), (4, 16, 256), (4, 5, 256)])
 def test_attn_block_bf16_matches_two_launches(KD, ops, nh, B, K):
     """kd_attn_block_bf16 (round 5: AdaRMSNorm -> qkv projection of a head -> cosine-sim + RoPE -> dense attention in one launch per
