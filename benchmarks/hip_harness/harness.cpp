@@ -226,6 +226,127 @@ static void run_gemm_case(const GemmCase& c) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// fp8 arithmetic mode (kd_gemm_mx8, round 6) from C++: AdaRMSNorm -> up projection + GEGLU with the hidden activation leaving as e4m3 rows +
+// E8M0 block scales (c_split), then the down projection + skip add with both operands in e4m3 (a_split).  The quantiser is restated HERE in
+// plain C++ (a third statement next to the kernel and oracle/hdit.py): e4m3 round-to-nearest-even, power-of-two scales 2^ceil(log2(amax / 448)).
+static float e4m3_rne(float x) {        // the value of x rounded to OCP e4m3 (|x| <= 448)
+  if (x == 0.f) return 0.f;
+  int e;
+  frexpf(fabsf(x), &e);                 // |x| = m 2^e, m in [0.5, 1): binade exponent e - 1
+  const int be = std::max(e - 1, -6);   // below 2^-6: the subnormal spacing
+  const float step = ldexpf(1.f, be - 3);
+  return nearbyintf(x / step) * step;
+}
+static int mx_byte(float amax) {
+  const float r = amax / 448.0f;
+  unsigned b;
+  memcpy(&b, &r, 4);
+  b = (b + 0x7FFFFFu) >> 23;
+  return (int)std::min(253u, std::max(1u, b));
+}
+static float e4m3_decode(uint8_t v) {
+  const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
+  const float x = e == 0 ? ldexpf((float)m, -9) : ldexpf(1.0f + m / 8.0f, e - 7);
+  return s ? -x : x;
+}
+
+static void run_mx8_case(const char* name, int M, int K, int dff, int rps) {
+  if (!want(name)) return;
+  const int B = (M + rps - 1) / rps;
+  auto x_h = to_bf(randn((size_t)M * K));
+  std::vector<float> scale_h((size_t)B * K);
+  for (auto& v : scale_h) v = 1.0f + 0.3f * std::normal_distribution<float>(0, 1)(rng);
+  auto Wg = randn((size_t)2 * dff * K, 1.0f / sqrtf((float)K)), Wd = randn((size_t)K * dff, 1.0f / sqrtf((float)dff));
+  DevBuf<uint16_t> dX(x_h.size()), dOut((size_t)M * K);
+  DevBuf<float> dS(scale_h.size()), dWg(Wg.size()), dWd(Wd.size());
+  DevBuf<uint8_t> dH((size_t)M * dff), dHs((size_t)M * dff / 32);
+  dX.up(x_h); dS.up(scale_h); dWg.up(Wg); dWd.up(Wd);
+  DevBuf<char> dWgp((size_t)kd_packed_weight_bytes_mx8(dff, K, 1)), dWdp((size_t)kd_packed_weight_bytes_mx8(K, dff, 0));
+  if (kd_pack_weight_mx8(dWg.p, dWgp.p, dff, K, 1, nullptr) || kd_pack_weight_mx8(dWd.p, dWdp.p, K, dff, 0, nullptr)) {
+    printf("%s: pack failed: %s\n", name, kd_last_error()); ++g_fail; return;
+  }
+  KdGemm up, dn;
+  memset(&up, 0, sizeof(up)); memset(&dn, 0, sizeof(dn));
+  up.M = M; up.N = dff; up.K = K; up.epi = KD_EPI_GEGLU; up.norm = 1; up.rows_per_sample = rps; up.scale_stride = K; up.eps = 1e-6f;
+  up.A = reinterpret_cast<const float*>(dX.p); up.W = dWg.p; up.Wp = dWgp.p; up.scale = dS.p; up.precision = KD_PREC_BF16;
+  up.c_split = 1; up.C = reinterpret_cast<float*>(dH.p); up.C_lo = dHs.p;
+  dn.M = M; dn.N = K; dn.K = dff; dn.epi = KD_EPI_RESIDUAL; dn.precision = KD_PREC_BF16; dn.W = dWd.p; dn.Wp = dWdp.p;
+  dn.a_split = 1; dn.A = reinterpret_cast<const float*>(dH.p); dn.A_lo = dHs.p;
+  dn.C = reinterpret_cast<float*>(dOut.p); dn.R = reinterpret_cast<const float*>(dX.p);
+  if (!kd_gemm_mx8_supported(M, dff, K, KD_EPI_GEGLU, 1) || !kd_gemm_mx8_supported(M, K, dff, KD_EPI_RESIDUAL, 0)) { printf("%-28s not taken\n", name); return; }
+  if (int rc = kd_gemm_mx8(&up, nullptr)) { printf("%-28s up REJECTED (%d): %s\n", name, rc, kd_last_error()); ++g_fail; return; }
+  if (int rc = kd_gemm_mx8(&dn, nullptr)) { printf("%-28s down REJECTED (%d): %s\n", name, rc, kd_last_error()); ++g_fail; return; }
+  HIPCHK(hipDeviceSynchronize());
+  auto H = dH.down(); auto Hs = dHs.down(); auto Out = dOut.down();
+  // quantised weights (one power-of-two scale per output channel)
+  auto quant_rows = [&](const std::vector<float>& W, int rows, int cols) {
+    std::vector<float> q(W.size());
+    for (int n = 0; n < rows; ++n) {
+      float amax = 0;
+      for (int k = 0; k < cols; ++k) amax = std::max(amax, fabsf(W[(size_t)n * cols + k]));
+      const float s = ldexpf(1.f, mx_byte(amax) - 127);
+      for (int k = 0; k < cols; ++k) q[(size_t)n * cols + k] = e4m3_rne(W[(size_t)n * cols + k] / s) * s;
+    }
+    return q;
+  };
+  const auto Wgq = quant_rows(Wg, 2 * dff, K), Wdq = quant_rows(Wd, K, dff);
+  std::vector<int> rows;
+  for (int i = 0; i < 24; ++i) { rows.push_back(i); rows.push_back(M - 1 - i); }
+  std::uniform_int_distribution<int> rd(0, M - 1);
+  for (int i = 0; i < 80; ++i) rows.push_back(rd(rng));
+  long bad_h = 0, bad_o = 0;
+  double max_eh = 0, max_eo = 0;
+  for (int m : rows) {
+    const int b = m / rps;
+    std::vector<double> uq(K), h(dff);
+    double ssq = 0;
+    for (int kb = 0; kb < K / 32; ++kb) {
+      float u[32], amax = 0;
+      for (int j = 0; j < 32; ++j) {
+        const float xv = bf2f(x_h[(size_t)m * K + kb * 32 + j]);
+        ssq += (double)xv * xv;
+        u[j] = xv * scale_h[(size_t)b * K + kb * 32 + j];
+        amax = std::max(amax, fabsf(u[j]));
+      }
+      const float s = ldexpf(1.f, mx_byte(amax) - 127);
+      for (int j = 0; j < 32; ++j) uq[kb * 32 + j] = (double)(e4m3_rne(u[j] / s) * s);
+    }
+    const double rs = 1.0 / sqrt(ssq / K + 1e-6);
+    for (int n = 0; n < dff; ++n) {
+      double v = 0, g = 0;
+      for (int k = 0; k < K; ++k) { v += uq[k] * Wgq[(size_t)n * K + k]; g += uq[k] * Wgq[(size_t)(dff + n) * K + k]; }
+      h[n] = v * rs * gelu(g * rs);
+    }
+    // the stored hidden row decodes to within one e4m3 rounding of the restated hidden (the kernel's fp32 GEGLU value may sit a last bit away)
+    std::vector<double> hdec(dff);
+    for (int kb = 0; kb < dff / 32; ++kb) {
+      double amax = 0;
+      for (int j = 0; j < 32; ++j) amax = std::max(amax, fabs(h[kb * 32 + j]));
+      const double s = ldexp(1.0, (int)Hs[(size_t)m * (dff / 32) + kb] - 127);
+      for (int j = 0; j < 32; ++j) {
+        hdec[kb * 32 + j] = e4m3_decode(H[(size_t)m * dff + kb * 32 + j]) * s;
+        const double err = fabs(hdec[kb * 32 + j] - h[kb * 32 + j]);
+        max_eh = std::max(max_eh, err / (amax + 1e-30));
+        if (!(err <= amax / 15.0 + 1e-9)) ++bad_h;
+      }
+      if (amax > 0 && !(amax / s <= 448.0 * 1.001 && amax / s > 448.0 / 2 * 0.97)) ++bad_h;      // the block scale is the smallest power of two that fits
+    }
+    for (int n = 0; n < K; ++n) {
+      double o = bf2f(x_h[(size_t)m * K + n]);
+      for (int k = 0; k < dff; ++k) o += hdec[k] * Wdq[(size_t)n * dff + k];
+      const double got = bf2f(Out[(size_t)m * K + n]), err = fabs(got - o);
+      max_eo = std::max(max_eo, err);
+      if (!(err <= 0.01 * fabs(o) + 0.02)) ++bad_o;
+    }
+  }
+  const float us_up = time_us([&] { kd_gemm_mx8(&up, nullptr); }), us_dn = time_us([&] { kd_gemm_mx8(&dn, nullptr); });
+  printf("%-28s M=%6d K=%4d d_ff=%4d  hidden: max err / block max %.3g bad=%ld   down + skip: max|err|=%.4g bad=%ld   up %6.1f us (%6.1f TF/s)  down %6.1f us (%6.1f TF/s)  %s\n",
+         name, M, K, dff, max_eh, bad_h, max_eo, bad_o, us_up, 4.0 * M * (double)dff * K / us_up * 1e-6, us_dn, 2.0 * M * (double)dff * K / us_dn * 1e-6,
+         (bad_h || bad_o) ? "FAIL" : "ok");
+  if (bad_h || bad_o) ++g_fail;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // fused feed-forward block (kd_ffn_bf16) against an fp64 restatement; the two-kernel form (GEGLU GEMM + residual GEMM) timed beside it
 static void run_ffn_case(const char* name, int M, int K, int dff, int rps) {
   if (!want(name)) return;
@@ -615,6 +736,9 @@ int main(int argc, char** argv) {
       {"tiled ragged res", 300, 160, 64, KD_EPI_RESIDUAL, 0, 300, 0},
   };
   for (const auto& c : cases) run_gemm_case(c);
+  run_mx8_case("mx8 L1 ff", 32768, 256, 768, 1024);
+  run_mx8_case("mx8 L2 ff", 8192, 512, 1536, 256);
+  run_mx8_case("mx8 ragged ff", 1000, 256, 768, 50);
   if (want("astat")) {
     const GemmCase ca[] = {
         {"astat L1 qkv", 32768, 768, 256, KD_EPI_QKV, 1, 1024, 4},
