@@ -52,9 +52,9 @@ for name, B, T, d, dff in [("L1", 32, 1024, 256, 768), ("L2", 32, 256, 512, 1536
     wq = (torch.randn(3 * d, d, generator=g) * d ** -0.5).to(dev)
     nh = d // 64
     H = W = int(T ** 0.5)
-    from oracle import hdit
     import numpy as np
-    qk = (torch.linspace(5.0, 12.0, nh).to(dev), hdit.axial_pos(H, W).reshape(T, 2).contiguous().to(dev), (hdit.rope_freqs(nh) / (2 * np.pi)).contiguous().to(dev), nh)
+    rope = K.models.axial_rope
+    qk = (torch.linspace(5.0, 12.0, nh).to(dev), rope.make_axial_pos(H, W).reshape(T, 2).contiguous().to(dev), (rope.rope_freqs(32, nh) / (2 * np.pi)).contiguous().to(dev), nh)
     cases = [("GEGLU", dict(epi=nat.EPI_GEGLU), wg), ("qkv", dict(epi=nat.EPI_QKV, qk=qk), wq)]
     for what, kw, w in cases:
         f16 = lambda: ops.norm_linear(x, scale, w, rows_per_sample=T, **kw)  # noqa: E731

@@ -14,7 +14,6 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["KDIFF_GEMM"] = "split3"
 import k_diffusion_amd as K  # noqa: E402
-from oracle import hdit  # noqa: E402  (axial positions / rope frequencies of the test inputs only)
 
 nat, ops = K._native, K.ops
 dev = "cuda"
@@ -75,9 +74,10 @@ for name, B, H, W, nh, Kd, dff in LEVELS:
     wo = (torch.randn(Kd, Kd, generator=g) * Kd ** -0.5).to(dev)
     att = torch.randn(B, T, Kd, generator=g).to(dev)
     qs = torch.linspace(5.0, 12.0, nh).to(dev)
-    pos, freqs = hdit.axial_pos(H, W).reshape(T, 2), hdit.rope_freqs(nh)
-    theta = hdit.rope_theta(hdit.axial_pos(H, W), freqs).reshape(T, nh, 16)
-    qk = (qs, torch.cos(theta).to(dev), torch.sin(theta).to(dev), nh, pos.contiguous().to(dev), (freqs / (2 * np.pi)).contiguous().to(dev))
+    rope = K.models.axial_rope                  # the product's own position / frequency helpers (nothing outside tests/ imports the oracle)
+    pos, freqs = rope.make_axial_pos(H, W).reshape(T, 2), rope.rope_freqs(32, nh)
+    cos_t, sin_t = rope.rope_tables(pos.reshape(H, W, 2), freqs)
+    qk = (qs, cos_t.to(dev), sin_t.to(dev), nh, pos.contiguous().to(dev), (freqs / (2 * np.pi)).contiguous().to(dev))
     oq, og = torch.empty(B, T, 3 * d, device=dev), torch.empty(B, T, dff, device=dev)
     cases = [("qkv (norm -> projection + cosine-sim + RoPE)", lambda: ops.norm_linear(x, scale, wq, rows_per_sample=T, epi=nat.EPI_QKV, qk=qk, qkv_packed=True, out=oq))]
     if Kd <= 256:
