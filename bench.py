@@ -89,6 +89,8 @@ def parse(argv=None):
                                                                               "launcher's CPU test together with --stub-workload)")
     p.add_argument("--stub-workload", action="store_true",
                    help="launcher / rank-plumbing test: a tiny CPU tensor op per pass instead of the sampler (no GPU, no kernels; the line says so and is no measurement)")
+    for gone in ("--no-other-configs", "--no-power", "--no-small-batch", "--no-job"):     # rounds 2 - 5: these blocks were on by default; the command
+        p.add_argument(gone, action="store_true", help=argparse.SUPPRESS)                 # lists of benchmarks/profile_round*.sh still name the flags
     args = p.parse_args(argv)
     if args.detail:
         args.other_configs = args.small_batch = args.job = True
