@@ -55,6 +55,8 @@ __device__ __forceinline__ void glds16(const void* src, void* dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
 
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
 __device__ __forceinline__ void wait_vm_dyn8(int n) {
   switch (n) {
 #define KD_C(v) case v: asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); break;
@@ -154,42 +156,45 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_astat_kernel(const MArgs p) {
       }
       if (NR > 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    float ssq = 0.f;
+    // packed fp32 arithmetic throughout (two elements per v_pk_mul / v_pk_fma; the block maxima by v_max3 with |.| modifiers): this prologue is
+    // vector-issue bound and every n-split of a panel repeats it
+    f32x2 ssq2 = {0.f, 0.f};
     const float* spl = reinterpret_cast<const float*>(scl);
 #pragma unroll
     for (int ks = 0; ks < NK64; ++ks) {
-      float y[32];
+      f32x2 y[16];
       float amax[2] = {0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int k0 = 64 * ks + 32 * (u >> 1) + 16 * lh + 8 * (u & 1);
         const f32x4 s0 = *reinterpret_cast<const f32x4*>((uni ? spl : sp) + k0), s1 = *reinterpret_cast<const f32x4*>((uni ? spl : sp) + k0 + 4);
-        float x[8];
+        const f32x2 sc[4] = {{s0[0], s0[1]}, {s0[2], s0[3]}, {s1[0], s1[1]}, {s1[2], s1[3]}};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { x[2 * e] = bf_lo(raw[ks][u][e]); x[2 * e + 1] = bf_hi(raw[ks][u][e]); }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          ssq = fmaf(x[e], x[e], ssq);
-          const float v = x[e] * (e < 4 ? s0[e] : s1[e - 4]);
-          y[8 * u + e] = v;
-          amax[u >> 1] = fmaxf(amax[u >> 1], fabsf(v));
+        for (int e = 0; e < 4; ++e) {
+          const f32x2 x = {bf_lo(raw[ks][u][e]), bf_hi(raw[ks][u][e])};
+          ssq2 = __builtin_elementwise_fma(x, x, ssq2);
+          const f32x2 v = x * sc[e];
+          y[4 * u + e] = v;
+          amax[u >> 1] = max3f(amax[u >> 1], fabsf(v.x), fabsf(v.y));
         }
       }
       // a 32-k block lives in BOTH lanes of a row (16 values each): its maximum is the larger of the two halves'
       unsigned sb[2];
-      float inv[2];
+      f32x2 inv[2];
 #pragma unroll
       for (int bk = 0; bk < 2; ++bk) {
         amax[bk] = fmaxf(amax[bk], __shfl_xor(amax[bk], 32, 64));
         sb[bk] = mx_scale_byte(amax[bk]);
-        inv[bk] = mx_inv_scale(sb[bk]);
+        const float iv = mx_inv_scale(sb[bk]);
+        inv[bk] = f32x2{iv, iv};
       }
       i32x8 f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) {
+        const f32x2 q0 = y[2 * w] * inv[w >> 2], q1 = y[2 * w + 1] * inv[w >> 2];
         int pk = 0;
-        pk = __builtin_amdgcn_cvt_pk_fp8_f32(y[4 * w] * inv[w >> 2], y[4 * w + 1] * inv[w >> 2], pk, false);
-        pk = __builtin_amdgcn_cvt_pk_fp8_f32(y[4 * w + 2] * inv[w >> 2], y[4 * w + 3] * inv[w >> 2], pk, true);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(q0.x, q0.y, pk, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(q1.x, q1.y, pk, true);
         f[w] = pk;
       }
       asm volatile("" : "+v"(f));                      // materialise the fragment here (see gemm_astat_kernel)
@@ -197,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mx8_astat_kernel(const MArgs p) {
       asc[ks] = (int)((lh ? sb[1] : sb[0]) * 0x01010101u);      // block b's byte is read from the lane half b of the row
       __builtin_amdgcn_sched_barrier(0);
     }
+    float ssq = ssq2.x + ssq2.y;
     ssq += __shfl_xor(ssq, 32, 64);
     rs = rsqrtf(ssq / (float)K + p.eps);
   }
