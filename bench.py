@@ -87,6 +87,9 @@ def parse(argv=None):
     p.add_argument("--no-parity", action="store_true", help="skip the golden-vector parity block (the 50-step batch-32 golden of this workload per measured mode)")
     p.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="process-group backend (default: nccl = RCCL on a GPU box; gloo is for the "
                                                                               "launcher's CPU test together with --stub-workload)")
+    p.add_argument("--force-collectives", action="store_true",
+                   help="with --gpus 1: create the one-rank RCCL group and run the N-GPU pass (sampling + uint8 conversion + all-gather) anyway -- "
+                        "how a 1-GPU box exercises the calls of the 8-GPU job (tests/test_model_gpu.py)")
     p.add_argument("--stub-workload", action="store_true",
                    help="launcher / rank-plumbing test: a tiny CPU tensor op per pass instead of the sampler (no GPU, no kernels; the line says so and is no measurement)")
     for gone in ("--no-other-configs", "--no-power", "--no-small-batch", "--no-job"):     # rounds 2 - 5: these blocks were on by default; the command
@@ -490,7 +493,7 @@ class Timed:
         ctx.wait_for_everyone()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if ctx.num_processes > 1:
+        if ctx.collectives:
             t = torch.tensor([dt], device=ctx.device, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = t.item()
@@ -642,7 +645,23 @@ def emit(result, detail_file):
             result = dict(result, detail_file_error=str(e))
             detail_file = None
     sys.stderr.flush()
-    print(json.dumps(compact_line(result, detail_file)), flush=True)
+    print(json.dumps(compact_line(result, detail_file)), file=LINE_OUT or sys.stdout, flush=True)
+
+
+LINE_OUT = None
+
+
+def claim_stdout():
+    """The JSON line is the ONLY thing a rank of this job writes to the stdout it was started with: the line goes to a duplicate of that
+    descriptor and descriptor 1 itself is pointed at stderr for everything else.  RCCL announces itself with a C-level printf
+    ("Librccl path : ...") whose stdio buffer is flushed at process exit -- i.e. AFTER the line, on every rank -- and gloo prints its
+    connection notes the same way; a reader that takes the last line of stdout would get those instead
+    (tests/test_model_gpu.py::test_bench_runs_the_n_gpu_pass_over_rccl_on_one_gpu caught it on the hardware)."""
+    global LINE_OUT
+    if LINE_OUT is None:
+        sys.stdout.flush()
+        LINE_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
 
 
 def launch_ranks(args):
@@ -697,17 +716,18 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)                         # does not return
+    claim_stdout()
     os.environ["KDIFF_GEMM"] = args.mode
     if args.stub_workload:
         ctx = K.distributed.RankContext(device="cpu", backend=args.backend or "gloo")
     else:
-        ctx = K.distributed.RankContext(backend=args.backend)
+        ctx = K.distributed.RankContext(backend=args.backend, force_collectives=args.force_collectives)
     if ctx.num_processes != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.num_processes}: start it plainly (python bench.py --gpus N launches its own ranks) "
                          f"or under torch.distributed.run with --nproc-per-node {args.gpus}")
     if args.stub_workload:
         return stub_line(args, ctx)
-    if args.gpus > 1:
+    if ctx.collectives:
         assert torch.distributed.get_world_size() == args.gpus and torch.distributed.get_backend() == "nccl", "one rank per GPU over RCCL"
     if ctx.device.type != "cuda":
         raise SystemExit("bench.py needs an MI355X: no ROCm device visible (there is no CPU fallback for the hot path)")
@@ -730,7 +750,7 @@ def main():
 
     def one_pass():
         imgs = sampler(den, x0, sigmas, extra_args=extra, disable=True)
-        if ctx.num_processes == 1:
+        if not ctx.collectives:
             return imgs
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -773,7 +793,7 @@ def main():
             "config": {"workload": f"{os.path.basename(args.config)} {mc['input_size'][0]}x{mc['input_size'][1]}, {args.sampler} "
                                    f"{args.sampler_steps} steps, batch {B}/GPU, all-gather of finished images",
                        "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus} (independent images, one final all-gather)",
-                       "rccl_nranks": torch.distributed.get_world_size() if args.gpus > 1 else 1,
+                       "rccl_nranks": torch.distributed.get_world_size() if ctx.collectives else 1,
                        "launcher": os.environ.get("KDIFF_BENCH_LAUNCHER", "external") if args.gpus > 1 else None,
                        "gather": {"ms_per_step": round(gather_ms, 3), "dtype": args.gather, "bytes_per_rank": px * (1 if args.gather == "uint8" else 4),
                                   "bytes_per_rank_uint8": px, "bytes_per_rank_fp32": 4 * px,

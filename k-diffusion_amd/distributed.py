@@ -14,7 +14,9 @@ import torch.distributed as dist
 
 
 class RankContext:
-    def __init__(self, device=None, backend=None):
+    def __init__(self, device=None, backend=None, force_collectives=False):
+        """``force_collectives``: create the process group and issue the collectives even when WORLD_SIZE == 1 (a one-rank RCCL
+        communicator: how the 1-GPU test box exercises the very calls the N-GPU job makes)."""
         self.num_processes = int(os.environ.get("WORLD_SIZE", "1"))
         self.process_index = int(os.environ.get("RANK", "0"))
         self.local_process_index = int(os.environ.get("LOCAL_RANK", "0"))
@@ -26,7 +28,8 @@ class RankContext:
                 device = torch.device("cpu")
         self.device = torch.device(device)
         self._owns_group = False
-        if self.num_processes > 1 and not dist.is_initialized():
+        self.collectives = self.num_processes > 1 or force_collectives
+        if self.collectives and not dist.is_initialized():
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # RCCL over dmabuf IPC (the host driver has no legacy IPC)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
@@ -45,7 +48,7 @@ class RankContext:
 
     def gather(self, tensor):
         """All-gather along dim 0 (every rank must pass the same shape), like Accelerator.gather."""
-        if self.num_processes == 1:
+        if not self.collectives:
             return tensor
         tensor = tensor.contiguous()
         out = torch.empty((self.num_processes * tensor.shape[0], *tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
@@ -53,7 +56,7 @@ class RankContext:
         return out
 
     def wait_for_everyone(self):
-        if self.num_processes > 1:
+        if self.collectives:
             dist.barrier()
 
     def print(self, *args, **kwargs):

@@ -680,6 +680,9 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert len(lines) == 1, r.stdout
     # what the driver reads: the line is the LAST thing on stdout, short enough for any tail, strict JSON; stderr stays quiet
     assert r.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096 and len(r.stderr) < 2000, (len(lines[0]), r.stderr[-2000:])
+    # ... and the ONLY thing: what the collective library prints to descriptor 1 from C (gloo's connection notes here, RCCL's "Librccl path"
+    # on the GPU box -- flushed at process exit, i.e. behind the line) goes to stderr (bench.py: claim_stdout)
+    assert r.stdout.strip() == lines[0], r.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["data"] == "stub"
     assert line["config"]["nranks"] == 2 and line["config"]["backend"] == "gloo" and line["config"]["ranks_in_gather"] == [0, 1]
@@ -689,7 +692,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
                         os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--backend", "gloo", "--stub-workload"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    line = json.loads(r.stdout)                                          # nothing but the line
     assert line["config"]["launcher"] == "external" and line["config"]["nranks"] == 2
     # a world size that contradicts --gpus is refused with the way out spelled out
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--stub-workload"], env=dict(env, WORLD_SIZE="1", RANK="0"),
