@@ -218,6 +218,8 @@ class _Loop:
         """[len(values), B] device table of per-sample sigma vectors (sigma * s_in): row i is the sigma argument of one
         model call of the run.  The model is told so (``prefetch_schedule``): the conditioning chain is a function of
         sigma / class / ... only, so a model that takes the hint runs it once for the whole table instead of once per call."""
+        if not len(values):                  # a schedule of the terminal sigma only: no model call, the loop body never runs (the reference's trange(0))
+            return torch.empty((0, self.B), device=self.x.device, dtype=torch.float32)
         v = torch.stack([torch.as_tensor(s, dtype=torch.float32).reshape(()) for s in values])
         v = v.pin_memory() if self.x.is_cuda and len(values) else v      # (a pageable .to(device) ends with a stream synchronisation)
         table = v.to(self.x.device, non_blocking=True)[:, None].expand(len(values), self.B).contiguous()
