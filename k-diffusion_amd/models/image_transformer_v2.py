@@ -44,6 +44,7 @@ SCHEDULE_TABLE_MAX_BYTES = 1 << 30
 SCHEDULES_KEPT = 4            # a run of a two-stage solver hints two tables; older records (and their tensors) are dropped
 SCHEDULE_CHAINS_KEPT = 2      # conditioning workspaces kept per plan, by schedule length (least recently used dropped)
 # environment switches read while a plan is built (name, default): part of the plan key
+MAX_PLANS = 16     # cached launch plans (one per batch / size / conditioning kinds / device / arithmetic mode / switches) per model: least recently used beyond that
 PLAN_SWITCHES = (("KDIFF_ATTN_BLOCK", "1"), ("KDIFF_PROJ_BLOCK", "1"), ("KDIFF_FFN_OUT", "all"), ("KDIFF_RUN_LIST", "1"))
 CLASS_IDS_KEPT = 4            # range-checked class_cond tensors remembered per plan (cond / uncond pairs of a guidance wrapper)
 
@@ -865,9 +866,18 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         key = (B, H, W, aug_cond is not None, has_class, self.mapping_cond_in_proj is not None, x.device, nat.default_precision()) \
             + tuple(os.environ.get(k, d) for k, d in PLAN_SWITCHES)
         plan = self._plans.get(key)
+        if plan is not None and len(self._plans) > 1:
+            self._plans[key] = self._plans.pop(key)                # most recently used last (dicts keep insertion order)
         if plan is None and create:
             if self.patch_in.proj.weight.device != x.device:
                 raise RuntimeError(f"model weights are on {self.patch_in.proj.weight.device}, input on {x.device}")
+            if len(self._plans) >= MAX_PLANS:
+                # a plan owns the workspaces of its shape (~20 MB per 256 x 256 image in the fp32 modes): a caller that walks through
+                # batch sizes would otherwise keep them all.  The least recently used one goes; its side-stream work (conditioning
+                # prefetch) may still be in flight in buffers the allocator would hand out again at once, hence the device-wide wait
+                # (rare: only when a NEW shape arrives with MAX_PLANS shapes cached).
+                torch.cuda.synchronize(x.device)
+                del self._plans[next(iter(self._plans))]
             with torch.inference_mode(False):     # (workspaces made under inference_mode could not be written in place outside it later)
                 plan = self._plans[key] = _Plan(self, B, H, W, key[3], has_class, key[5], x.device)
         if plan is not None and has_class and class_cond is not None:
