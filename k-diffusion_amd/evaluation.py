@@ -72,4 +72,6 @@ def compute_features_indexed(accelerator, sample_fn, n, batch_size, post=None, o
         for r, (lo, count) in enumerate(shares):
             if count:
                 out[lo:lo + count] = g_x[r * width:r * width + count]
+    if out is None:                  # n == 0: no round ran and nothing tells the sample shape (the reference's torch.cat of no batches raises here)
+        out = torch.empty(0, device=accelerator.device)
     return out

@@ -732,8 +732,10 @@ def test_indexed_rounds_and_the_schedule_callback(KD):
         assert all(cnt <= width <= bs for width, shares in rounds for _, cnt in shares)
 
     class One:
-        num_processes, process_index, is_main_process = 1, 0, False
+        num_processes, process_index, is_main_process, device = 1, 0, False, torch.device("cpu")
         gather = staticmethod(lambda t: t)
+    # n = 0: no round, no call of the sample_fn, an empty result (`sample.py -n 0` writes nothing)
+    assert ev.indexed_rounds(0, 4, 3) == [] and ev.compute_features_indexed(One(), lambda idx: 1 / 0, 0, 3).shape == (0,)
     seen, calls = [], []
     out = ev.compute_features_indexed(One(), lambda idx: (calls.append(idx.tolist()), idx.float()[:, None] * torch.ones(1, 2))[1], 7, 3, on_schedule=seen.append)
     assert [p.tolist() for p in seen[0]] == [[0, 1, 2], [3, 4, 5], [6]] == calls
