@@ -62,3 +62,21 @@ class DenoiserWithVariance(Denoiser):
 
 class SimpleLossDenoiser(Denoiser):
     """``loss_config == 'simple'`` (config.py:229-230; layers.py:104-111): again only ``loss`` differs in the reference."""
+
+
+class FourierFeatures(nn.Module):
+    """``cat[cos, sin](2 pi x W^T)`` with ``W`` a ``randn([out_features // 2, in_features]) * std`` BUFFER (k_diffusion/layers.py:285-293; the
+    model's ``time_emb`` and ``aug_emb``, image_transformer_v2.py:677-680, whose state_dict entries are this buffer).  The model itself reaches
+    the kernel directly (``ops.fourier_sigma`` folds ``c_noise = log(sigma) / 4`` in); this is the stand-alone module of the reference's
+    surface, on the same kernel (``kd_fourier_f32``: angles in revolutions, hardware sin / cos).  ROCm tensors only, like every op here."""
+
+    def __init__(self, in_features, out_features, std=1.):
+        super().__init__()
+        assert out_features % 2 == 0
+        self.register_buffer('weight', torch.randn([out_features // 2, in_features]) * std)
+
+    def forward(self, input):
+        x = input.to(torch.float32)
+        if x.shape[-1] != self.weight.shape[1]:
+            raise ValueError(f'FourierFeatures: last dimension {x.shape[-1]} != in_features {self.weight.shape[1]}')
+        return ops.fourier_features(x.contiguous(), self.weight.to(torch.float32).contiguous())
