@@ -1418,3 +1418,53 @@ def test_bf16_merge_split_patch(ops, golden):
     assert out.dtype == torch.float32
     f = hdit.token_split(hdit.rms_norm(_rt(tok), gain), _rt(w_out), 4, 4).movedim(-1, 1)
     assert relerr(out, f * c_out.view(-1, 1, 1, 1) + img * c_skip.view(-1, 1, 1, 1)) < 5e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_third_party_operator_signatures_on_the_hip_cores(KD, gtol, dtype):
+    """compat.na2d / flash_attn_qkvpacked_func / scaled_dot_product_attention: the operators the reference's model calls
+    (image_transformer_v2.py:428, :383, :392), with their own signatures, layouts and default scales, against the oracle's restatement
+    (fp32 on the CPU) -- at the reference's scale = 1.0 and at the libraries' defaults."""
+    C = KD.compat
+    tol = gtol if dtype == torch.float32 else 2e-2
+    g = torch.Generator().manual_seed(4)
+    n, h, w, nh, e = 2, 12, 20, 3, 64
+    q, k, v = (torch.randn(n, h, w, nh, e, generator=g) * 0.7 for _ in range(3))
+    dq, dk, dv = (t.to(DEV, dtype) for t in (q, k, v))
+    # natten.functional.na2d: [n, h, w, nh, e], default scale e ** -0.5
+    import os
+    exact = dtype == torch.float32 and os.environ["KDIFF_GEMM"] == "exact"
+    if exact:
+        with pytest.raises(NotImplementedError):                      # the exact-fp32 neighbourhood core: kernel size 7 only
+            C.na2d(dq, dk, dv, 5)
+    for ks, scale in ((7, 1.0), (7, None)) if exact else ((7, 1.0), (5, None), ((3, 3), 0.3), (11, 1.0)):
+        want = hdit.na2d(q, k, v, ks if isinstance(ks, int) else ks[0], e ** -0.5 if scale is None else scale)
+        got = C.na2d(dq, dk, dv, ks) if scale is None else C.na2d(dq, dk, dv, kernel_size=ks, scale=scale)
+        assert got.shape == want.shape and got.dtype == dtype and relerr(got.float(), want) < tol, (ks, scale, relerr(got.float(), want))
+    # flash_attn_qkvpacked_func: [n, s, 3, nh, e] -> [n, s, nh, e]
+    s = h * w
+    packed = torch.stack([q.reshape(n, s, nh, e), k.reshape(n, s, nh, e), v.reshape(n, s, nh, e)], dim=2)
+    for scale in (1.0, None):
+        want = hdit.attn_global(q, k, v, e ** -0.5 if scale is None else scale).reshape(n, s, nh, e)
+        got = C.flash_attn_qkvpacked_func(packed.to(DEV, dtype), softmax_scale=scale)
+        assert got.shape == (n, s, nh, e) and relerr(got.float(), want) < tol, scale
+    # F.scaled_dot_product_attention: [n, nh, s, e]
+    hq, hk, hv = (t.reshape(n, s, nh, e).permute(0, 2, 1, 3) for t in (q, k, v))
+    for scale in (1.0, None):
+        want = hdit.attn_global(q, k, v, e ** -0.5 if scale is None else scale).reshape(n, s, nh, e).permute(0, 2, 1, 3)
+        got = C.scaled_dot_product_attention(hq.to(DEV, dtype), hk.to(DEV, dtype), hv.to(DEV, dtype), scale=scale)
+        assert got.shape == (n, nh, s, e) and relerr(got.float(), want) < tol, scale
+        if dtype == torch.float32:      # and against torch's own operator on the device
+            ref = torch.nn.functional.scaled_dot_product_attention(hq.to(DEV), hk.to(DEV), hv.to(DEV), scale=scale)
+            assert relerr(got, ref) < 1e-4
+    # what the cores do not do is an error, not a silent approximation
+    with pytest.raises(NotImplementedError):
+        C.na2d(dq, dk, dv, 7, dilation=2)
+    with pytest.raises(NotImplementedError):
+        C.scaled_dot_product_attention(hq.to(DEV), hk.to(DEV), hv.to(DEV), attn_mask=torch.ones(s, s, dtype=torch.bool, device=DEV))
+    with pytest.raises(NotImplementedError):
+        C.flash_attn_qkvpacked_func(packed.to(DEV), causal=True)
+    with pytest.raises(NotImplementedError):
+        C.na2d(dq[..., :32], dk[..., :32], dv[..., :32], 7)
+    with pytest.raises(RuntimeError):
+        C.na2d(q, k, v, 7)                                            # CPU tensors: no fallback
