@@ -23,6 +23,7 @@ The plan (workspace + prebuilt launch descriptors) is cached per input shape.  T
 CPU path: calling ``forward`` without a ROCm device or without the built library raises.
 """
 import ctypes as C
+import gc
 import itertools
 import operator
 import weakref
@@ -212,6 +213,12 @@ class _Schedule:
 class _Plan:
     """Workspace + prebuilt launch list for one (batch, H, W, conditioning-kinds) combination."""
 
+    def release(self):
+        """Give the workspaces back NOW: a plan's launch lists and conditioning chains close over the plan and over each other (reference
+        cycles), so dropping the last outside reference would leave ~20 MB per image allocated until Python's cycle collector happens to run.
+        The callers (eviction, ``_drop_plans``: rare events) run the collector once behind this for the helper objects' own cycles."""
+        self.__dict__.clear()
+
     def __init__(self, model, B, H, W, has_aug, has_class, has_mapping_cond, device):
         lib = nat.lib()
         m = model
@@ -264,7 +271,13 @@ class _Plan:
         for name, mod in norm_mods:
             offsets[name] = total
             total += mod.linear.weight.shape[0]
-        wcat = torch.cat([mod.linear.weight.detach() for _, mod in norm_mods], dim=0).contiguous()
+        # one concatenation of the AdaRMSNorm projections per MODEL, not per plan: it is a function of the weights only, and the packed-image
+        # cache keeps its source alive -- made per plan, every batch size ever seen left 2 x 7.5 MB behind (256 x 256 configs) until the
+        # weights changed.  (model._packed goes with the plans whenever the weights do.)
+        wcat_ent = m._packed.get("ada_norm_wcat")
+        if wcat_ent is None or wcat_ent.device != device:
+            wcat_ent = m._packed["ada_norm_wcat"] = torch.cat([mod.linear.weight.detach() for _, mod in norm_mods], dim=0).contiguous()
+        wcat = wcat_ent
         # AdaRMSNorm scale tables, ping-pong: the main chain reads one while the next step's table is being written
         self.scales = [torch.empty(B, total, **f32), torch.empty(B, total, **f32)]
         self.norm_descs = []                                # (descriptor, byte offset into a scale table)
@@ -718,6 +731,19 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         freq = sa.pos_emb.freqs.detach().to(torch.float32).cpu() / (2.0 * math.pi)
         return pos.reshape(-1, 2).to(torch.float32).contiguous().to(device), freq.contiguous().to(device)
 
+    def _drop_plans(self):
+        """All cached plans go, workspaces at once (``_Plan.release``).  The device is idle first: a plan's side-stream work may still be
+        reading buffers the allocator would hand out again."""
+        if self._plans:
+            dev = next(iter(self._plans))[6]
+            if getattr(dev, "type", "cpu") == "cuda":
+                torch.cuda.synchronize(dev)
+            for plan in self._plans.values():
+                plan.release()
+            self._plans = {}
+            gc.collect()
+        self._plans = {}
+
     def invalidate(self):
         """Drop the plans and packed weight images at the next call.  Needed only after an IN-PLACE edit of weights that were created
         under torch.inference_mode() outside load_state_dict / .to(): such tensors carry no version counter, so the edit leaves no trace
@@ -852,7 +878,8 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         if fp != self._fingerprint:
             if not create:
                 return None
-            self._plans, self._fingerprint, self._packed = {}, fp, {}
+            self._drop_plans()
+            self._fingerprint, self._packed = fp, {}
         has_class = self.class_emb is not None
         # Kernel selection is fixed when a plan is built: by the arithmetic mode, by the environment switches read in _Plan and by
         # library options (kd_ffn_f32_supported follows "ffn_x3").  The switches are part of the key; a change of any library option
@@ -862,7 +889,8 @@ class ImageTransformerDenoiserModelV2(nn.Module):
         if self._plans_epoch != nat.option_epoch:
             if not create:
                 return None
-            self._plans, self._plans_epoch = {}, nat.option_epoch
+            self._drop_plans()
+            self._plans_epoch = nat.option_epoch
         key = (B, H, W, aug_cond is not None, has_class, self.mapping_cond_in_proj is not None, x.device, nat.default_precision()) \
             + tuple(os.environ.get(k, d) for k, d in PLAN_SWITCHES)
         plan = self._plans.get(key)
@@ -877,7 +905,8 @@ class ImageTransformerDenoiserModelV2(nn.Module):
                 # prefetch) may still be in flight in buffers the allocator would hand out again at once, hence the device-wide wait
                 # (rare: only when a NEW shape arrives with MAX_PLANS shapes cached).
                 torch.cuda.synchronize(x.device)
-                del self._plans[next(iter(self._plans))]
+                self._plans.pop(next(iter(self._plans))).release()
+                gc.collect()
             with torch.inference_mode(False):     # (workspaces made under inference_mode could not be written in place outside it later)
                 plan = self._plans[key] = _Plan(self, B, H, W, key[3], has_class, key[5], x.device)
         if plan is not None and has_class and class_cond is not None:

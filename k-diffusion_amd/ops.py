@@ -77,7 +77,11 @@ def pack_weight(W, N, K, geglu, cache=True, bf16=False):
                 del _packed[k]
             if len(_packed) > 512:
                 _packed.clear()
-        _packed[key] = (weakref.ref(W), W._version, (tuple(W.shape), N, K, geglu, W.data_ptr()), img)
+        def gone(ref, key=key):               # the weight died: its image goes with it (plans pack per-plan concatenations of weights)
+            ent = _packed.get(key)
+            if ent is not None and ent[0] is ref:
+                del _packed[key]
+        _packed[key] = (weakref.ref(W, gone), W._version, (tuple(W.shape), N, K, geglu, W.data_ptr()), img)
     return img
 
 
