@@ -14,6 +14,15 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+
+def _free_port():
+    """A port asked of the kernel: fixed rendezvous ports collide when two runs of the suite share a host."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def header_symbols():
     src = open(os.path.join(REPO, "include", "kdiff_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
@@ -454,7 +463,7 @@ def test_indexed_gather_many_ranks_over_gloo(KD, tmp_path, world, n, bs, port):
     script.write_text(_WORKER_INDEXED.format(repo=REPO, out=out, world=world, n=n, bs=bs))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     got, got8 = torch.load(out)
@@ -479,7 +488,7 @@ def test_two_rank_gather_over_gloo(KD, tmp_path):
     script.write_text(_WORKER.format(repo=REPO, out=out))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29613", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     got = torch.load(out)
@@ -739,7 +748,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert line["config"]["nranks"] == 2 and line["config"]["backend"] == "gloo" and line["config"]["ranks_in_gather"] == [0, 1]
     assert line["config"]["launcher"] == "self"
     # started under the launcher by somebody else (what the driver's multi-GPU command does): no second launch, launcher reported as external
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29655",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                         os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--backend", "gloo", "--stub-workload"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
