@@ -20,6 +20,9 @@ class RankContext:
         self.num_processes = int(os.environ.get("WORLD_SIZE", "1"))
         self.process_index = int(os.environ.get("RANK", "0"))
         self.local_process_index = int(os.environ.get("LOCAL_RANK", "0"))
+        # RCCL between processes goes over dmabuf IPC (the host driver has no legacy IPC); the runtime reads this when HIP initialises, i.e.
+        # at the first torch.cuda call below, not when the process group is made
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if device is None:
             if torch.cuda.is_available():
                 torch.cuda.set_device(self.local_process_index % torch.cuda.device_count())
@@ -30,7 +33,6 @@ class RankContext:
         self._owns_group = False
         self.collectives = self.num_processes > 1 or force_collectives
         if self.collectives and not dist.is_initialized():
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # RCCL over dmabuf IPC (the host driver has no legacy IPC)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             backend = backend or ("nccl" if self.device.type == "cuda" else "gloo")
